@@ -1,0 +1,241 @@
+/* libhftt_hip.so -- C ABI of the MI355X (gfx950) hFT-Transformer hot path.
+ *
+ * The reference (d-f/nylon-amt, vendored Sony hFT-Transformer) has no FFI: its hot path is the Python
+ * classes of hftt_code/model/model_spec2midi.py driven by hftt_code/training/train.py and
+ * hftt_code/model/amt.py.  This header is the boundary a replacement binds instead of the stock
+ * torch.nn ops those classes call; every entry point cites the reference lines whose arithmetic it
+ * replaces (paths relative to /root/reference/hftt_code).  Rules of the ABI:
+ *   - extern "C", plain device pointers + sizes (+ one POD descriptor per call), no torch types;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no allocation, no sync:
+ *     the caller owns all buffers, including workspaces sized by the *_ws_bytes helpers;
+ *   - return value 0 = ok, non-zero = error (message via hftt_last_error(), thread-local);
+ *   - all activations / gradients are fp32 row-major in HBM; `npass` selects the MFMA arithmetic:
+ *       1 = bf16 operands, fp32 accumulate ("bf16" throughput mode),
+ *       3 = split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): the <=1e-3 parity mode.
+ */
+#ifndef HFTT_HIP_H
+#define HFTT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HFTT_ABI_VERSION 1
+
+int hftt_abi_version(void);
+const char* hftt_last_error(void);
+/* number of compute units of the current device (for workspace sizing on the host side) */
+int hftt_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight preparation.  fp32 parameters -> bf16 hi/lo planes in the layouts the GEMMs consume
+ * (replaces nothing in the reference: it is the operand format of the MFMA kernels).
+ * Each entry copies a [rows, cols] fp32 matrix (row stride src_ld) from `params + src_off` to
+ * planes `whi/wlo + dst_off`, either as-is (dst[r*dst_ld + c]) or transposed (dst[c*dst_ld + r]).
+ * Entries may also write fp32 copies (bias concatenation): kind 2 copies `rows*cols` floats to
+ * `fdst + dst_off`.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t src_off;   /* element offset into params */
+  int64_t dst_off;   /* element offset into the destination plane(s) */
+  int32_t rows, cols, src_ld, dst_ld;
+  int32_t kind;      /* 0 = split copy, 1 = split transposed copy, 2 = fp32 copy into fdst */
+  int32_t pad;
+} hftt_prep_entry;
+int hftt_prep_weights(const float* params, uint16_t* whi, uint16_t* wlo, float* fdst,
+                      const hftt_prep_entry* table_dev, int n_entries, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * NT GEMM with fused epilogue:  C[M,N] = epi( A[M,K] . W[N,K]^T + bias )
+ * Replaces nn.Linear in MultiHeadAttentionLayer.fc_q/k/v/o (model_spec2midi.py:328-330,357),
+ * PositionwiseFeedforwardLayer.fc_1/fc_2 (:372,375), Encoder tok_embedding_freq (:85, after the
+ * conv fold), the output heads (:172-175, :203-206) and, with transposed weights, every dX = dY.W of
+ * loss.backward() (training/train.py:158).
+ * epilogue, in this order:  v = acc + bias[col];  if act==1 v = max(v,0);  v *= out_scale;
+ *   if add_table: v += add_table[(row % add_mod)*N + col]              (position embedding, :95)
+ *   if gate:      v = gate[row*ldg+col] > 0 ? v*gate_scale : 0          (ReLU/dropout backward)
+ *   if drop_p>0:  v = keep(seed,site,row*N+col) ? v/(1-p) : 0           (nn.Dropout, :95,236,242,372)
+ *   if residual:  v += residual[(row % res_mod)*ldr + col]              (:236,242)
+ *   if ln_gamma:  pre_ln_out = v;  v = LayerNorm(v)*gamma+beta (eps 1e-5, over N; needs N in {64,128,256})
+ *                 mean/rstd written per row                              (nn.LayerNorm, :225,236)
+ *   C[row*ldc+col] = v
+ * W is given as prepared bf16 planes [N_pad, K] (K % 32 == 0, N_pad % 64 == 0, rows >= N zero).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t M, N, K, npass;
+  const float* A; int64_t lda;
+  const uint16_t* Whi; const uint16_t* Wlo;      /* [N_pad, K] */
+  const float* bias;                              /* [N] or NULL */
+  float* C; int64_t ldc;
+  int32_t act; float out_scale;
+  const float* add_table; int32_t add_mod;
+  const float* gate; int64_t ldg; float gate_scale;
+  float drop_p; uint32_t drop_site; uint64_t drop_seed;
+  const float* residual; int64_t ldr; int32_t res_mod;
+  const float* ln_gamma; const float* ln_beta; float* pre_ln_out; float* ln_mean; float* ln_rstd;
+} hftt_gemm_nt_desc;
+int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * TN GEMM (weight gradient):  dW[N,K] = out_scale * dY[M,N]^T . X[M,K],  db[N] = colsum(dY)
+ * Replaces the weight/bias gradient of every nn.Linear in loss.backward() (training/train.py:158).
+ * Two launches: partial products per M-split into `ws`, then a reduce that writes (beta=0) or
+ * accumulates (beta=1) into up to 4 row segments of the destination (fused QKV / packed heads).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t M, N, K, npass;
+  const float* dY; int64_t lddy;
+  const float* X; int64_t ldx;
+  float out_scale; float beta;
+  int32_t n_seg;
+  int32_t seg_row0[4]; int32_t seg_rows[4];
+  float* seg_dw[4];          /* [seg_rows, K] row-major (ld = K_out) */
+  float* seg_db[4];          /* [seg_rows] or NULL */
+  int32_t K_out;             /* number of K columns to write (<= K), destination leading dim */
+  int32_t pad;
+  void* ws; int64_t ws_bytes;
+} hftt_gemm_tn_desc;
+int64_t hftt_gemm_tn_ws_bytes(int32_t M, int32_t N, int32_t K);
+int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused multi-head attention, one workgroup per (sequence, head); Lq, Lk <= 256, dh in {32, 64}.
+ * forward:  P = softmax(Q K^T / sqrt(dh));  out = dropout(P) V;  lse = logsumexp rows;
+ *           probs (optional) = P (pre-dropout)         -- model_spec2midi.py:335-354, returned P :360
+ * backward: recomputes P from (Q,K,lse); dQ,dK,dV      -- autograd of the same lines
+ * Q/K/V/out element (seq, row, head, c) lives at  base + seq*seq_stride + row*ld + head*dh + c.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_seq, n_heads, Lq, Lk, dh, npass;
+  const float* q; int64_t q_seq_stride; int64_t ldq;
+  const float* k; int64_t k_seq_stride; int64_t ldk;
+  const float* v; int64_t v_seq_stride; int64_t ldv;
+  float* out; int64_t o_seq_stride; int64_t ldo;
+  float* lse;                 /* [n_seq, n_heads, Lq] */
+  float* probs;               /* [n_seq, n_heads, Lq, Lk] or NULL */
+  float drop_p; uint32_t drop_site; uint64_t drop_seed;
+  /* backward only */
+  const float* dout;          /* same layout as out */
+  float* dq; int64_t dq_seq_stride; int64_t lddq;
+  float* dk; int64_t dk_seq_stride; int64_t lddk;
+  float* dv; int64_t dv_seq_stride; int64_t lddv;
+} hftt_attn_desc;
+int hftt_attn_fwd(const hftt_attn_desc* d, void* stream);
+int hftt_attn_bwd(const hftt_attn_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder front: fold of Conv2d(1,C,(1,k)) + window flatten + Linear(C*(n_proc-k+1), d)
+ * (model_spec2midi.py:65-85) into one Linear over the n_proc-wide window:
+ *   tok[j] = sum_u Weff[j,u] * spec[f, t+u] + beff[j],
+ *   Weff[j,u] = sum_{c, kk, w+kk=u} Wtok[j, c*nw + w] * wconv[c,kk],  beff[j] = btok[j] + sum_c bconv[c] sum_w Wtok[j,c*nw+w]
+ * fold_fwd writes Weff as bf16 hi/lo planes [d_pad, Kp] (Kp = n_proc rounded up to 32, zero padded) + beff.
+ * fold_bwd maps (dWeff [d, Kp] fp32, dbeff [d]) back to the four reference parameters' gradients.
+ * im2win materialises A[(b,t,f), u] = spec[b, f, t+u] (zero for u >= n_proc), row stride Kp.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t d, C, kw, n_proc, Kp, d_pad;
+  const float* wconv;   /* [C, kw] */
+  const float* bconv;   /* [C] */
+  const float* wtok;    /* [d, C*(n_proc-kw+1)] */
+  const float* btok;    /* [d] */
+  uint16_t* weff_hi; uint16_t* weff_lo;   /* [d_pad, Kp] */
+  float* beff;          /* [d] */
+  /* backward */
+  const float* dweff;   /* [d, Kp] */
+  const float* dbeff;   /* [d] */
+  float* g_wconv; float* g_bconv; float* g_wtok; float* g_btok;
+} hftt_fold_desc;
+int hftt_embed_fold_fwd(const hftt_fold_desc* d, void* stream);
+int hftt_embed_fold_bwd(const hftt_fold_desc* d, void* stream);
+int hftt_im2win(const float* spec, float* win, int32_t B, int32_t F, int32_t T, int32_t n_proc, int32_t Kp, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm backward (shared gamma/beta per layer, model_spec2midi.py:225,250,277):
+ *   dr = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy*gamma,  xhat = (r-mean)*rstd
+ *   dr_drop (optional) = dropout-masked dr for the residual branch (site/seed of the forward dropout)
+ *   partial dgamma/dbeta per workgroup -> ws; hftt_ln_bwd_reduce sums them into the parameter grads.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t M, N;
+  const float* dy; const float* r; const float* mean; const float* rstd; const float* gamma;
+  float* dr; float* dr_drop;
+  float drop_p; uint32_t drop_site; uint64_t drop_seed;
+  float* ws;            /* [n_wg, 2, N] partial sums; n_wg = hftt_ln_bwd_wgs(M) */
+} hftt_ln_bwd_desc;
+int32_t hftt_ln_bwd_wgs(int32_t M);
+int hftt_ln_bwd(const hftt_ln_bwd_desc* d, void* stream);
+int hftt_ln_bwd_reduce(const float* ws, int32_t n_wg, int32_t N, float* dgamma, float* dbeta, float beta, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small data-movement kernels of the decoder (model_spec2midi.py:189-191, :172-175, :203-206).
+ * --------------------------------------------------------------------------------------------- */
+/* y[(b,n), t, :] = dropout( x[(b,t), n, :]*scale + pos[t, :] )  */
+int hftt_time_embed_fwd(const float* x, const float* pos, float* y, int32_t B, int32_t T, int32_t Nn, int32_t d,
+                        float scale, float drop_p, uint32_t site, uint64_t seed, void* stream);
+/* dx[(b,t), n, :] (+)= mask*dy[(b,n), t, :]*scale ; dym (optional, [(b,n),t,:]) = masked dy (for the pos-emb colsum) */
+int hftt_time_embed_bwd(const float* dy, float* dx, float* dym, int32_t B, int32_t T, int32_t Nn, int32_t d,
+                        float scale, float drop_p, uint32_t site, uint64_t seed, int32_t accumulate, void* stream);
+/* in-place dropout backward: g *= mask/(1-p) (same indexing as the forward epilogue: idx = row*N+col) */
+int hftt_dropout_bwd(float* g, int64_t n, float drop_p, uint32_t site, uint64_t seed, void* stream);
+/* colsum: out[j] = beta*out[j] + sum_r x[r*ld + j], j < n */
+int hftt_colsum(const float* x, int64_t rows, int64_t n, int64_t ld, float* out, float beta, float* ws, void* stream);
+int64_t hftt_colsum_ws_bytes(int64_t rows, int64_t n);
+/* heads: logits [S, ldl] with cols [0,V) velocity, V onset, V+1 offset, V+2 mpe ->
+ *   velocity [.,V] raw, onset/offset/mpe sigmoid; time_major!=0: rows are (b,n,t) and outputs are (b,t,n). */
+int hftt_heads_split(const float* logits, int64_t ldl, float* onset, float* offset, float* mpe, float* velocity,
+                     int32_t B, int32_t T, int32_t Nn, int32_t V, int32_t time_major, void* stream);
+/* backward of hftt_heads_split: dlogits[., ldl] from d(onset,offset,mpe probabilities) and d(velocity logits) */
+int hftt_heads_split_bwd(const float* p_onset, const float* p_offset, const float* p_mpe,
+                         const float* d_onset, const float* d_offset, const float* d_mpe, const float* d_velocity,
+                         float* dlogits, int64_t ldl, int32_t B, int32_t T, int32_t Nn, int32_t V, int32_t time_major,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss (training/train.py:141-153): 6x BCELoss(mean) + 2x CrossEntropyLoss(mean), weighted sum.
+ * loss_out[0] = total, [1..8] = the eight terms.  Gradients w.r.t. the eight model outputs are
+ * written when the d_* pointers are non-NULL (scaled by grad_scale, normally 1).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t n;            /* B*T*Nn label elements */
+  int32_t V; int32_t pad;
+  const float* prob[6]; /* onset_A, offset_A, mpe_A, onset_B, offset_B, mpe_B : [n] */
+  const float* vel[2];  /* velocity_A, velocity_B : [n, V] logits */
+  const float* label_onset; const float* label_offset; const float* label_mpe; const int64_t* label_velocity;
+  float weight_A, weight_B, grad_scale; float pad2;
+  float* d_prob[6]; float* d_vel[2];
+  float* loss_out;      /* [9] */
+  float* ws;            /* hftt_loss_ws_bytes(n) */
+} hftt_loss_desc;
+int64_t hftt_loss_ws_bytes(int64_t n);
+int hftt_loss(const hftt_loss_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused Adam over one flat parameter buffer (torch.optim.Adam defaults, m_training.py:146):
+ *   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * --------------------------------------------------------------------------------------------- */
+int hftt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Log-mel front end (model/amt.py:55-63 after resampling): frames of n_fft with hop, centred,
+ * zero padded, periodic hann, |rDFT|^2, sparse slaney/htk mel filterbank, log(. + offset).
+ * feat [n_frames, n_mels], n_frames = 1 + n_samples/hop.  fb is given in CSR-by-mel form.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* wave; int64_t n_samples;
+  int32_t n_fft, hop, n_mels, n_frames;
+  const float* window;       /* [n_fft] */
+  const float* twiddle;      /* [n_fft/2] cos, then [n_fft/2] sin of 2*pi*k/n_fft */
+  const int32_t* fb_start;   /* [n_mels] first frequency bin of each mel filter */
+  const int32_t* fb_len;     /* [n_mels] number of bins */
+  const int32_t* fb_off;     /* [n_mels] offset into fb_w */
+  const float* fb_w;         /* packed weights */
+  float log_offset; int32_t pad;
+  float* feat;
+} hftt_logmel_desc;
+int hftt_logmel(const hftt_logmel_desc* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HFTT_HIP_H */

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Build libhftt_hip.so (gfx950) in-tree with hipcc.  Usage: python nylon-amt_amd/build.py [--force]
+
+Objects are rebuilt only when their source (or a shared header) is newer.  The .so stays in-tree
+(git-ignored) so it travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+OBJDIR = os.path.join(HERE, 'build')
+LIB = os.path.join(LIBDIR, 'libhftt_hip.so')
+SOURCES = ['capi.cpp', 'gemm_nt.hip', 'gemm_tn.hip', 'attn_fwd.hip', 'attn_bwd.hip', 'elementwise.hip', 'logmel.hip']
+HEADERS = [os.path.join(CSRC, 'hftt_common.h'), os.path.join(CSRC, 'hftt_host.h'),
+           os.path.join(HERE, '..', 'include', 'hftt_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + HEADERS):
+        cmd = [_hipcc()] + FLAGS + ['-x', 'hip', '-c', path, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-6000:]))
+    return obj
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJDIR):
+            os.remove(os.path.join(OBJDIR, f))
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+        if verbose:
+            print('built', LIB)
+    elif verbose:
+        print('up to date', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

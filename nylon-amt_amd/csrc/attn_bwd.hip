@@ -1,0 +1,286 @@
+// Fused multi-head attention backward (gfx950), one workgroup per (sequence, head), one wave per 32 keys.
+//   recompute P = exp(Q K^T/sqrt(dh) - lse);  dP = dO V^T;  dS = P*(dP - rowsum(dO*O))/sqrt(dh)
+//   dV = Pd^T dO,  dK = dS^T Q,  dQ = dS K                                  -- include/hftt_hip.h (hftt_attn_bwd)
+// Layout choices (all lane maps verified by tools/probe_mfma):
+//   * S and dP are produced with the KEY on the MFMA lane (B operand = this wave's K / V rows, held in registers for
+//     the whole kernel), so P and dS accumulator tiles are directly the B operands of dV^T += dO^T.P and
+//     dK^T += Q^T.dS (accumulator-as-operand, probe T4 "Y = A2*X"); dK^T/dV^T never leave the wave's registers.
+//   * only dS crosses LDS (bf16 [query][key] image) for dQ = dS.K, computed with 16x16x32 tiles spread over the waves;
+//     K for that product is the row-major LDS image read through ds_read_b64_tr_b16.
+//   * Q and dO blocks (32 rows) are staged per iteration; their transposes are again tr reads of the same image.
+#include "hftt_common.h"
+#include "hftt_host.h"
+#include "../../include/hftt_hip.h"
+#include <math.h>
+
+int hftt_attn_check(const hftt_attn_desc* d, bool bwd);
+
+namespace {
+
+template <int KT, int DH, int NPASS>
+struct AbCfg {
+  static constexpr int LKP = KT * 32;
+  static constexpr int PL = (NPASS == 3) ? 2 : 1;
+  static constexpr int RSK = (DH == 64) ? 96 : 32;   // tr-read friendly (64 mod 128 bytes)
+  static constexpr int RSQ = DH + 8;                 // b128-read friendly
+  static constexpr int RSS = LKP + 8;
+  static constexpr int K_ELEMS = LKP * RSK;
+  static constexpr int Q_ELEMS = 32 * RSQ;
+  static constexpr int S_ELEMS = 32 * RSS;
+  static constexpr int SHORTS = PL * (K_ELEMS + 2 * Q_ELEMS + S_ELEMS);
+  static constexpr int LDS_BYTES = SHORTS * 2 + 64 * 4;
+  static constexpr int NTHR = KT * 64;
+};
+
+template <int KT, int DH, int NPASS>
+__global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc g) {
+  using Cfg = AbCfg<KT, DH, NPASS>;
+  constexpr int PL = Cfg::PL, RSK = Cfg::RSK, RSQ = Cfg::RSQ, RSS = Cfg::RSS, LKP = Cfg::LKP, NTHR = Cfg::NTHR;
+  constexpr int KS = DH / 16, NT = DH / 32, F4R = DH / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* sm = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Ks[2] = {sm, sm + (PL - 1) * Cfg::K_ELEMS};
+  unsigned short* Qs[2] = {sm + PL * Cfg::K_ELEMS, sm + PL * Cfg::K_ELEMS + (PL - 1) * Cfg::Q_ELEMS};
+  unsigned short* Os[2] = {Qs[0] + PL * Cfg::Q_ELEMS, Qs[0] + PL * Cfg::Q_ELEMS + (PL - 1) * Cfg::Q_ELEMS};
+  unsigned short* Ss[2] = {Os[0] + PL * Cfg::Q_ELEMS, Os[0] + PL * Cfg::Q_ELEMS + (PL - 1) * Cfg::S_ELEMS};
+  float* lse_s = reinterpret_cast<float*>(sm + Cfg::SHORTS);
+  float* delta_s = lse_s + 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int gi = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
+  const int Lq = g.Lq, Lk = g.Lk;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+
+  auto pack4 = [&](const float4& f, uint2& ph, uint2& pl) {
+    const float v[4] = {f.x, f.y, f.z, f.w};
+    unsigned short hi[4], lo[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (PL == 2) split_bf16(v[e], hi[e], lo[e]); else hi[e] = f2bf(v[e]);
+    }
+    ph.x = hi[0] | ((unsigned)hi[1] << 16); ph.y = hi[2] | ((unsigned)hi[3] << 16);
+    pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16);
+  };
+
+  const float* kb = g.k + (long)seq * g.k_seq_stride + head * DH;
+  const float* vb = g.v + (long)seq * g.v_seq_stride + head * DH;
+  // ---- stage all of K (bf16 planes, row-major) for the dQ product ----
+  for (int i = tid; i < LKP * F4R; i += NTHR) {
+    const int key = i / F4R, c4 = i % F4R;
+    float4 kf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (key < Lk) kf = *reinterpret_cast<const float4*>(kb + (long)key * g.ldk + c4 * 4);
+    uint2 ph, pl;
+    pack4(kf, ph, pl);
+    *reinterpret_cast<uint2*>(Ks[0] + key * RSK + c4 * 4) = ph;
+    if (PL == 2) *reinterpret_cast<uint2*>(Ks[PL - 1] + key * RSK + c4 * 4) = pl;
+  }
+  // ---- this wave's K and V rows as B-operand fragments (B[k = dh][col = key]) ----
+  const int mykey = wave * 32 + lr;
+  bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    float kv[8], vv[8];
+    if (mykey < Lk) {
+      const float4 a0 = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + 16 * s + 8 * lh);
+      const float4 a1 = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + 16 * s + 8 * lh + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + 16 * s + 8 * lh);
+      const float4 b1 = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + 16 * s + 8 * lh + 4);
+      kv[0] = a0.x; kv[1] = a0.y; kv[2] = a0.z; kv[3] = a0.w; kv[4] = a1.x; kv[5] = a1.y; kv[6] = a1.z; kv[7] = a1.w;
+      vv[0] = b0.x; vv[1] = b0.y; vv[2] = b0.z; vv[3] = b0.w; vv[4] = b1.x; vv[5] = b1.y; vv[6] = b1.z; vv[7] = b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      unsigned short h1, l1 = 0, h2, l2 = 0;
+      if (PL == 2) { split_bf16(kv[e], h1, l1); split_bf16(vv[e], h2, l2); }
+      else { h1 = f2bf(kv[e]); h2 = f2bf(vv[e]); }
+      kfh[s][e] = (short)h1; kfl[s][e] = (short)l1; vfh[s][e] = (short)h2; vfl[s][e] = (short)l2;
+    }
+  }
+  f32x16 dKT[NT], dVT[NT];
+#pragma unroll
+  for (int n = 0; n < NT; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dKT[n][r] = 0.f; dVT[n][r] = 0.f; }
+
+  const float* qbase = g.q + (long)seq * g.q_seq_stride + head * DH;
+  const float* obase = g.out + (long)seq * g.o_seq_stride + head * DH;
+  const float* dobase = g.dout + (long)seq * g.o_seq_stride + head * DH;
+  float* dqbase = g.dq + (long)seq * g.dq_seq_stride + head * DH;
+  const long sh = (long)seq * g.n_heads + head;
+  const int nqb = (Lq + 31) / 32;
+
+  for (int qb = 0; qb < nqb; qb++) {
+    // ---- (a) stage the Q and dO blocks, delta = rowsum(dO*O), lse ----
+    for (int i = tid; i < 32 * F4R; i += NTHR) {
+      const int row = i / F4R, c4 = i % F4R;
+      const int q = qb * 32 + row;
+      float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), df = qf, of = qf;
+      if (q < Lq) {
+        qf = *reinterpret_cast<const float4*>(qbase + (long)q * g.ldq + c4 * 4);
+        df = *reinterpret_cast<const float4*>(dobase + (long)q * g.ldo + c4 * 4);
+        of = *reinterpret_cast<const float4*>(obase + (long)q * g.ldo + c4 * 4);
+      }
+      uint2 ph, pl;
+      pack4(qf, ph, pl);
+      *reinterpret_cast<uint2*>(Qs[0] + row * RSQ + c4 * 4) = ph;
+      if (PL == 2) *reinterpret_cast<uint2*>(Qs[PL - 1] + row * RSQ + c4 * 4) = pl;
+      pack4(df, ph, pl);
+      *reinterpret_cast<uint2*>(Os[0] + row * RSQ + c4 * 4) = ph;
+      if (PL == 2) *reinterpret_cast<uint2*>(Os[PL - 1] + row * RSQ + c4 * 4) = pl;
+      float dot = df.x * of.x + df.y * of.y + df.z * of.z + df.w * of.w;
+#pragma unroll
+      for (int o = F4R / 2; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+      if (c4 == 0) {
+        delta_s[row] = dot;
+        lse_s[row] = (q < Lq) ? g.lse[sh * Lq + q] : 0.f;
+      }
+    }
+    __syncthreads();   // (b)
+
+    // ---- (c) S tile and (d) dP tile: rows = queries (registers), column = this lane's key ----
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int off = lr * RSQ + 16 * s + 8 * lh;
+      const bf16x8 qh = lds_read_b128(Qs[0] + off);
+      const bf16x8 ql = (PL == 2) ? lds_read_b128(Qs[PL - 1] + off) : qh;
+      sacc = mfma32_split<NPASS>(qh, ql, kfh[s], kfl[s], sacc);
+      const bf16x8 oh = lds_read_b128(Os[0] + off);
+      const bf16x8 ol = (PL == 2) ? lds_read_b128(Os[PL - 1] + off) : oh;
+      pacc = mfma32_split<NPASS>(oh, ol, vfh[s], vfl[s], pacc);
+    }
+    const bool key_ok = mykey < Lk;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int ql_ = acc_row32(r, lh);
+      const float arg = sacc[r] * scale - lse_s[ql_];
+      float p = (NPASS == 3) ? expf(arg) : __expf(arg);
+      if (!key_ok) p = 0.f;
+      float pd = p, dp = pacc[r];
+      if (g.drop_p > 0.f) {
+        const long q = qb * 32 + ql_;
+        const bool keep = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)((sh * Lq + q) * (long)Lk + mykey), thr);
+        pd = keep ? p * inv_keep : 0.f;
+        dp = keep ? dp * inv_keep : 0.f;
+      }
+      sacc[r] = pd;                                        // dropped probabilities (for dV)
+      pacc[r] = p * (dp - delta_s[ql_]) * scale;           // dS (scaled): for dK, dQ
+    }
+    // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS ----
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      bf16x8 ph, pl, sh_, sl_;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        unsigned short h1, l1 = 0, h2, l2 = 0;
+        if (PL == 2) { split_bf16(sacc[8 * s2 + e], h1, l1); split_bf16(pacc[8 * s2 + e], h2, l2); }
+        else { h1 = f2bf(sacc[8 * s2 + e]); h2 = f2bf(pacc[8 * s2 + e]); }
+        ph[e] = (short)h1; pl[e] = (short)l1; sh_[e] = (short)h2; sl_[e] = (short)l2;
+      }
+#pragma unroll
+      for (int n = 0; n < NT; n++) {
+        const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
+        const int r0 = 16 * s2 + 4 * lh + qq;
+        const bf16x8 oh = join4(lds_read_tr16(Os[0] + r0 * RSQ + col), lds_read_tr16(Os[0] + (r0 + 8) * RSQ + col));
+        const bf16x8 ol = (PL == 2) ? join4(lds_read_tr16(Os[PL - 1] + r0 * RSQ + col), lds_read_tr16(Os[PL - 1] + (r0 + 8) * RSQ + col)) : oh;
+        dVT[n] = mfma32_split<NPASS>(oh, ol, ph, pl, dVT[n]);
+        const bf16x8 qh = join4(lds_read_tr16(Qs[0] + r0 * RSQ + col), lds_read_tr16(Qs[0] + (r0 + 8) * RSQ + col));
+        const bf16x8 ql = (PL == 2) ? join4(lds_read_tr16(Qs[PL - 1] + r0 * RSQ + col), lds_read_tr16(Qs[PL - 1] + (r0 + 8) * RSQ + col)) : qh;
+        dKT[n] = mfma32_split<NPASS>(qh, ql, sh_, sl_, dKT[n]);
+      }
+    }
+    // ---- (g) dS -> LDS [query][key] ----
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      unsigned short h1, l1 = 0;
+      if (PL == 2) split_bf16(pacc[r], h1, l1); else h1 = f2bf(pacc[r]);
+      const int off = acc_row32(r, lh) * RSS + wave * 32 + lr;
+      Ss[0][off] = h1;
+      if (PL == 2) Ss[PL - 1][off] = l1;
+    }
+    __syncthreads();   // (h)
+
+    // ---- (i) dQ block = dS . K with 16x16x32 tiles spread over the waves ----
+    constexpr int CT = DH / 16;
+    for (int t = wave; t < 2 * CT; t += KT) {
+      const int qh2 = t / CT, ct = t % CT;
+      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KT; ks++) {
+        const int aoff = (qh2 * 16 + (lane & 15)) * RSS + ks * 32 + 8 * gi;
+        const bf16x8 ah = lds_read_b128(Ss[0] + aoff);
+        const bf16x8 al = (PL == 2) ? lds_read_b128(Ss[PL - 1] + aoff) : ah;
+        const int krow = ks * 32 + 8 * gi + qq;
+        const int kcol = ct * 16 + 4 * pp;
+        const bf16x8 bh = join4(lds_read_tr16(Ks[0] + krow * RSK + kcol), lds_read_tr16(Ks[0] + (krow + 4) * RSK + kcol));
+        const bf16x8 bl = (PL == 2) ? join4(lds_read_tr16(Ks[PL - 1] + krow * RSK + kcol), lds_read_tr16(Ks[PL - 1] + (krow + 4) * RSK + kcol)) : bh;
+        a4 = mfma16_split<NPASS>(ah, al, bh, bl, a4);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int q = qb * 32 + qh2 * 16 + gi * 4 + r;
+        if (q < Lq) dqbase[(long)q * g.lddq + ct * 16 + (lane & 15)] = a4[r];
+      }
+    }
+    // no barrier needed here: the next iteration's staging touches only Qs/Os/lse/delta, which no wave reads in (i);
+    // barrier (b) of the next iteration orders (i) before the next (g).
+  }
+
+  // ---- epilogue: dK, dV (this wave's 32 keys) ----
+  if (mykey < Lk) {
+    float* dkb = g.dk + (long)seq * g.dk_seq_stride + (long)mykey * g.lddk + head * DH;
+    float* dvb = g.dv + (long)seq * g.dv_seq_stride + (long)mykey * g.lddv + head * DH;
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int dh0 = n * 32 + 8 * c + 4 * lh;
+        *reinterpret_cast<float4*>(dkb + dh0) = make_float4(dKT[n][4 * c], dKT[n][4 * c + 1], dKT[n][4 * c + 2], dKT[n][4 * c + 3]);
+        *reinterpret_cast<float4*>(dvb + dh0) = make_float4(dVT[n][4 * c], dVT[n][4 * c + 1], dVT[n][4 * c + 2], dVT[n][4 * c + 3]);
+      }
+  }
+}
+
+template <int KT, int DH, int NPASS>
+int launch_ab(const hftt_attn_desc& d, hipStream_t st) {
+  using Cfg = AbCfg<KT, DH, NPASS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT, DH, NPASS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) { hftt_set_error("attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_kernel<KT, DH, NPASS>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, d);
+  HFTT_CHECK_LAUNCH("attn_bwd");
+  return 0;
+}
+
+template <int DH, int NPASS>
+int dispatch_ab(const hftt_attn_desc& d, hipStream_t st) {
+  const int kt = (d.Lk + 31) / 32;
+  if (kt <= 1) return launch_ab<1, DH, NPASS>(d, st);
+  if (kt <= 2) return launch_ab<2, DH, NPASS>(d, st);
+  if (kt <= 3) return launch_ab<3, DH, NPASS>(d, st);
+  if (kt <= 4) return launch_ab<4, DH, NPASS>(d, st);
+  return launch_ab<8, DH, NPASS>(d, st);
+}
+
+}  // namespace
+
+extern "C" int hftt_attn_bwd(const hftt_attn_desc* d, void* stream) {
+  int rc = hftt_attn_check(d, true);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dh == 64) return d->npass == 3 ? dispatch_ab<64, 3>(*d, st) : dispatch_ab<64, 1>(*d, st);
+  return d->npass == 3 ? dispatch_ab<32, 3>(*d, st) : dispatch_ab<32, 1>(*d, st);
+}

@@ -1,0 +1,261 @@
+// Fused multi-head attention forward (gfx950), one workgroup per (sequence, head).
+//   P = softmax(Q K^T / sqrt(dh)),  out = dropout(P) V,  lse = logsumexp       -- include/hftt_hip.h (hftt_attn_fwd)
+// Sequence lengths on this path are fixed and short (256 bins / 88 notes / 128 frames), so the whole K/V of a
+// (sequence, head) is staged once in LDS as bf16 (hi[/lo]) and each wave owns 32 query rows at a time:
+//   S^T tile = mfma(A = K rows from LDS, B = Q rows in registers): lane = one query, its keys in the 16 accumulator
+//   registers  -> the softmax row reduction is register-local plus ONE cross-half shuffle (lane ^ 32);
+//   the probability tile is then fed straight back as the A operand of the PV product (accumulator-as-operand,
+//   probe T4), V fragments come from the row-major LDS image through ds_read_b64_tr_b16 (probe T5).
+#include "hftt_common.h"
+#include "hftt_host.h"
+#include "../../include/hftt_hip.h"
+#include <math.h>
+
+namespace {
+
+template <int KT, int DH, int NPASS>
+struct AfCfg {
+  static constexpr int LKP = KT * 32;
+  static constexpr int PL = (NPASS == 3) ? 2 : 1;
+  static constexpr int RSK = DH + 8;   // bf16 elements: 144 B / 80 B rows, conflict-free ds_read_b128
+  // tr16 reads are conflict-free when the row stride is 64 (mod 128) bytes; the 256-key, dh=64 parity build
+  // falls back to 144 B rows (2-way conflicts) to fit 160 KiB.
+  static constexpr int RSV = (DH == 64) ? ((NPASS == 3 && KT == 8) ? 72 : 96) : 32;
+  static constexpr int K_ELEMS = LKP * RSK;
+  static constexpr int V_ELEMS = LKP * RSV;
+  static constexpr int LDS_BYTES = PL * (K_ELEMS + V_ELEMS) * 2;
+};
+
+template <int KT, int DH, int NPASS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
+  using Cfg = AfCfg<KT, DH, NPASS>;
+  constexpr int PL = Cfg::PL, RSK = Cfg::RSK, RSV = Cfg::RSV, LKP = Cfg::LKP;
+  constexpr int KS = DH / 16;   // k-steps of the QK^T product
+  constexpr int NT = DH / 32;   // output column tiles
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* sm = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Ks[2] = {sm, sm + (PL - 1) * Cfg::K_ELEMS};
+  unsigned short* Vs[2] = {sm + PL * Cfg::K_ELEMS, sm + PL * Cfg::K_ELEMS + (PL - 1) * Cfg::V_ELEMS};
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int gi = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
+  const int Lq = g.Lq, Lk = g.Lk;
+
+  // ---- stage K and V of this (seq, head) into LDS as bf16 planes ----
+  {
+    const float* kb = g.k + (long)seq * g.k_seq_stride + head * DH;
+    const float* vb = g.v + (long)seq * g.v_seq_stride + head * DH;
+    constexpr int F4R = DH / 4;
+    for (int i = tid; i < LKP * F4R; i += 256) {
+      const int key = i / F4R, c4 = i % F4R;
+      float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
+      if (key < Lk) {
+        kf = *reinterpret_cast<const float4*>(kb + (long)key * g.ldk + c4 * 4);
+        vf = *reinterpret_cast<const float4*>(vb + (long)key * g.ldv + c4 * 4);
+      }
+      const float kv[4] = {kf.x, kf.y, kf.z, kf.w};
+      const float vv[4] = {vf.x, vf.y, vf.z, vf.w};
+      unsigned short khi[4], klo[4], vhi[4], vlo[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (PL == 2) { split_bf16(kv[e], khi[e], klo[e]); split_bf16(vv[e], vhi[e], vlo[e]); }
+        else { khi[e] = f2bf(kv[e]); vhi[e] = f2bf(vv[e]); }
+      }
+      uint2 w;
+      w.x = khi[0] | ((unsigned)khi[1] << 16); w.y = khi[2] | ((unsigned)khi[3] << 16);
+      *reinterpret_cast<uint2*>(Ks[0] + key * RSK + c4 * 4) = w;
+      w.x = vhi[0] | ((unsigned)vhi[1] << 16); w.y = vhi[2] | ((unsigned)vhi[3] << 16);
+      *reinterpret_cast<uint2*>(Vs[0] + key * RSV + c4 * 4) = w;
+      if (PL == 2) {
+        w.x = klo[0] | ((unsigned)klo[1] << 16); w.y = klo[2] | ((unsigned)klo[3] << 16);
+        *reinterpret_cast<uint2*>(Ks[PL - 1] + key * RSK + c4 * 4) = w;
+        w.x = vlo[0] | ((unsigned)vlo[1] << 16); w.y = vlo[2] | ((unsigned)vlo[3] << 16);
+        *reinterpret_cast<uint2*>(Vs[PL - 1] + key * RSV + c4 * 4) = w;
+      }
+    }
+  }
+  __syncthreads();
+
+  const float scale = 1.0f / sqrtf((float)DH);
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const int nqb = (Lq + 31) / 32;
+  const bool vec_probs = (Lk % 4) == 0;
+
+  for (int qb = wave; qb < nqb; qb += 4) {
+    const int qrow = qb * 32 + lr;                     // this lane's query (as the B-operand column)
+    const int qrow_c = qrow < Lq ? qrow : Lq - 1;
+    const float* qp = g.q + (long)seq * g.q_seq_stride + (long)qrow_c * g.ldq + head * DH;
+    bf16x8 qh[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const float4 f0 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * lh);
+      const float4 f1 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * lh + 4);
+      const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        unsigned short hi, lo = 0;
+        const float x = v[e] * scale;
+        if (PL == 2) split_bf16(x, hi, lo); else hi = f2bf(x);
+        qh[s][e] = (short)hi; ql[s][e] = (short)lo;
+      }
+    }
+    // ---- S^T = K . Q^T  (rows = keys in registers, column = this lane's query) ----
+    f32x16 sacc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) sacc[kt][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        const int off = (kt * 32 + lr) * RSK + 16 * s + 8 * lh;
+        const bf16x8 kh = lds_read_b128(Ks[0] + off);
+        const bf16x8 kl = (PL == 2) ? lds_read_b128(Ks[PL - 1] + off) : kh;
+        sacc[kt] = mfma32_split<NPASS>(kh, kl, qh[s], ql[s], sacc[kt]);
+      }
+    }
+    // ---- softmax over keys (register-local + one cross-half exchange) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = kt * 32 + acc_row32(r, lh);
+        if (key >= Lk) sacc[kt][r] = -INFINITY;
+        mx = fmaxf(mx, sacc[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float p = (NPASS == 3) ? expf(sacc[kt][r] - mx) : __expf(sacc[kt][r] - mx);
+        sacc[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (lh == 0 && qrow < Lq) g.lse[((long)seq * g.n_heads + head) * Lq + qrow] = mx + logf(sum);
+
+    const long prow = (((long)seq * g.n_heads + head) * Lq + qrow) * (long)Lk;   // element index base of this query's row
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float p4[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) p4[e] = sacc[kt][4 * c + e] * inv;
+        const int key0 = kt * 32 + 8 * c + 4 * lh;
+        if (g.probs != nullptr && qrow < Lq) {
+          if (vec_probs && key0 + 3 < Lk) {
+            *reinterpret_cast<float4*>(g.probs + prow + key0) = make_float4(p4[0], p4[1], p4[2], p4[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (key0 + e < Lk) g.probs[prow + key0 + e] = p4[e];
+          }
+        }
+        if (g.drop_p > 0.f) {
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            p4[e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(prow + key0 + e), thr) ? p4[e] * inv_keep : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) sacc[kt][4 * c + e] = p4[e];
+      }
+    }
+    // ---- out = P . V  (probability tile reused as the A operand; keys are the reduction index) ----
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[n][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 xh, xl;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          unsigned short hi, lo = 0;
+          const float x = sacc[kt][8 * s2 + e];
+          if (PL == 2) split_bf16(x, hi, lo); else hi = f2bf(x);
+          xh[e] = (short)hi; xl[e] = (short)lo;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+          const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
+          const int r0 = kt * 32 + 16 * s2 + 4 * lh + qq;     // + 8 for the second half of the fragment
+          const bf16x8 vh = join4(lds_read_tr16(Vs[0] + r0 * RSV + col), lds_read_tr16(Vs[0] + (r0 + 8) * RSV + col));
+          const bf16x8 vl = (PL == 2) ? join4(lds_read_tr16(Vs[PL - 1] + r0 * RSV + col), lds_read_tr16(Vs[PL - 1] + (r0 + 8) * RSV + col)) : vh;
+          oacc[n] = mfma32_split<NPASS>(xh, xl, vh, vl, oacc[n]);
+        }
+      }
+    }
+    float* ob = g.out + (long)seq * g.o_seq_stride + head * DH;
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int q = qb * 32 + acc_row32(r, lh);
+        if (q < Lq) ob[(long)q * g.ldo + n * 32 + lr] = oacc[n][r];
+      }
+  }
+}
+
+template <int KT, int DH, int NPASS>
+int launch_af(const hftt_attn_desc& d, hipStream_t st) {
+  using Cfg = AfCfg<KT, DH, NPASS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT, DH, NPASS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) { hftt_set_error("attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<KT, DH, NPASS>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(256), Cfg::LDS_BYTES, st, d);
+  HFTT_CHECK_LAUNCH("attn_fwd");
+  return 0;
+}
+
+template <int DH, int NPASS>
+int dispatch_af(const hftt_attn_desc& d, hipStream_t st) {
+  const int kt = (d.Lk + 31) / 32;
+  if (kt <= 1) return launch_af<1, DH, NPASS>(d, st);
+  if (kt <= 2) return launch_af<2, DH, NPASS>(d, st);
+  if (kt <= 3) return launch_af<3, DH, NPASS>(d, st);
+  if (kt <= 4) return launch_af<4, DH, NPASS>(d, st);
+  return launch_af<8, DH, NPASS>(d, st);
+}
+
+}  // namespace
+
+int hftt_attn_check(const hftt_attn_desc* d, bool bwd) {
+  HFTT_REQUIRE(d != nullptr, "attn: null descriptor");
+  HFTT_REQUIRE(d->n_seq > 0 && d->n_heads > 0, "attn: bad batch");
+  HFTT_REQUIRE(d->Lq >= 1 && d->Lq <= 256 && d->Lk >= 1 && d->Lk <= 256, "attn: Lq=%d Lk=%d must be in 1..256", d->Lq, d->Lk);
+  HFTT_REQUIRE(d->dh == 32 || d->dh == 64, "attn: head_dim=%d must be 32 or 64", d->dh);
+  HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "attn: npass must be 1 or 3");
+  HFTT_REQUIRE(d->q && d->k && d->v && d->out && d->lse, "attn: null operand");
+  HFTT_REQUIRE(d->ldq % 4 == 0 && d->ldk % 4 == 0 && d->ldv % 4 == 0 && d->ldo % 4 == 0, "attn: row strides must be multiples of 4");
+  HFTT_REQUIRE(d->q_seq_stride % 4 == 0 && d->k_seq_stride % 4 == 0 && d->v_seq_stride % 4 == 0, "attn: seq strides must be multiples of 4");
+  HFTT_REQUIRE((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 15) == 0, "attn: operands must be 16-byte aligned");
+  HFTT_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "attn: drop_p out of range");
+  if (bwd) {
+    HFTT_REQUIRE(d->dout && d->dq && d->dk && d->dv, "attn_bwd: null gradient operand");
+    HFTT_REQUIRE(d->lddq % 4 == 0 && d->lddk % 4 == 0 && d->lddv % 4 == 0, "attn_bwd: row strides must be multiples of 4");
+    HFTT_REQUIRE((((uintptr_t)d->dout | (uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 15) == 0, "attn_bwd: operands must be 16-byte aligned");
+  }
+  return 0;
+}
+
+extern "C" int hftt_attn_fwd(const hftt_attn_desc* d, void* stream) {
+  int rc = hftt_attn_check(d, false);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dh == 64) return d->npass == 3 ? dispatch_af<64, 3>(*d, st) : dispatch_af<64, 1>(*d, st);
+  return d->npass == 3 ? dispatch_af<32, 3>(*d, st) : dispatch_af<32, 1>(*d, st);
+}

@@ -1,0 +1,25 @@
+// C ABI plumbing: version, thread-local error string, device query.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/hftt_hip.h"
+#include "hftt_host.h"
+
+static thread_local char g_err[512] = "";
+
+void hftt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int hftt_abi_version(void) { return HFTT_ABI_VERSION; }
+extern "C" const char* hftt_last_error(void) { return g_err; }
+extern "C" int hftt_device_cus(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
+  return p.multiProcessorCount;
+}

@@ -1,0 +1,594 @@
+// HBM-bound helper kernels of the hFT-Transformer path (gfx950): weight preparation, encoder-front fold,
+// window materialisation, LayerNorm backward, decoder transposes, output heads, fused loss, fused Adam.
+// All of them stream fp32 with 16-byte accesses where the layout allows; reductions are two-stage and
+// deterministic (no float atomics).  Entry points and reference citations: include/hftt_hip.h.
+#include "hftt_common.h"
+#include "hftt_host.h"
+#include "../../include/hftt_hip.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------ weight preparation
+__global__ void prep_weights_kernel(const float* __restrict__ params, uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo,
+                                    float* __restrict__ fdst, const hftt_prep_entry* __restrict__ table) {
+  const hftt_prep_entry e = table[blockIdx.x];
+  const long total = (long)e.rows * e.cols;
+  for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.y * blockDim.x) {
+    const int r = (int)(i / e.cols), c = (int)(i % e.cols);
+    const float x = params[e.src_off + (long)r * e.src_ld + c];
+    if (e.kind == 2) {
+      fdst[e.dst_off + (long)r * e.dst_ld + c] = x;
+    } else {
+      const long d = (e.kind == 1) ? (e.dst_off + (long)c * e.dst_ld + r) : (e.dst_off + (long)r * e.dst_ld + c);
+      unsigned short hi, lo;
+      split_bf16(x, hi, lo);
+      whi[d] = hi;
+      if (wlo != nullptr) wlo[d] = lo;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ encoder front fold (conv + flatten + linear)
+__global__ void fold_fwd_kernel(const hftt_fold_desc f) {
+  const int nw = f.n_proc - f.kw + 1;
+  const int cd = f.C * nw;
+  const long total = (long)f.d_pad * f.Kp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / f.Kp), u = (int)(i % f.Kp);
+    float acc = 0.f;
+    if (j < f.d && u < f.n_proc) {
+      for (int c = 0; c < f.C; c++)
+        for (int kk = 0; kk < f.kw; kk++) {
+          const int w = u - kk;
+          if (w >= 0 && w < nw) acc += f.wtok[(long)j * cd + c * nw + w] * f.wconv[c * f.kw + kk];
+        }
+    }
+    unsigned short hi, lo;
+    split_bf16(acc, hi, lo);
+    f.weff_hi[i] = hi;
+    if (f.weff_lo != nullptr) f.weff_lo[i] = lo;
+    if (u == 0 && j < f.d) {
+      float b = f.btok[j];
+      for (int c = 0; c < f.C; c++) {
+        float s = 0.f;
+        for (int w = 0; w < nw; w++) s += f.wtok[(long)j * cd + c * nw + w];
+        b += f.bconv[c] * s;
+      }
+      f.beff[j] = b;
+    }
+  }
+}
+
+// grads of tok_embedding_freq.{weight,bias}
+__global__ void fold_bwd_tok_kernel(const hftt_fold_desc f) {
+  const int nw = f.n_proc - f.kw + 1;
+  const int cd = f.C * nw;
+  const long total = (long)f.d * cd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / cd), cw = (int)(i % cd);
+    const int c = cw / nw, w = cw % nw;
+    float acc = f.dbeff[j] * f.bconv[c];
+    for (int kk = 0; kk < f.kw; kk++) acc += f.dweff[(long)j * f.Kp + w + kk] * f.wconv[c * f.kw + kk];
+    f.g_wtok[i] = acc;
+    if (cw == 0) f.g_btok[j] = f.dbeff[j];
+  }
+}
+// grads of conv.{weight,bias}: one workgroup per (c,kk) plus one per c for the bias
+__global__ __launch_bounds__(256) void fold_bwd_conv_kernel(const hftt_fold_desc f) {
+  __shared__ float red[256];
+  const int nw = f.n_proc - f.kw + 1;
+  const int cd = f.C * nw;
+  const int b = blockIdx.x;
+  const bool is_bias = b >= f.C * f.kw;
+  const int c = is_bias ? (b - f.C * f.kw) : (b / f.kw);
+  const int kk = is_bias ? 0 : (b % f.kw);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < f.d * nw; i += 256) {
+    const int j = i / nw, w = i % nw;
+    const float wt = f.wtok[(long)j * cd + c * nw + w];
+    acc += is_bias ? f.dbeff[j] * wt : f.dweff[(long)j * f.Kp + w + kk] * wt;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (is_bias) f.g_bconv[c] = red[0];
+    else f.g_wconv[c * f.kw + kk] = red[0];
+  }
+}
+
+// A[(b,t,f), u] = spec[b, f, t+u]
+__global__ void im2win_kernel(const float* __restrict__ spec, float* __restrict__ win, int B, int F, int T, int n_proc, int Kp) {
+  const int W = T + n_proc - 1;
+  const int q4 = Kp / 4;
+  const long total = (long)B * T * F * q4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int u4 = (int)(i % q4);
+    const long row = i / q4;
+    const int f = (int)(row % F);
+    const int t = (int)((row / F) % T);
+    const int b = (int)(row / ((long)F * T));
+    const float* src = spec + ((long)b * F + f) * W + t;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int u = u4 * 4 + e;
+      v[e] = (u < n_proc) ? src[u] : 0.f;
+    }
+    *reinterpret_cast<float4*>(win + row * Kp + u4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
+  constexpr int N = VPL * 64;
+  __shared__ float red[4][2][N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  float gam[VPL], dg[VPL], db[VPL];
+#pragma unroll
+  for (int e = 0; e < VPL; e++) { gam[e] = g.gamma[lane * VPL + e]; dg[e] = 0.f; db[e] = 0.f; }
+  for (long row = (long)blockIdx.x * 4 + wave; row < g.M; row += (long)gridDim.x * 4) {
+    float dy[VPL], r[VPL];
+    const long base = row * N + lane * VPL;
+    if (VPL == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(g.dy + base);
+      const float4 b = *reinterpret_cast<const float4*>(g.r + base);
+      dy[0] = a.x; dy[1 % VPL] = a.y; dy[2 % VPL] = a.z; dy[3 % VPL] = a.w;
+      r[0] = b.x; r[1 % VPL] = b.y; r[2 % VPL] = b.z; r[3 % VPL] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VPL; e++) { dy[e] = g.dy[base + e]; r[e] = g.r[base + e]; }
+    }
+    const float mean = g.mean[row], rstd = g.rstd[row];
+    float xh[VPL], gg[VPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      xh[e] = (r[e] - mean) * rstd;
+      gg[e] = dy[e] * gam[e];
+      s1 += gg[e];
+      s2 += gg[e] * xh[e];
+      dg[e] += dy[e] * xh[e];
+      db[e] += dy[e];
+    }
+    s1 = wave_sum(s1) * (1.0f / N);
+    s2 = wave_sum(s2) * (1.0f / N);
+    float o[VPL], od[VPL];
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      o[e] = rstd * (gg[e] - s1 - xh[e] * s2);
+      od[e] = o[e];
+      if (g.dr_drop != nullptr && g.drop_p > 0.f)
+        od[e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(base + e), thr) ? o[e] * inv_keep : 0.f;
+    }
+    if (VPL == 4) {
+      *reinterpret_cast<float4*>(g.dr + base) = make_float4(o[0], o[1 % VPL], o[2 % VPL], o[3 % VPL]);
+      if (g.dr_drop != nullptr) *reinterpret_cast<float4*>(g.dr_drop + base) = make_float4(od[0], od[1 % VPL], od[2 % VPL], od[3 % VPL]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VPL; e++) {
+        g.dr[base + e] = o[e];
+        if (g.dr_drop != nullptr) g.dr_drop[base + e] = od[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VPL; e++) { red[wave][0][lane * VPL + e] = dg[e]; red[wave][1][lane * VPL + e] = db[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    const int which = i / N, c = i % N;
+    g.ws[(long)blockIdx.x * 2 * N + i] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+// out[c] = beta*out[c] + sum_w ws[w][c]   (c over 2N entries: dgamma then dbeta)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int n_wg, int N, float* dgamma, float* dbeta, float beta) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float acc = 0.f;
+  if (c < 2 * N)
+    for (int w = rg; w < n_wg; w += 16) acc += ws[(long)w * 2 * N + c];
+  red[rg][cl] = acc;
+  __syncthreads();
+  if (rg == 0 && c < 2 * N) {
+    float s = 0.f;
+    for (int q = 0; q < 16; q++) s += red[q][cl];
+    float* dst = (c < N) ? (dgamma + c) : (dbeta + (c - N));
+    *dst = (beta != 0.f) ? (*dst * beta + s) : s;
+  }
+}
+
+// ------------------------------------------------------------------ decoder time transpose (+scale, +pos, dropout)
+__global__ void time_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ y,
+                                      int B, int T, int Nn, int d, float scale, float drop_p, uint32_t site, uint64_t seed) {
+  const int d4 = d / 4;
+  const long total = (long)B * Nn * T * d4;
+  const uint32_t thr = hftt_keep_thr(drop_p);
+  const float inv_keep = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4);
+    const long orow = i / d4;                      // (b*Nn + n)*T + t
+    const int t = (int)(orow % T);
+    const int n = (int)((orow / T) % Nn);
+    const int b = (int)(orow / ((long)T * Nn));
+    const long irow = ((long)b * T + t) * Nn + n;
+    const float4 a = *reinterpret_cast<const float4*>(x + irow * d + c4 * 4);
+    const float4 p = *reinterpret_cast<const float4*>(pos + (long)t * d + c4 * 4);
+    float v[4] = {a.x * scale + p.x, a.y * scale + p.y, a.z * scale + p.z, a.w * scale + p.w};
+    if (drop_p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = hftt_keep(seed, site, (uint64_t)(orow * d + c4 * 4 + e), thr) ? v[e] * inv_keep : 0.f;
+    }
+    *reinterpret_cast<float4*>(y + orow * d + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+__global__ void time_embed_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dym,
+                                      int B, int T, int Nn, int d, float scale, float drop_p, uint32_t site, uint64_t seed, int accumulate) {
+  const int d4 = d / 4;
+  const long total = (long)B * Nn * T * d4;
+  const uint32_t thr = hftt_keep_thr(drop_p);
+  const float inv_keep = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4);
+    const long orow = i / d4;
+    const int t = (int)(orow % T);
+    const int n = (int)((orow / T) % Nn);
+    const int b = (int)(orow / ((long)T * Nn));
+    const long irow = ((long)b * T + t) * Nn + n;
+    const float4 a = *reinterpret_cast<const float4*>(dy + orow * d + c4 * 4);
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (drop_p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = hftt_keep(seed, site, (uint64_t)(orow * d + c4 * 4 + e), thr) ? v[e] * inv_keep : 0.f;
+    }
+    if (dym != nullptr) *reinterpret_cast<float4*>(dym + orow * d + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    float4* dst = reinterpret_cast<float4*>(dx + irow * d + c4 * 4);
+    float4 o = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+    if (accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+    *dst = o;
+  }
+}
+__global__ void dropout_bwd_kernel(float* __restrict__ gbuf, long n, float drop_p, uint32_t site, uint64_t seed) {
+  const uint32_t thr = hftt_keep_thr(drop_p);
+  const float inv_keep = 1.0f / (1.0f - drop_p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    gbuf[i] = hftt_keep(seed, site, (uint64_t)i, thr) ? gbuf[i] * inv_keep : 0.f;
+}
+
+// ------------------------------------------------------------------ column sums (two-stage)
+constexpr int CS_SPLITS = 16;
+__global__ void colsum_stage1_kernel(const float* __restrict__ x, long rows, long n, long ld, float* __restrict__ ws) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int sp = blockIdx.y;
+  const long per = (rows + CS_SPLITS - 1) / CS_SPLITS;
+  const long r0 = sp * per;
+  long r1 = r0 + per; if (r1 > rows) r1 = rows;
+  float acc = 0.f;
+  for (long r = r0; r < r1; r++) acc += x[r * ld + j];
+  ws[(long)sp * n + j] = acc;
+}
+__global__ void colsum_stage2_kernel(const float* __restrict__ ws, long n, float* __restrict__ out, float beta) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int s = 0; s < CS_SPLITS; s++) acc += ws[(long)s * n + j];
+  out[j] = (beta != 0.f) ? (out[j] * beta + acc) : acc;
+}
+
+// ------------------------------------------------------------------ output heads
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void heads_split_kernel(const float* __restrict__ logits, long ldl, float* __restrict__ onset, float* __restrict__ offset,
+                                   float* __restrict__ mpe, float* __restrict__ velocity, int B, int T, int Nn, int V, int time_major) {
+  const int v4 = V / 4;
+  const long total = (long)B * T * Nn * v4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % v4);
+    const long s = i / v4;
+    long o = s;
+    if (time_major) {
+      const int t = (int)(s % T);
+      const int n = (int)((s / T) % Nn);
+      const int b = (int)(s / ((long)T * Nn));
+      o = ((long)b * T + t) * Nn + n;
+    }
+    *reinterpret_cast<float4*>(velocity + o * V + c4 * 4) = *reinterpret_cast<const float4*>(logits + s * ldl + c4 * 4);
+    if (c4 == 0) {
+      onset[o] = sigmoidf_(logits[s * ldl + V]);
+      offset[o] = sigmoidf_(logits[s * ldl + V + 1]);
+      mpe[o] = sigmoidf_(logits[s * ldl + V + 2]);
+    }
+  }
+}
+__global__ void heads_split_bwd_kernel(const float* __restrict__ p_on, const float* __restrict__ p_of, const float* __restrict__ p_mp,
+                                       const float* __restrict__ d_on, const float* __restrict__ d_of, const float* __restrict__ d_mp,
+                                       const float* __restrict__ d_vel, float* __restrict__ dlogits, long ldl,
+                                       int B, int T, int Nn, int V, int time_major) {
+  const int l4 = (int)(ldl / 4);
+  const int v4 = V / 4;
+  const long total = (long)B * T * Nn * l4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % l4);
+    const long s = i / l4;
+    long o = s;
+    if (time_major) {
+      const int t = (int)(s % T);
+      const int n = (int)((s / T) % Nn);
+      const int b = (int)(s / ((long)T * Nn));
+      o = ((long)b * T + t) * Nn + n;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < v4) {
+      v = *reinterpret_cast<const float4*>(d_vel + o * V + c4 * 4);
+    } else if (c4 == v4) {
+      const float a = p_on[o], b2 = p_of[o], c = p_mp[o];
+      v.x = d_on[o] * a * (1.f - a);
+      v.y = d_of[o] * b2 * (1.f - b2);
+      v.z = d_mp[o] * c * (1.f - c);
+    }
+    *reinterpret_cast<float4*>(dlogits + s * ldl + c4 * 4) = v;
+  }
+}
+
+// ------------------------------------------------------------------ fused loss (6x BCE + 2x CE) and its gradient
+constexpr int LOSS_WGS = 1024;
+__global__ __launch_bounds__(256) void loss_kernel(const hftt_loss_desc g) {
+  __shared__ float red[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_n = 1.0f / (float)g.n;
+  float part = 0.f;    // lanes 0..5: BCE terms; lanes 6,7: CE terms (A, B)
+  for (long el = (long)blockIdx.x * 4 + wave; el < g.n; el += (long)gridDim.x * 4) {
+    if (lane < 6) {
+      const float p = g.prob[lane][el];
+      const float y = (lane % 3 == 0) ? g.label_onset[el] : ((lane % 3 == 1) ? g.label_offset[el] : g.label_mpe[el]);
+      const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
+      part += -(y * lp + (1.f - y) * l1p);
+      if (g.d_prob[lane] != nullptr) {
+        const float w = (lane < 3) ? g.weight_A : g.weight_B;
+        g.d_prob[lane][el] = (p - y) / fmaxf((1.f - p) * p, 1e-12f) * (w * inv_n * g.grad_scale);
+      }
+    }
+    const int label = (int)g.label_velocity[el];
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const float* lg = g.vel[side] + el * g.V;
+      float v[4], mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int c = lane + 64 * e;
+        v[e] = (c < g.V) ? lg[c] : -INFINITY;
+        mx = fmaxf(mx, v[e]);
+      }
+      mx = wave_max(mx);
+      float s = 0.f, ex[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { ex[e] = (lane + 64 * e < g.V) ? expf(v[e] - mx) : 0.f; s += ex[e]; }
+      s = wave_sum(s);
+      const float lse = mx + logf(s);
+      float picked = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (lane + 64 * e == label) picked = v[e];
+      picked = wave_sum(picked);
+      if (lane == 6 + side) part += lse - picked;
+      if (g.d_vel[side] != nullptr) {
+        const float w = (side == 0 ? g.weight_A : g.weight_B) * inv_n * g.grad_scale;
+        float* dst = g.d_vel[side] + el * g.V;
+        const float inv_s = 1.0f / s;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int c = lane + 64 * e;
+          if (c < g.V) dst[c] = (ex[e] * inv_s - (c == label ? 1.f : 0.f)) * w;
+        }
+      }
+    }
+  }
+  if (lane < 8) red[wave][lane] = part;
+  __syncthreads();
+  if (threadIdx.x < 8) g.ws[(long)blockIdx.x * 8 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const hftt_loss_desc g, int n_wg) {
+  __shared__ float red[32][8];
+  const int term = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  float acc = 0.f;
+  for (int w = grp; w < n_wg; w += 32) acc += g.ws[(long)w * 8 + term];
+  red[grp][term] = acc;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float s = 0.f;
+    for (int q = 0; q < 32; q++) s += red[q][threadIdx.x];
+    red[0][threadIdx.x] = s / (float)g.n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // order of loss_out[1..8]: onset_A, offset_A, mpe_A, velocity_A, onset_B, offset_B, mpe_B, velocity_B
+    const float t[8] = {red[0][0], red[0][1], red[0][2], red[0][6], red[0][3], red[0][4], red[0][5], red[0][7]};
+    float la = (t[0] + t[1]) + t[2];
+    la += t[3];
+    float lb = (t[4] + t[5]) + t[6];
+    lb += t[7];
+    g.loss_out[0] = g.weight_A * la + g.weight_B * lb;
+    for (int i = 0; i < 8; i++) g.loss_out[1 + i] = t[i];
+  }
+}
+
+// ------------------------------------------------------------------ fused Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                            float lr_c, float beta1, float beta2, float eps, float inv_sqrt_bc2, float grad_scale) {
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pe = &pp.x; const float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float gr = ge[e] * grad_scale;
+      me[e] = beta1 * me[e] + (1.f - beta1) * gr;
+      ve[e] = beta2 * ve[e] + (1.f - beta2) * gr * gr;
+      pe[e] -= lr_c * me[e] / (sqrtf(ve[e]) * inv_sqrt_bc2 + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  const long tail = n4 * 4;
+  for (long i = tail + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * grad_scale;
+    m[i] = beta1 * m[i] + (1.f - beta1) * gr;
+    v[i] = beta2 * v[i] + (1.f - beta2) * gr * gr;
+    p[i] -= lr_c * m[i] / (sqrtf(v[i]) * inv_sqrt_bc2 + eps);
+  }
+}
+
+inline int grid_for(long work_items, int block, int cap = 4096) {
+  long b = (work_items + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int hftt_prep_weights(const float* params, uint16_t* whi, uint16_t* wlo, float* fdst,
+                                 const hftt_prep_entry* table_dev, int n_entries, void* stream) {
+  HFTT_REQUIRE(params && whi && table_dev && n_entries > 0, "prep_weights: null operand");
+  hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)n_entries, 8), dim3(256), 0, (hipStream_t)stream, params, whi, wlo, fdst, table_dev);
+  HFTT_CHECK_LAUNCH("prep_weights");
+  return 0;
+}
+
+extern "C" int hftt_embed_fold_fwd(const hftt_fold_desc* d, void* stream) {
+  HFTT_REQUIRE(d && d->wconv && d->bconv && d->wtok && d->btok && d->weff_hi && d->beff, "embed_fold_fwd: null operand");
+  HFTT_REQUIRE(d->Kp % 32 == 0 && d->Kp >= d->n_proc && d->d_pad >= d->d && d->n_proc >= d->kw, "embed_fold_fwd: bad shape");
+  hipLaunchKernelGGL(fold_fwd_kernel, dim3(grid_for((long)d->d_pad * d->Kp, 256)), dim3(256), 0, (hipStream_t)stream, *d);
+  HFTT_CHECK_LAUNCH("embed_fold_fwd");
+  return 0;
+}
+extern "C" int hftt_embed_fold_bwd(const hftt_fold_desc* d, void* stream) {
+  HFTT_REQUIRE(d && d->dweff && d->dbeff && d->g_wconv && d->g_bconv && d->g_wtok && d->g_btok, "embed_fold_bwd: null operand");
+  const int nw = d->n_proc - d->kw + 1;
+  hipLaunchKernelGGL(fold_bwd_tok_kernel, dim3(grid_for((long)d->d * d->C * nw, 256)), dim3(256), 0, (hipStream_t)stream, *d);
+  HFTT_CHECK_LAUNCH("embed_fold_bwd(tok)");
+  hipLaunchKernelGGL(fold_bwd_conv_kernel, dim3((unsigned)(d->C * d->kw + d->C)), dim3(256), 0, (hipStream_t)stream, *d);
+  HFTT_CHECK_LAUNCH("embed_fold_bwd(conv)");
+  return 0;
+}
+extern "C" int hftt_im2win(const float* spec, float* win, int32_t B, int32_t F, int32_t T, int32_t n_proc, int32_t Kp, void* stream) {
+  HFTT_REQUIRE(spec && win && B > 0 && F > 0 && T > 0 && n_proc > 0 && Kp % 4 == 0 && Kp >= n_proc, "im2win: bad arguments");
+  hipLaunchKernelGGL(im2win_kernel, dim3(grid_for((long)B * T * F * (Kp / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream, spec, win, B, F, T, n_proc, Kp);
+  HFTT_CHECK_LAUNCH("im2win");
+  return 0;
+}
+
+extern "C" int32_t hftt_ln_bwd_wgs(int32_t M) {
+  int w = (M + 3) / 4;
+  if (w > 1024) w = 1024;
+  if (w < 1) w = 1;
+  return w;
+}
+extern "C" int hftt_ln_bwd(const hftt_ln_bwd_desc* d, void* stream) {
+  HFTT_REQUIRE(d && d->dy && d->r && d->mean && d->rstd && d->gamma && d->dr && d->ws, "ln_bwd: null operand");
+  HFTT_REQUIRE(d->N == 64 || d->N == 128 || d->N == 256, "ln_bwd: N=%d must be 64, 128 or 256", d->N);
+  const int wgs = hftt_ln_bwd_wgs(d->M);
+  if (d->N == 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  else if (d->N == 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  HFTT_CHECK_LAUNCH("ln_bwd");
+  return 0;
+}
+extern "C" int hftt_ln_bwd_reduce(const float* ws, int32_t n_wg, int32_t N, float* dgamma, float* dbeta, float beta, void* stream) {
+  HFTT_REQUIRE(ws && dgamma && dbeta && n_wg > 0 && N > 0, "ln_bwd_reduce: bad arguments");
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * N + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, n_wg, N, dgamma, dbeta, beta);
+  HFTT_CHECK_LAUNCH("ln_bwd_reduce");
+  return 0;
+}
+
+extern "C" int hftt_time_embed_fwd(const float* x, const float* pos, float* y, int32_t B, int32_t T, int32_t Nn, int32_t d,
+                                   float scale, float drop_p, uint32_t site, uint64_t seed, void* stream) {
+  HFTT_REQUIRE(x && pos && y && d % 4 == 0, "time_embed_fwd: bad arguments");
+  hipLaunchKernelGGL(time_embed_fwd_kernel, dim3(grid_for((long)B * T * Nn * (d / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     x, pos, y, B, T, Nn, d, scale, drop_p, site, seed);
+  HFTT_CHECK_LAUNCH("time_embed_fwd");
+  return 0;
+}
+extern "C" int hftt_time_embed_bwd(const float* dy, float* dx, float* dym, int32_t B, int32_t T, int32_t Nn, int32_t d,
+                                   float scale, float drop_p, uint32_t site, uint64_t seed, int32_t accumulate, void* stream) {
+  HFTT_REQUIRE(dy && dx && d % 4 == 0, "time_embed_bwd: bad arguments");
+  hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(grid_for((long)B * T * Nn * (d / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     dy, dx, dym, B, T, Nn, d, scale, drop_p, site, seed, accumulate);
+  HFTT_CHECK_LAUNCH("time_embed_bwd");
+  return 0;
+}
+extern "C" int hftt_dropout_bwd(float* g, int64_t n, float drop_p, uint32_t site, uint64_t seed, void* stream) {
+  HFTT_REQUIRE(g && n > 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_bwd: bad arguments");
+  if (drop_p == 0.f) return 0;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, g, (long)n, drop_p, site, seed);
+  HFTT_CHECK_LAUNCH("dropout_bwd");
+  return 0;
+}
+extern "C" int64_t hftt_colsum_ws_bytes(int64_t rows, int64_t n) { (void)rows; return (int64_t)CS_SPLITS * n * 4; }
+extern "C" int hftt_colsum(const float* x, int64_t rows, int64_t n, int64_t ld, float* out, float beta, float* ws, void* stream) {
+  HFTT_REQUIRE(x && out && ws && rows > 0 && n > 0 && ld >= n, "colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)((n + 255) / 256), CS_SPLITS), dim3(256), 0, (hipStream_t)stream, x, (long)rows, (long)n, (long)ld, ws);
+  HFTT_CHECK_LAUNCH("colsum(1)");
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, (long)n, out, beta);
+  HFTT_CHECK_LAUNCH("colsum(2)");
+  return 0;
+}
+extern "C" int hftt_heads_split(const float* logits, int64_t ldl, float* onset, float* offset, float* mpe, float* velocity,
+                                int32_t B, int32_t T, int32_t Nn, int32_t V, int32_t time_major, void* stream) {
+  HFTT_REQUIRE(logits && onset && offset && mpe && velocity, "heads_split: null operand");
+  HFTT_REQUIRE(V % 4 == 0 && ldl % 4 == 0 && ldl >= V + 3, "heads_split: V=%d / ldl=%ld unsupported", V, (long)ldl);
+  hipLaunchKernelGGL(heads_split_kernel, dim3(grid_for((long)B * T * Nn * (V / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     logits, (long)ldl, onset, offset, mpe, velocity, B, T, Nn, V, time_major);
+  HFTT_CHECK_LAUNCH("heads_split");
+  return 0;
+}
+extern "C" int hftt_heads_split_bwd(const float* p_onset, const float* p_offset, const float* p_mpe,
+                                    const float* d_onset, const float* d_offset, const float* d_mpe, const float* d_velocity,
+                                    float* dlogits, int64_t ldl, int32_t B, int32_t T, int32_t Nn, int32_t V, int32_t time_major, void* stream) {
+  HFTT_REQUIRE(p_onset && p_offset && p_mpe && d_onset && d_offset && d_mpe && d_velocity && dlogits, "heads_split_bwd: null operand");
+  HFTT_REQUIRE(V % 4 == 0 && ldl % 4 == 0 && ldl >= V + 4, "heads_split_bwd: V=%d / ldl=%ld unsupported", V, (long)ldl);
+  hipLaunchKernelGGL(heads_split_bwd_kernel, dim3(grid_for((long)B * T * Nn * (ldl / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     p_onset, p_offset, p_mpe, d_onset, d_offset, d_mpe, d_velocity, dlogits, (long)ldl, B, T, Nn, V, time_major);
+  HFTT_CHECK_LAUNCH("heads_split_bwd");
+  return 0;
+}
+
+extern "C" int64_t hftt_loss_ws_bytes(int64_t n) { (void)n; return (int64_t)LOSS_WGS * 8 * 4; }
+extern "C" int hftt_loss(const hftt_loss_desc* d, void* stream) {
+  HFTT_REQUIRE(d && d->n > 0 && d->V > 0 && d->V <= 256, "loss: bad shape");
+  for (int i = 0; i < 6; i++) HFTT_REQUIRE(d->prob[i] != nullptr, "loss: null probability tensor %d", i);
+  HFTT_REQUIRE(d->vel[0] && d->vel[1] && d->label_onset && d->label_offset && d->label_mpe && d->label_velocity && d->loss_out && d->ws, "loss: null operand");
+  int wgs = (int)((d->n + 3) / 4);
+  if (wgs > LOSS_WGS) wgs = LOSS_WGS;
+  hipLaunchKernelGGL(loss_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  HFTT_CHECK_LAUNCH("loss");
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d, wgs);
+  HFTT_CHECK_LAUNCH("loss_reduce");
+  return 0;
+}
+
+extern "C" int hftt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                              float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  HFTT_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  HFTT_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float lr_c = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
+                     lr_c, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+  HFTT_CHECK_LAUNCH("adam_step");
+  return 0;
+}

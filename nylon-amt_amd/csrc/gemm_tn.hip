@@ -1,0 +1,304 @@
+// TN GEMM (weight gradients) on MFMA 32x32x16 bf16 (gfx950):
+//   dW[N,K] = out_scale * dY[M,N]^T . X[M,K],   db[N] = colsum(dY)      -- include/hftt_hip.h (hftt_gemm_tn)
+// The reduction runs over the (huge) token dimension M, so both operands are needed "token-major" in the
+// MFMA fragments.  Tiles of dY and X are staged ROW-major in LDS (coalesced 16-byte global loads) and the
+// fragments are fetched with ds_read_b64_tr_b16 (hardware transpose; lane map verified by tools/probe_mfma T5).
+// M is split over workgroups; partial tiles go to a slab workspace and a second kernel reduces them in a fixed
+// order (bitwise reproducible; no float atomics).
+#include "hftt_common.h"
+#include "hftt_host.h"
+#include "../../include/hftt_hip.h"
+
+namespace {
+
+constexpr int BMT = 32;   // token rows per LDS stage
+
+struct TnPlan {
+  int tm, tn;            // template tile selectors
+  int tile_n, tile_k;    // output tile
+  int n_tiles, k_tiles, splits, rows_per_split;
+  long nws, kws;         // padded slab dims
+};
+
+TnPlan tn_plan(int M, int N, int K) {
+  TnPlan p;
+  if (N >= 256 && K >= 256) { p.tm = 2; p.tn = 4; }
+  else if (N >= 128 && K >= 128) { p.tm = 1; p.tn = 2; }
+  else { p.tm = 1; p.tn = 1; }
+  p.tile_n = 128 * p.tm;
+  p.tile_k = 64 * p.tn;
+  p.n_tiles = (N + p.tile_n - 1) / p.tile_n;
+  p.k_tiles = (K + p.tile_k - 1) / p.tile_k;
+  const int tiles = p.n_tiles * p.k_tiles;
+  int target = (p.tm == 2) ? 256 : 512;
+  int splits = target / tiles;
+  if (splits < 1) splits = 1;
+  const int max_splits = (M + 63) / 64;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rps = (M + splits - 1) / splits;
+  rps = ((rps + BMT - 1) / BMT) * BMT;
+  p.splits = (M + rps - 1) / rps;
+  p.rows_per_split = rps;
+  p.nws = (long)p.n_tiles * p.tile_n;
+  p.kws = (long)p.k_tiles * p.tile_k;
+  return p;
+}
+
+template <int TM, int TN, int NPASS>
+struct TnCfg {
+  static constexpr int TILE_N = 128 * TM;
+  static constexpr int TILE_K = 64 * TN;
+  static constexpr int RSY = TILE_N + 32;   // shorts; bytes = 2*TILE_N + 64 == 64 (mod 128): conflict-free tr reads
+  static constexpr int RSX = TILE_K + 32;
+  static constexpr int PL = (NPASS == 3) ? 2 : 1;
+  static constexpr int Y_ELEMS = BMT * RSY;
+  static constexpr int X_ELEMS = BMT * RSX;
+  static constexpr int BUF_ELEMS = PL * (Y_ELEMS + X_ELEMS);
+  static constexpr int LDS_BYTES = 2 * BUF_ELEMS * 2;
+  static constexpr int YL = TILE_N / 64;    // float4 loads per thread (dY)
+  static constexpr int XL = (TILE_K + 63) / 64;   // float4 loads per thread (X)
+};
+
+template <int TM, int TN, int NPASS>
+__global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g, const int k_tiles, const int rows_per_split,
+                                                     const long nws, const long kws) {
+  using Cfg = TnCfg<TM, TN, NPASS>;
+  constexpr int PL = Cfg::PL, RSY = Cfg::RSY, RSX = Cfg::RSX, TILE_N = Cfg::TILE_N, TILE_K = Cfg::TILE_K;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* sm = reinterpret_cast<unsigned short*>(smem);
+  auto Ys = [&](int buf, int pl) { return sm + buf * Cfg::BUF_ELEMS + pl * Cfg::Y_ELEMS; };
+  auto Xs = [&](int buf, int pl) { return sm + buf * Cfg::BUF_ELEMS + PL * Cfg::Y_ELEMS + pl * Cfg::X_ELEMS; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn4 = wave >> 1, wk2 = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tile = blockIdx.x;
+  const int nt = tile / k_tiles, ktile = tile % k_tiles;
+  const int n0 = nt * TILE_N, k0 = ktile * TILE_K;
+  const int split = blockIdx.y;
+  const long mbeg = (long)split * rows_per_split;
+  long mend = mbeg + rows_per_split;
+  if (mend > g.M) mend = g.M;
+  const int nsteps = (int)((mend - mbeg + BMT - 1) / BMT);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  float4 yreg[Cfg::YL], xreg[Cfg::XL];
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int YF4R = TILE_N / 4;   // float4 per row
+  constexpr int XF4R = TILE_K / 4;
+  const int yc4 = tid % YF4R;
+  const int ycol = n0 + yc4 * 4;
+  const bool ycol_ok = ycol < g.N;    // N % 4 == 0
+
+  auto gload = [&](int step) {
+    const long mb = mbeg + (long)step * BMT;
+#pragma unroll
+    for (int j = 0; j < Cfg::YL; j++) {
+      const int i = tid + 512 * j;
+      const int row = i / YF4R;
+      const long m = mb + row;
+      if (ycol_ok && m < mend) yreg[j] = *reinterpret_cast<const float4*>(g.dY + m * g.lddy + ycol);
+      else yreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::XL; j++) {
+      const int i = tid + 512 * j;
+      const int row = i / XF4R, c4 = i % XF4R;
+      const long m = mb + row;
+      const int col = k0 + c4 * 4;
+      if (row < BMT && col < g.K && m < mend) xreg[j] = *reinterpret_cast<const float4*>(g.X + m * g.ldx + col);
+      else xreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto put4 = [&](unsigned short* hi_p, unsigned short* lo_p, const float4& f) {
+    const float v[4] = {f.x, f.y, f.z, f.w};
+    unsigned short hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (PL == 2) split_bf16(v[e], hi[e], lo[e]);
+      else hi[e] = f2bf(v[e]);
+    }
+    uint2 ph;
+    ph.x = hi[0] | ((unsigned)hi[1] << 16); ph.y = hi[2] | ((unsigned)hi[3] << 16);
+    *reinterpret_cast<uint2*>(hi_p) = ph;
+    if (PL == 2) {
+      uint2 pl;
+      pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16);
+      *reinterpret_cast<uint2*>(lo_p) = pl;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < Cfg::YL; j++) {
+      const int i = tid + 512 * j;
+      const int row = i / YF4R;
+      csum[0] += yreg[j].x; csum[1] += yreg[j].y; csum[2] += yreg[j].z; csum[3] += yreg[j].w;
+      put4(Ys(buf, 0) + row * RSY + yc4 * 4, Ys(buf, PL - 1) + row * RSY + yc4 * 4, yreg[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::XL; j++) {
+      const int i = tid + 512 * j;
+      const int row = i / XF4R, c4 = i % XF4R;
+      if (row < BMT) put4(Xs(buf, 0) + row * RSX + c4 * 4, Xs(buf, PL - 1) + row * RSX + c4 * 4, xreg[j]);
+    }
+  };
+
+  // transposed-fragment addressing (probe T5): 16-lane group gi, block row qq, column quad p
+  const int gi = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int frag_col = 16 * (gi & 1) + 4 * pp;   // column inside a 32-wide tile
+  const int frag_row = 8 * (gi >> 1) + qq;       // + 16*s + 4*half
+
+  if (nsteps > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; step++) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) gload(step + 1);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const int c = wn4 * TM * 32 + i * 32 + frag_col;
+        const int r0 = 16 * s + frag_row;
+        ah[i] = join4(lds_read_tr16(Ys(buf, 0) + r0 * RSY + c), lds_read_tr16(Ys(buf, 0) + (r0 + 4) * RSY + c));
+        al[i] = (PL == 2) ? join4(lds_read_tr16(Ys(buf, PL - 1) + r0 * RSY + c), lds_read_tr16(Ys(buf, PL - 1) + (r0 + 4) * RSY + c)) : ah[i];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int c = wk2 * TN * 32 + j * 32 + frag_col;
+        const int r0 = 16 * s + frag_row;
+        bh[j] = join4(lds_read_tr16(Xs(buf, 0) + r0 * RSX + c), lds_read_tr16(Xs(buf, 0) + (r0 + 4) * RSX + c));
+        bl[j] = (PL == 2) ? join4(lds_read_tr16(Xs(buf, PL - 1) + r0 * RSX + c), lds_read_tr16(Xs(buf, PL - 1) + (r0 + 4) * RSX + c)) : bh[j];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = mfma32_split<NPASS>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+    }
+    if (step + 1 < nsteps) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> slab [split][nws][kws]
+  float* slab = reinterpret_cast<float*>(g.ws) + (long)split * nws * kws;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const long n = n0 + wn4 * TM * 32 + i * 32 + acc_row32(r, lh);
+        const long k = k0 + wk2 * TN * 32 + j * 32 + lr;
+        slab[n * kws + k] = acc[i][j][r];
+      }
+  // column sums of dY (bias gradient): only the k-tile-0 workgroups publish them
+  if (ktile == 0) {
+    float* red = reinterpret_cast<float*>(smem);   // [512/YF4R][TILE_N]
+    __syncthreads();
+    const int grp = tid / YF4R;
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[grp * TILE_N + yc4 * 4 + e] = csum[e];
+    __syncthreads();
+    float* bslab = reinterpret_cast<float*>(g.ws) + (long)gridDim.y * nws * kws + (long)split * nws;
+    for (int c = tid; c < TILE_N; c += 512) {
+      float s = 0.f;
+      for (int q = 0; q < 512 / YF4R; q++) s += red[q * TILE_N + c];
+      bslab[n0 + c] = s;
+    }
+  }
+}
+
+__global__ void gemm_tn_reduce_kernel(const hftt_gemm_tn_desc g, const int splits, const long nws, const long kws) {
+  const long total = (long)g.N * g.K_out;
+  const float* ws = reinterpret_cast<const float*>(g.ws);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / g.K_out), k = (int)(idx % g.K_out);
+    int sg = -1;
+    for (int s = 0; s < g.n_seg; s++)
+      if (n >= g.seg_row0[s] && n < g.seg_row0[s] + g.seg_rows[s]) sg = s;
+    if (sg < 0) continue;
+    float acc = 0.f;
+    for (int s = 0; s < splits; s++) acc += ws[((long)s * nws + n) * kws + k];
+    float* dst = g.seg_dw[sg] + (long)(n - g.seg_row0[sg]) * g.K_out + k;
+    const float v = acc * g.out_scale;
+    *dst = (g.beta != 0.f) ? (*dst * g.beta + v) : v;
+    if (k == 0 && g.seg_db[sg] != nullptr) {
+      const float* bs = ws + (long)splits * nws * kws;
+      float b = 0.f;
+      for (int s = 0; s < splits; s++) b += bs[(long)s * nws + n];
+      float* db = g.seg_db[sg] + (n - g.seg_row0[sg]);
+      const float bv = b * g.out_scale;
+      *db = (g.beta != 0.f) ? (*db * g.beta + bv) : bv;
+    }
+  }
+}
+
+template <int TM, int TN, int NPASS>
+int launch_tn(const hftt_gemm_tn_desc& d, const TnPlan& p, hipStream_t st) {
+  using Cfg = TnCfg<TM, TN, NPASS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<TM, TN, NPASS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) { hftt_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(p.n_tiles * p.k_tiles), (unsigned)p.splits, 1);
+  hipLaunchKernelGGL((gemm_tn_kernel<TM, TN, NPASS>), grid, dim3(512), Cfg::LDS_BYTES, st, d, p.k_tiles, p.rows_per_split, p.nws, p.kws);
+  HFTT_CHECK_LAUNCH("gemm_tn");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t hftt_gemm_tn_ws_bytes(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const TnPlan p = tn_plan(M, N, K);
+  return (int64_t)p.splits * p.nws * (p.kws + 1) * 4;
+}
+
+extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
+  HFTT_REQUIRE(d != nullptr, "gemm_tn: null descriptor");
+  HFTT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_tn: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+  HFTT_REQUIRE(d->N % 4 == 0 && d->K % 4 == 0, "gemm_tn: N=%d and K=%d must be multiples of 4", d->N, d->K);
+  HFTT_REQUIRE(d->lddy % 4 == 0 && d->ldx % 4 == 0, "gemm_tn: leading dims must be multiples of 4");
+  HFTT_REQUIRE(((uintptr_t)d->dY & 15) == 0 && ((uintptr_t)d->X & 15) == 0, "gemm_tn: dY/X must be 16-byte aligned");
+  HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "gemm_tn: npass must be 1 or 3");
+  HFTT_REQUIRE(d->n_seg >= 1 && d->n_seg <= 4, "gemm_tn: n_seg must be 1..4");
+  HFTT_REQUIRE(d->K_out > 0 && d->K_out <= d->K, "gemm_tn: K_out out of range");
+  for (int s = 0; s < d->n_seg; s++) {
+    HFTT_REQUIRE(d->seg_dw[s] != nullptr, "gemm_tn: null segment pointer");
+    HFTT_REQUIRE(d->seg_row0[s] >= 0 && d->seg_rows[s] > 0 && d->seg_row0[s] + d->seg_rows[s] <= d->N, "gemm_tn: segment %d out of range", s);
+  }
+  HFTT_REQUIRE(d->ws != nullptr && d->ws_bytes >= hftt_gemm_tn_ws_bytes(d->M, d->N, d->K), "gemm_tn: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const TnPlan p = tn_plan(d->M, d->N, d->K);
+  int rc;
+  if (d->npass == 3) {
+    if (p.tm == 2) rc = launch_tn<2, 4, 3>(*d, p, st);
+    else if (p.tn == 2) rc = launch_tn<1, 2, 3>(*d, p, st);
+    else rc = launch_tn<1, 1, 3>(*d, p, st);
+  } else {
+    if (p.tm == 2) rc = launch_tn<2, 4, 1>(*d, p, st);
+    else if (p.tn == 2) rc = launch_tn<1, 2, 1>(*d, p, st);
+    else rc = launch_tn<1, 1, 1>(*d, p, st);
+  }
+  if (rc != 0) return rc;
+  const long total = (long)d->N * d->K_out;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, st, *d, p.splits, p.nws, p.kws);
+  HFTT_CHECK_LAUNCH("gemm_tn_reduce");
+  return 0;
+}
