@@ -1,0 +1,35 @@
+"""torch.autograd glue: the whole model forward/backward as ONE autograd.Function over the HIP engine.
+
+This is the compatibility path (``loss.backward()`` of training/train.py:158 works unchanged with any torch
+optimizer).  The fast path used by ``training.train`` / bench.py drives the same engine plans without autograd.
+"""
+import torch
+
+_D_NAMES = ('onset_A', 'offset_A', 'mpe_A', 'velocity_A', None, 'onset_B', 'offset_B', 'mpe_B', 'velocity_B')
+
+
+class HfttModelFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, engine, training, *params):
+        outs = engine.forward(spec, training=training)
+        ctx.engine = engine
+        ctx.B = spec.shape[0]
+        ctx.generation = engine.generation
+        ctx.mark_non_differentiable(outs[4])     # attention map: returned for inspection, never part of the loss
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        eng = ctx.engine
+        ws = eng._ws[ctx.B]
+        for name, g in zip(_D_NAMES, gouts):
+            if name is None:
+                continue
+            buf = ws['bufs']['d.' + name]
+            if g is None:
+                buf.zero_()
+            else:
+                buf.copy_(g.reshape(buf.shape))
+        eng.backward(ctx.B, ctx.generation)
+        grads = eng.grad_views(eng.flat_grads.clone())   # private copy: autograd may keep references
+        return (None, None, None) + tuple(grads)

@@ -1,0 +1,799 @@
+"""Host-side engine of the MI355X hFT-Transformer path.
+
+It owns (a) ONE flat fp32 parameter buffer + ONE flat gradient buffer (the module's nn.Parameters are views
+into the first), (b) the prepared bf16 weight planes the MFMA kernels consume, (c) all activation /
+gradient workspaces for a batch size, and (d) pre-built launch plans: lists of C-ABI calls
+(libhftt_hip.so) with their descriptors filled in once, replayed every step on torch's current HIP stream.
+
+PyTorch is used for device memory, streams and autograd glue only; every arithmetic op of the path is a
+HIP kernel behind the C ABI (include/hftt_hip.h).  There is no fallback: without the library or on a CPU
+tensor the engine raises.
+
+Reference algorithm: hftt_code/model/model_spec2midi.py (forward), training/train.py:141-159 (loss,
+backward, step).  Shapes follow the reference: T frames, F bins, N notes, V velocities, d hidden, p ffn.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import _capi
+from ._capi import (AttnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, check, lib)
+
+PRECISION_NPASS = {'parity': 3, 'bf16': 1}
+
+
+def _align(x, a):
+    return (x + a - 1) // a * a
+
+
+class _Flat:
+    """Bump allocator over one flat tensor (element offsets, 16-byte aligned)."""
+
+    def __init__(self):
+        self.off = 0
+        self.items = OrderedDict()
+
+    def add(self, name, numel, align=8):
+        self.off = _align(self.off, align)
+        self.items[name] = self.off
+        self.off += numel
+        return self.items[name]
+
+
+class HfttEngine:
+    def __init__(self, cfg, device, precision='parity', dropout=0.0, seed=1234):
+        """cfg: dict with n_margin,n_frame,n_bin,cnn_channel,cnn_kernel,hid_dim,pf_dim,enc_layer,dec_layer,
+        enc_head,dec_head,n_note,n_velocity (the constructor arguments of the reference classes)."""
+        self.lib = lib()
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _capi.HfttError('HfttEngine needs a ROCm device (got %s): the HIP kernels are the only compute path' % device)
+        c = self.cfg
+        self.T, self.F, self.N, self.V = c['n_frame'], c['n_bin'], c['n_note'], c['n_velocity']
+        self.d, self.p = c['hid_dim'], c['pf_dim']
+        self.He, self.Hd = c['enc_head'], c['dec_head']
+        self.Le, self.Ld = c['enc_layer'], c['dec_layer']
+        self.n_proc = 2 * c['n_margin'] + 1
+        self.Kp = _align(self.n_proc, 32)
+        self.W = self.T + 2 * c['n_margin']
+        self.nw = self.n_proc - (c['cnn_kernel'] - 1)
+        if self.d % 32 or self.p % 32 or self.d not in (64, 128, 256):
+            raise _capi.HfttError('hid_dim must be 64/128/256 and pf_dim a multiple of 32 (got %d/%d)' % (self.d, self.p))
+        for h in (self.He, self.Hd):
+            if self.d % h or (self.d // h) not in (32, 64):
+                raise _capi.HfttError('head_dim must be 32 or 64 (hid_dim %d, heads %d)' % (self.d, h))
+        if max(self.T, self.F, self.N) > 256:
+            raise _capi.HfttError('sequence axes must be <= 256')
+        if self.V % 4:
+            raise _capi.HfttError('n_velocity must be a multiple of 4')
+        self.NH = self.V + 3                       # packed head rows: velocity[0:V], onset, offset, mpe
+        self.NHp = _align(self.NH + 1, 64)
+        self.set_precision(precision)
+        self.dropout = float(dropout)
+        self.base_seed = int(seed)
+        self.step_counter = 0
+        self.generation = 0
+        self._bound = None                          # list of (name, param, offset, numel)
+        self._ws = {}
+        self._site = 0
+
+    # ------------------------------------------------------------------ precision / parameters
+    def set_precision(self, precision):
+        if precision not in PRECISION_NPASS:
+            raise ValueError('precision must be one of %s' % list(PRECISION_NPASS))
+        self.precision = precision
+        self.npass = PRECISION_NPASS[precision]
+        self._ws = {}
+
+    def bind(self, named_params):
+        """Flatten the module's parameters into one buffer (reference state_dict order) and rebind .data as views."""
+        named = list(named_params)
+        lay = _Flat()
+        offs = [lay.add(n, p.numel()) for n, p in named]
+        total = _align(lay.off, 8)
+        flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        for (n, p), o in zip(named, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1).to(self.device, torch.float32))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self.flat_params = flat
+        self.flat_grads = torch.zeros_like(flat)
+        self.poff = {n: o for (n, _), o in zip(named, offs)}
+        self.pshape = {n: tuple(p.shape) for n, p in named}
+        self._bound = [(n, p, o, p.numel()) for (n, p), o in zip(named, offs)]
+        self._build_prep()
+        self._ws = {}
+
+    def is_bound(self):
+        if self._bound is None:
+            return False
+        base = self.flat_params.data_ptr()
+        for _, p, o, _ in self._bound:
+            if p.data_ptr() != base + 4 * o:
+                return False
+        return True
+
+    def grad_views(self, source=None):
+        src = self.flat_grads if source is None else source
+        return [src[o:o + n].view(self.pshape[name]) for name, _, o, n in self._bound]
+
+    def P(self, name):   # device address of a parameter
+        return self.flat_params.data_ptr() + 4 * self.poff[name]
+
+    def G(self, name):   # device address of a parameter's gradient
+        return self.flat_grads.data_ptr() + 4 * self.poff[name]
+
+    # ------------------------------------------------------------------ prepared weights
+    def _build_prep(self):
+        d, p = self.d, self.p
+        wl, fl = _Flat(), _Flat()
+        entries = []
+
+        def mat(key, srcs, rows_each, cols, transposed):
+            """srcs: parameter names stacked along rows; returns plane offset of the [sum rows, cols] (or transposed) matrix."""
+            rows = rows_each * len(srcs)
+            if transposed:
+                off = wl.add(key, cols * _align(rows, 32), 64)
+                for i, s in enumerate(srcs):
+                    entries.append((self.poff[s], off + i * rows_each, rows_each, cols, cols, _align(rows, 32), 1))
+            else:
+                off = wl.add(key, _align(rows, 64) * cols, 64)
+                for i, s in enumerate(srcs):
+                    entries.append((self.poff[s], off + i * rows_each * cols, rows_each, cols, cols, cols, 0))
+            return off
+
+        def vec(key, srcs, n_each, pad_to=None):
+            n = n_each * len(srcs)
+            off = fl.add(key, pad_to or n, 8)
+            for i, s in enumerate(srcs):
+                entries.append((self.poff[s], off + i * n_each, 1, n_each, n_each, n_each, 2))
+            return off
+
+        W = {}
+
+        def attn_self(pre, key):
+            names = [pre + 'fc_q', pre + 'fc_k', pre + 'fc_v']
+            W[key + '.qkv'] = mat(key + '.qkv', [n + '.weight' for n in names], d, d, False)
+            W[key + '.qkv_t'] = mat(key + '.qkv_t', [n + '.weight' for n in names], d, d, True)
+            W[key + '.qkv_b'] = vec(key + '.qkv_b', [n + '.bias' for n in names], d)
+            W[key + '.o'] = mat(key + '.o', [pre + 'fc_o.weight'], d, d, False)
+            W[key + '.o_t'] = mat(key + '.o_t', [pre + 'fc_o.weight'], d, d, True)
+
+        def attn_cross(pre, key):
+            W[key + '.q'] = mat(key + '.q', [pre + 'fc_q.weight'], d, d, False)
+            W[key + '.q_t'] = mat(key + '.q_t', [pre + 'fc_q.weight'], d, d, True)
+            names = [pre + 'fc_k', pre + 'fc_v']
+            W[key + '.kv'] = mat(key + '.kv', [n + '.weight' for n in names], d, d, False)
+            W[key + '.kv_t'] = mat(key + '.kv_t', [n + '.weight' for n in names], d, d, True)
+            W[key + '.kv_b'] = vec(key + '.kv_b', [n + '.bias' for n in names], d)
+            W[key + '.o'] = mat(key + '.o', [pre + 'fc_o.weight'], d, d, False)
+            W[key + '.o_t'] = mat(key + '.o_t', [pre + 'fc_o.weight'], d, d, True)
+
+        def ffn(pre, key):
+            # fc_1.weight [p, d], fc_2.weight [d, p]
+            off = wl.add(key + '.f1', _align(p, 64) * d, 64); entries.append((self.poff[pre + 'fc_1.weight'], off, p, d, d, d, 0)); W[key + '.f1'] = off
+            off = wl.add(key + '.f1_t', d * p, 64); entries.append((self.poff[pre + 'fc_1.weight'], off, p, d, d, p, 1)); W[key + '.f1_t'] = off
+            off = wl.add(key + '.f2', d * p, 64); entries.append((self.poff[pre + 'fc_2.weight'], off, d, p, p, p, 0)); W[key + '.f2'] = off
+            off = wl.add(key + '.f2_t', _align(p, 64) * d, 64); entries.append((self.poff[pre + 'fc_2.weight'], off, d, p, p, d, 1)); W[key + '.f2_t'] = off
+
+        def heads(tag, key):
+            pre = 'decoder_spec2midi.'
+            NHp, V = self.NHp, self.V
+            off = wl.add(key, NHp * d, 64)
+            W[key] = off
+            entries.append((self.poff[f'{pre}fc_velocity_{tag}.weight'], off, V, d, d, d, 0))
+            for i, nm in enumerate(('onset', 'offset', 'mpe')):
+                entries.append((self.poff[f'{pre}fc_{nm}_{tag}.weight'], off + (V + i) * d, 1, d, d, d, 0))
+            offt = wl.add(key + '_t', d * NHp, 64)
+            W[key + '_t'] = offt
+            entries.append((self.poff[f'{pre}fc_velocity_{tag}.weight'], offt, V, d, d, NHp, 1))
+            for i, nm in enumerate(('onset', 'offset', 'mpe')):
+                entries.append((self.poff[f'{pre}fc_{nm}_{tag}.weight'], offt + V + i, 1, d, d, NHp, 1))
+            ob = fl.add(key + '_b', NHp, 8)
+            W[key + '_b'] = ob
+            entries.append((self.poff[f'{pre}fc_velocity_{tag}.bias'], ob, 1, V, V, V, 2))
+            for i, nm in enumerate(('onset', 'offset', 'mpe')):
+                entries.append((self.poff[f'{pre}fc_{nm}_{tag}.bias'], ob + V + i, 1, 1, 1, 1, 2))
+
+        W['embed'] = wl.add('embed', _align(d, 64) * self.Kp, 64)
+        W['embed_b'] = fl.add('embed_b', d, 8)
+        for i in range(self.Le):
+            pre = f'encoder_spec2midi.layers_freq.{i}.'
+            attn_self(pre + 'self_attention.', f'enc{i}.sa')
+            ffn(pre + 'positionwise_feedforward.', f'enc{i}')
+        pre = 'decoder_spec2midi.layer_zero_freq.'
+        attn_cross(pre + 'encoder_attention.', 'dec0.ca')
+        ffn(pre + 'positionwise_feedforward.', 'dec0')
+        for i in range(self.Ld - 1):
+            pre = f'decoder_spec2midi.layers_freq.{i}.'
+            attn_self(pre + 'self_attention.', f'dec{i + 1}.sa')
+            attn_cross(pre + 'encoder_attention.', f'dec{i + 1}.ca')
+            ffn(pre + 'positionwise_feedforward.', f'dec{i + 1}')
+        heads('freq', 'heads_f')
+        for i in range(self.Ld):
+            pre = f'decoder_spec2midi.layers_time.{i}.'
+            attn_self(pre + 'self_attention.', f'time{i}.sa')
+            ffn(pre + 'positionwise_feedforward.', f'time{i}')
+        heads('time', 'heads_t')
+
+        self.Woff = W
+        self.whi = torch.zeros(_align(wl.off, 64), dtype=torch.int16, device=self.device)
+        self.wlo = torch.zeros_like(self.whi)
+        self.fprep = torch.zeros(_align(fl.off, 8), dtype=torch.float32, device=self.device)
+        arr = (PrepEntry * len(entries))()
+        for i, (so, do, r, c_, sld, dld, kind) in enumerate(entries):
+            arr[i] = PrepEntry(so, do, r, c_, sld, dld, kind, 0)
+        raw = bytes(arr)
+        self.prep_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.n_prep = len(entries)
+        # embed-fold scratch (dWeff, dbeff)
+        self.dweff = torch.zeros(self.d * self.Kp, dtype=torch.float32, device=self.device)
+        self.dbeff = torch.zeros(self.d, dtype=torch.float32, device=self.device)
+        e = 'encoder_spec2midi.'
+        self.fold = FoldDesc(self.d, self.cfg['cnn_channel'], self.cfg['cnn_kernel'], self.n_proc, self.Kp, _align(self.d, 64),
+                             self.P(e + 'conv.weight'), self.P(e + 'conv.bias'), self.P(e + 'tok_embedding_freq.weight'),
+                             self.P(e + 'tok_embedding_freq.bias'),
+                             self.whi.data_ptr() + 2 * W['embed'], self.wlo.data_ptr() + 2 * W['embed'],
+                             self.fprep.data_ptr() + 4 * W['embed_b'],
+                             self.dweff.data_ptr(), self.dbeff.data_ptr(),
+                             self.G(e + 'conv.weight'), self.G(e + 'conv.bias'), self.G(e + 'tok_embedding_freq.weight'),
+                             self.G(e + 'tok_embedding_freq.bias'))
+
+    def Wp(self, key):   # (hi, lo) device addresses of a prepared matrix
+        o = self.Woff[key]
+        return (self.whi.data_ptr() + 2 * o, self.wlo.data_ptr() + 2 * o)
+
+    def Fp(self, key):
+        return self.fprep.data_ptr() + 4 * self.Woff[key]
+
+    def prepare_weights(self, stream):
+        check(self.lib.hftt_prep_weights(self.flat_params.data_ptr(), self.whi.data_ptr(), self.wlo.data_ptr(),
+                                         self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights')
+        check(self.lib.hftt_embed_fold_fwd(C.byref(self.fold), stream), 'embed_fold_fwd')
+
+    # ------------------------------------------------------------------ plan building helpers
+    def _new_site(self):
+        self._site += 1
+        return self._site
+
+    def _buf(self, ws, name, *shape, dtype=torch.float32):
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        ws['bufs'][name] = t
+        return t
+
+    def _nt(self, plan, ws, M, N, K, A, lda, W, bias, Cp, ldc, act=0, out_scale=1.0, add_table=0, add_mod=0,
+            gate=0, ldg=0, gate_scale=1.0, drop_site=0, residual=0, ldr=0, res_mod=0, ln=None):
+        dsc = GemmNtDesc()
+        dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, self.npass
+        dsc.A, dsc.lda = A, lda
+        dsc.Whi, dsc.Wlo = W
+        dsc.bias = bias
+        dsc.C, dsc.ldc = Cp, ldc
+        dsc.act, dsc.out_scale = act, out_scale
+        dsc.add_table, dsc.add_mod = add_table, add_mod
+        if isinstance(gate_scale, tuple):      # run-time value: 1/(1-p) of the hidden-layer dropout
+            ws.setdefault('gate_descs', []).append(dsc)
+            gate_scale = 1.0
+        dsc.gate, dsc.ldg, dsc.gate_scale = gate, ldg, gate_scale
+        dsc.drop_p, dsc.drop_site, dsc.drop_seed = 0.0, drop_site, 0
+        dsc.residual, dsc.ldr, dsc.res_mod = residual, ldr, (res_mod or M)
+        if ln is not None:
+            dsc.ln_gamma, dsc.ln_beta, dsc.pre_ln_out, dsc.ln_mean, dsc.ln_rstd = ln
+        if drop_site:
+            ws['drop'].append(dsc)
+        ws['keep'].append(dsc)
+        plan.append((self.lib.hftt_gemm_nt, (C.byref(dsc),), 'gemm_nt'))
+        return dsc
+
+    def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0):
+        """segs: list of (row0, rows, dw_addr, db_addr or 0)"""
+        need = self.lib.hftt_gemm_tn_ws_bytes(M, N, K)
+        ws['tn_need'] = max(ws.get('tn_need', 0), need)
+        dsc = GemmTnDesc()
+        dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, self.npass
+        dsc.dY, dsc.lddy, dsc.X, dsc.ldx = dY, lddy, X, ldx
+        dsc.out_scale, dsc.beta = out_scale, beta
+        dsc.n_seg = len(segs)
+        for i, (r0, rows, dw, db) in enumerate(segs):
+            dsc.seg_row0[i], dsc.seg_rows[i], dsc.seg_dw[i], dsc.seg_db[i] = r0, rows, dw, db
+        dsc.K_out = K_out or K
+        ws['tn'].append(dsc)
+        ws['keep'].append(dsc)
+        plan.append((self.lib.hftt_gemm_tn, (C.byref(dsc),), 'gemm_tn'))
+        return dsc
+
+    def _attn(self, plan, ws, bwd, n_seq, H, Lq, Lk, q, qss, ldq, k, kss, ldk, v, vss, ldv, out, oss, ldo, lse, probs=0,
+              drop_site=0, dout=0, dq=0, dqss=0, lddq=0, dk=0, dkss=0, lddk=0, dv=0, dvss=0, lddv=0):
+        dsc = AttnDesc()
+        dsc.n_seq, dsc.n_heads, dsc.Lq, dsc.Lk, dsc.dh, dsc.npass = n_seq, H, Lq, Lk, self.d // H, self.npass
+        dsc.q, dsc.q_seq_stride, dsc.ldq = q, qss, ldq
+        dsc.k, dsc.k_seq_stride, dsc.ldk = k, kss, ldk
+        dsc.v, dsc.v_seq_stride, dsc.ldv = v, vss, ldv
+        dsc.out, dsc.o_seq_stride, dsc.ldo = out, oss, ldo
+        dsc.lse, dsc.probs = lse, probs
+        dsc.drop_p, dsc.drop_site, dsc.drop_seed = 0.0, drop_site, 0
+        dsc.dout = dout
+        dsc.dq, dsc.dq_seq_stride, dsc.lddq = dq, dqss, lddq
+        dsc.dk, dsc.dk_seq_stride, dsc.lddk = dk, dkss, lddk
+        dsc.dv, dsc.dv_seq_stride, dsc.lddv = dv, dvss, lddv
+        if drop_site:
+            ws['drop'].append(dsc)
+        ws['keep'].append(dsc)
+        plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd'))
+        return dsc
+
+    def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta):
+        n_wg = self.lib.hftt_ln_bwd_wgs(M)
+        ws['ln_need'] = max(ws.get('ln_need', 0), n_wg * 2 * self.d * 4)
+        dsc = LnBwdDesc()
+        dsc.M, dsc.N = M, self.d
+        dsc.dy, dsc.r, dsc.mean, dsc.rstd, dsc.gamma = dy, r, mean, rstd, gamma
+        dsc.dr, dsc.dr_drop = dr, dr_drop
+        dsc.drop_p, dsc.drop_site, dsc.drop_seed = 0.0, drop_site, 0
+        ws['ln'].append(dsc)
+        if drop_site:
+            ws['drop'].append(dsc)
+        ws['keep'].append(dsc)
+        plan.append((self.lib.hftt_ln_bwd, (C.byref(dsc),), 'ln_bwd'))
+        plan.append(('ln_reduce', (n_wg, self.d, dgamma, dbeta, beta), 'ln_bwd_reduce'))
+
+    # ------------------------------------------------------------------ workspace + plans for one batch size
+    def workspace(self, B):
+        if B in self._ws:
+            return self._ws[B]
+        if not self.is_bound():
+            raise _capi.HfttError('engine parameters are not bound')
+        ws = {'bufs': {}, 'drop': [], 'keep': [], 'tn': [], 'ln': [], 'B': B}
+        self._site = 0
+        self._build_forward(ws)
+        self._build_backward(ws)
+        tnb = torch.empty(max(ws.get('tn_need', 8), 8) // 4 + 16, dtype=torch.float32, device=self.device)
+        lnb = torch.empty(max(ws.get('ln_need', 8), 8) // 4 + 16, dtype=torch.float32, device=self.device)
+        ws['bufs']['tn_ws'], ws['bufs']['ln_ws'] = tnb, lnb
+        for dsc in ws['tn']:
+            dsc.ws, dsc.ws_bytes = tnb.data_ptr(), tnb.numel() * 4
+        for dsc in ws['ln']:
+            dsc.ws = lnb.data_ptr()
+        ws['ln_ws_ptr'] = lnb.data_ptr()
+        self._ws[B] = ws
+        return ws
+
+    def _enc_layer_fwd(self, plan, ws, tag, key, pre, S, n_seq, L, H, x_in, x_in_ld=None):
+        """EncoderLayer (model_spec2midi.py:230-245).  Returns address of the layer output [S, d]."""
+        d, p = self.d, self.p
+        b = ws['bufs']
+        qkv = self._buf(ws, tag + '.qkv', S, 3 * d)
+        ctx = self._buf(ws, tag + '.ctx', S, d)
+        lse = self._buf(ws, tag + '.lse', n_seq * H * L)
+        r1 = self._buf(ws, tag + '.r1', S, d); x1 = self._buf(ws, tag + '.x1', S, d)
+        m1 = self._buf(ws, tag + '.m1', S); s1 = self._buf(ws, tag + '.s1', S)
+        h = self._buf(ws, tag + '.h', S, p)
+        r2 = self._buf(ws, tag + '.r2', S, d); x2 = self._buf(ws, tag + '.x2', S, d)
+        m2 = self._buf(ws, tag + '.m2', S); s2 = self._buf(ws, tag + '.s2', S)
+        sites = ws.setdefault('sites', {})
+        sa, so, sh, sf = (self._new_site() for _ in range(4))
+        sites[tag] = (sa, so, sh, sf)
+        gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
+        self._nt(plan, ws, S, 3 * d, d, x_in, d, self.Wp(key + '.sa.qkv'), self.Fp(key + '.sa.qkv_b'), qkv.data_ptr(), 3 * d)
+        q = qkv.data_ptr()
+        self._attn(plan, ws, False, n_seq, H, L, L, q, L * 3 * d, 3 * d, q + 4 * d, L * 3 * d, 3 * d, q + 8 * d, L * 3 * d, 3 * d,
+                   ctx.data_ptr(), L * d, d, lse.data_ptr(), drop_site=sa)
+        self._nt(plan, ws, S, d, d, ctx.data_ptr(), d, self.Wp(key + '.sa.o'), self.P(pre + 'self_attention.fc_o.bias'), x1.data_ptr(), d,
+                 drop_site=so, residual=x_in, ldr=d, ln=(gam, bet, r1.data_ptr(), m1.data_ptr(), s1.data_ptr()))
+        self._nt(plan, ws, S, p, d, x1.data_ptr(), d, self.Wp(key + '.f1'), self.P(pre + 'positionwise_feedforward.fc_1.bias'), h.data_ptr(), p,
+                 act=1, drop_site=sh)
+        self._nt(plan, ws, S, d, p, h.data_ptr(), p, self.Wp(key + '.f2'), self.P(pre + 'positionwise_feedforward.fc_2.bias'), x2.data_ptr(), d,
+                 drop_site=sf, residual=x1.data_ptr(), ldr=d, ln=(gam, bet, r2.data_ptr(), m2.data_ptr(), s2.data_ptr()))
+        return x2.data_ptr()
+
+    def _ffn_fwd(self, plan, ws, tag, key, pre, S, x_in, sites):
+        d, p = self.d, self.p
+        h = self._buf(ws, tag + '.h', S, p)
+        r = self._buf(ws, tag + '.fr', S, d); x = self._buf(ws, tag + '.fx', S, d)
+        m = self._buf(ws, tag + '.fm', S); s = self._buf(ws, tag + '.fs', S)
+        sh, sf = self._new_site(), self._new_site()
+        sites['ffn'] = (sh, sf)
+        gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
+        self._nt(plan, ws, S, p, d, x_in, d, self.Wp(key + '.f1'), self.P(pre + 'positionwise_feedforward.fc_1.bias'), h.data_ptr(), p,
+                 act=1, drop_site=sh)
+        self._nt(plan, ws, S, d, p, h.data_ptr(), p, self.Wp(key + '.f2'), self.P(pre + 'positionwise_feedforward.fc_2.bias'), x.data_ptr(), d,
+                 drop_site=sf, residual=x_in, ldr=d, ln=(gam, bet, r.data_ptr(), m.data_ptr(), s.data_ptr()))
+        return x.data_ptr()
+
+    def _build_forward(self, ws):
+        B, T, F, N, V, d, p = ws['B'], self.T, self.F, self.N, self.V, self.d, self.p
+        Se, Sn, BT, BN = B * T * F, B * T * N, B * T, B * N
+        plan = []
+        ws['sites'] = {}
+        spec = self._buf(ws, 'spec', B, F, self.W)
+        win = self._buf(ws, 'win', Se, self.Kp)
+        x0 = self._buf(ws, 'x0', Se, d)
+        e = 'encoder_spec2midi.'
+        plan.append((self.lib.hftt_im2win, (spec.data_ptr(), win.data_ptr(), B, F, T, self.n_proc, self.Kp), 'im2win'))
+        s_emb = self._new_site()
+        ws['sites']['embed'] = s_emb
+        self._nt(plan, ws, Se, d, self.Kp, win.data_ptr(), self.Kp, self.Wp('embed'), self.Fp('embed_b'), x0.data_ptr(), d,
+                 out_scale=math.sqrt(d), add_table=self.P(e + 'pos_embedding_freq.weight'), add_mod=F, drop_site=s_emb)
+        x = x0.data_ptr()
+        ws['enc_in'] = [x]
+        for i in range(self.Le):
+            x = self._enc_layer_fwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, x)
+            ws['enc_in'].append(x)
+        enc = x
+        # ---------------- decoder, frequency axis (cross attention notes x bins) ----------------
+        dd = 'decoder_spec2midi.'
+        H = self.Hd
+        pos_dec = self.P(dd + 'pos_embedding_freq.weight')
+        q0 = self._buf(ws, 'dec0.q0', N, d)
+        trg = None
+        ws['dec_out'] = []
+        for j in range(self.Ld):
+            tag = f'dec{j}'
+            sites = {}
+            ws['sites'][tag] = sites
+            pre = dd + ('layer_zero_freq.' if j == 0 else f'layers_freq.{j - 1}.')
+            gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
+            if j > 0:
+                sqkv = self._buf(ws, tag + '.sqkv', Sn, 3 * d)
+                sctx = self._buf(ws, tag + '.sctx', Sn, d)
+                slse = self._buf(ws, tag + '.slse', BT * H * N)
+                sr = self._buf(ws, tag + '.sr', Sn, d); sx = self._buf(ws, tag + '.sx', Sn, d)
+                sm = self._buf(ws, tag + '.sm', Sn); ss = self._buf(ws, tag + '.ss', Sn)
+                s_a, s_o = self._new_site(), self._new_site()
+                sites['self'] = (s_a, s_o)
+                self._nt(plan, ws, Sn, 3 * d, d, trg, d, self.Wp(tag + '.sa.qkv'), self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d)
+                q = sqkv.data_ptr()
+                self._attn(plan, ws, False, BT, H, N, N, q, N * 3 * d, 3 * d, q + 4 * d, N * 3 * d, 3 * d, q + 8 * d, N * 3 * d, 3 * d,
+                           sctx.data_ptr(), N * d, d, slse.data_ptr(), drop_site=s_a)
+                self._nt(plan, ws, Sn, d, d, sctx.data_ptr(), d, self.Wp(tag + '.sa.o'), self.P(pre + 'self_attention.fc_o.bias'), sx.data_ptr(), d,
+                         drop_site=s_o, residual=trg, ldr=d, ln=(gam, bet, sr.data_ptr(), sm.data_ptr(), ss.data_ptr()))
+                cross_in = sx.data_ptr()
+                cq = self._buf(ws, tag + '.cq', Sn, d)
+                self._nt(plan, ws, Sn, d, d, cross_in, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), cq.data_ptr(), d)
+                qaddr, qss = cq.data_ptr(), N * d
+                res, res_mod = cross_in, 0
+            else:
+                self._nt(plan, ws, N, d, d, pos_dec, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), q0.data_ptr(), d)
+                qaddr, qss = q0.data_ptr(), 0
+                res, res_mod = pos_dec, N
+            ckv = self._buf(ws, tag + '.ckv', Se, 2 * d)
+            cctx = self._buf(ws, tag + '.cctx', Sn, d)
+            clse = self._buf(ws, tag + '.clse', BT * H * N)
+            cr = self._buf(ws, tag + '.cr', Sn, d); cx = self._buf(ws, tag + '.cx', Sn, d)
+            cm = self._buf(ws, tag + '.cm', Sn); cs = self._buf(ws, tag + '.cs', Sn)
+            c_a, c_o = self._new_site(), self._new_site()
+            sites['cross'] = (c_a, c_o)
+            self._nt(plan, ws, Se, 2 * d, d, enc, d, self.Wp(tag + '.ca.kv'), self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d)
+            kk = ckv.data_ptr()
+            ad = self._attn(plan, ws, False, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + 4 * d, F * 2 * d, 2 * d,
+                            cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a)
+            if j == self.Ld - 1:
+                ws['attn_out_desc'] = ad
+            self._nt(plan, ws, Sn, d, d, cctx.data_ptr(), d, self.Wp(tag + '.ca.o'), self.P(pre + 'encoder_attention.fc_o.bias'), cx.data_ptr(), d,
+                     drop_site=c_o, residual=res, ldr=d, res_mod=res_mod, ln=(gam, bet, cr.data_ptr(), cm.data_ptr(), cs.data_ptr()))
+            trg = self._ffn_fwd(plan, ws, tag, tag, pre, Sn, cx.data_ptr(), sites)
+            ws['dec_out'].append(trg)
+        # ---------------- heads A ----------------
+        logits_f = self._buf(ws, 'logits_f', Sn, self.NHp)
+        self._nt(plan, ws, Sn, self.NH, d, trg, d, self.Wp('heads_f'), self.Fp('heads_f_b'), logits_f.data_ptr(), self.NHp)
+        plan.append(('heads', (logits_f.data_ptr(), 0), 'heads_split'))
+        # ---------------- decoder, time axis ----------------
+        y0 = self._buf(ws, 'y0', Sn, d)
+        s_t = self._new_site()
+        ws['sites']['time_embed'] = s_t
+        plan.append(('time_embed', (trg, self.P(dd + 'pos_embedding_time.weight'), y0.data_ptr(), s_t), 'time_embed_fwd'))
+        y = y0.data_ptr()
+        ws['time_in'] = [y]
+        for i in range(self.Ld):
+            y = self._enc_layer_fwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, y)
+            ws['time_in'].append(y)
+        logits_t = self._buf(ws, 'logits_t', Sn, self.NHp)
+        self._nt(plan, ws, Sn, self.NH, d, y, d, self.Wp('heads_t'), self.Fp('heads_t_b'), logits_t.data_ptr(), self.NHp)
+        plan.append(('heads', (logits_t.data_ptr(), 1), 'heads_split'))
+        ws['fwd'] = plan
+        ws['enc'] = enc
+
+    # ---- backward of one EncoderLayer; dx_out lives in GA on entry (grad of the layer output) and on exit (grad of input)
+    def _enc_layer_bwd(self, plan, ws, tag, key, pre, S, n_seq, L, H, x_in, G, extra_dx=0):
+        d, p = self.d, self.p
+        b = ws['bufs']
+        sa, so, sh, sf = ws['sites'][tag]
+        GA, GB, GC, Gh, Gq = G
+        gam = self.P(pre + 'layer_norm.weight')
+        dgam, dbet = self.G(pre + 'layer_norm.weight'), self.G(pre + 'layer_norm.bias')
+        pf = pre + 'positionwise_feedforward.'
+        pa = pre + 'self_attention.'
+        use_drop = self.dropout > 0.0
+        # LN2 backward
+        self._lnb(plan, ws, S, GA, b[tag + '.r2'].data_ptr(), b[tag + '.m2'].data_ptr(), b[tag + '.s2'].data_ptr(), gam,
+                  GB, GC if use_drop else 0, sf, dgam, dbet, 0.0)
+        dbr = GC if use_drop else GB
+        # fc_2
+        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))])
+        self._nt(plan, ws, S, p, d, dbr, d, self.Wp(key + '.f2_t'), 0, Gh, p, gate=b[tag + '.h'].data_ptr(), ldg=p,
+                 gate_scale=('inv_keep',))
+        # fc_1
+        self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))])
+        self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d)
+        # LN1 backward
+        self._lnb(plan, ws, S, GA, b[tag + '.r1'].data_ptr(), b[tag + '.m1'].data_ptr(), b[tag + '.s1'].data_ptr(), gam,
+                  GB, GC if use_drop else 0, so, dgam, dbet, 1.0)
+        # fc_o
+        self._tn(plan, ws, S, d, d, dbr, d, b[tag + '.ctx'].data_ptr(), d, [(0, d, self.G(pa + 'fc_o.weight'), self.G(pa + 'fc_o.bias'))])
+        self._nt(plan, ws, S, d, d, dbr, d, self.Wp(key + '.sa.o_t'), 0, GA, d)
+        # attention
+        qkv = b[tag + '.qkv'].data_ptr()
+        self._attn(plan, ws, True, n_seq, H, L, L, qkv, L * 3 * d, 3 * d, qkv + 4 * d, L * 3 * d, 3 * d, qkv + 8 * d, L * 3 * d, 3 * d,
+                   b[tag + '.ctx'].data_ptr(), L * d, d, b[tag + '.lse'].data_ptr(), drop_site=sa, dout=GA,
+                   dq=Gq, dqss=L * 3 * d, lddq=3 * d, dk=Gq + 4 * d, dkss=L * 3 * d, lddk=3 * d, dv=Gq + 8 * d, dvss=L * 3 * d, lddv=3 * d)
+        # qkv projection
+        self._tn(plan, ws, S, 3 * d, d, Gq, 3 * d, x_in, d,
+                 [(0, d, self.G(pa + 'fc_q.weight'), self.G(pa + 'fc_q.bias')), (d, d, self.G(pa + 'fc_k.weight'), self.G(pa + 'fc_k.bias')),
+                  (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))])
+        self._nt(plan, ws, S, d, 3 * d, Gq, 3 * d, self.Wp(key + '.sa.qkv_t'), 0, GA, d, residual=GB, ldr=d)
+
+    def _ffn_bwd(self, plan, ws, tag, key, pre, S, x_in, G, ln_beta):
+        """FFN + LN block of the decoder layers: grad of output in GA -> grad of x_in in GA."""
+        d, p = self.d, self.p
+        b = ws['bufs']
+        sh, sf = ws['sites'][tag]['ffn']
+        GA, GB, GC, Gh, Gq = G
+        gam = self.P(pre + 'layer_norm.weight')
+        dgam, dbet = self.G(pre + 'layer_norm.weight'), self.G(pre + 'layer_norm.bias')
+        pf = pre + 'positionwise_feedforward.'
+        use_drop = self.dropout > 0.0
+        self._lnb(plan, ws, S, GA, b[tag + '.fr'].data_ptr(), b[tag + '.fm'].data_ptr(), b[tag + '.fs'].data_ptr(), gam,
+                  GB, GC if use_drop else 0, sf, dgam, dbet, ln_beta)
+        dbr = GC if use_drop else GB
+        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))])
+        self._nt(plan, ws, S, p, d, dbr, d, self.Wp(key + '.f2_t'), 0, Gh, p, gate=b[tag + '.h'].data_ptr(), ldg=p, gate_scale=('inv_keep',))
+        self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))])
+        self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d)
+
+    def _build_backward(self, ws):
+        B, T, F, N, V, d, p = ws['B'], self.T, self.F, self.N, self.V, self.d, self.p
+        Se, Sn, BT, BN = B * T * F, B * T * N, B * T, B * N
+        b = ws['bufs']
+        plan = []
+        H = self.Hd
+        dd = 'decoder_spec2midi.'
+        e = 'encoder_spec2midi.'
+        use_drop = self.dropout > 0.0
+        # gradient scratch: note-token sized and bin-token sized sets
+        nGA = self._buf(ws, 'g.nA', Sn, d).data_ptr(); nGB = self._buf(ws, 'g.nB', Sn, d).data_ptr()
+        nGC = self._buf(ws, 'g.nC', Sn, d).data_ptr(); nGD = self._buf(ws, 'g.nD', Sn, d).data_ptr()
+        nGh = self._buf(ws, 'g.nh', Sn, p).data_ptr(); nGq = self._buf(ws, 'g.nq', Sn, 3 * d).data_ptr()
+        eGA = self._buf(ws, 'g.eA', Se, d).data_ptr(); eGB = self._buf(ws, 'g.eB', Se, d).data_ptr()
+        eGC = self._buf(ws, 'g.eC', Se, d).data_ptr()
+        eGh = self._buf(ws, 'g.eh', Se, p).data_ptr(); eGq = self._buf(ws, 'g.eq', Se, 3 * d).data_ptr()
+        dlog = self._buf(ws, 'g.dlog', Sn, self.NHp).data_ptr()
+        cs_n = max(F * d, N * d, T * d)
+        cs_ws = self._buf(ws, 'g.cs', self.lib.hftt_colsum_ws_bytes(1, cs_n) // 4 + 16).data_ptr()
+        dq0s = self._buf(ws, 'g.dq0', N * d).data_ptr()
+        # incoming gradients of the 8 differentiable outputs (filled by the loss kernel or by autograd glue)
+        for nm in ('onset_A', 'offset_A', 'mpe_A', 'onset_B', 'offset_B', 'mpe_B'):
+            self._buf(ws, 'd.' + nm, Sn)
+        self._buf(ws, 'd.velocity_A', Sn, V); self._buf(ws, 'd.velocity_B', Sn, V)
+
+        def head_segs(tag):
+            return [(0, V, self.G(f'{dd}fc_velocity_{tag}.weight'), self.G(f'{dd}fc_velocity_{tag}.bias')),
+                    (V, 1, self.G(f'{dd}fc_onset_{tag}.weight'), self.G(f'{dd}fc_onset_{tag}.bias')),
+                    (V + 1, 1, self.G(f'{dd}fc_offset_{tag}.weight'), self.G(f'{dd}fc_offset_{tag}.bias')),
+                    (V + 2, 1, self.G(f'{dd}fc_mpe_{tag}.weight'), self.G(f'{dd}fc_mpe_{tag}.bias'))]
+
+        # ---- heads B + time layers ----
+        plan.append(('heads_bwd', ('B', dlog, 1), 'heads_split_bwd'))
+        y_last = ws['time_in'][-1]
+        self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, y_last, d, head_segs('time'))
+        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_t_t'), 0, nGA, d)
+        Gn = (nGA, nGB, nGC, nGh, nGq)
+        for i in reversed(range(self.Ld)):
+            self._enc_layer_bwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, ws['time_in'][i], Gn)
+        # ---- heads A, then the time-embedding transpose back onto the note-major gradient ----
+        plan.append(('heads_bwd', ('A', dlog, 0), 'heads_split_bwd'))
+        f_last = ws['dec_out'][-1]
+        self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, f_last, d, head_segs('freq'))
+        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_f_t'), 0, nGD, d)
+        plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed']), 'time_embed_bwd'))
+        plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws), 'colsum'))
+        # ---- frequency decoder layers, last to first.  Gradient stream lives in A (= nGD), per-sequence dq in Q1 (= nGA);
+        #      the encoder-output gradient accumulates in eGA ----
+        A, Bf, Cf, Q1 = nGD, nGB, nGC, nGA
+        Gd = (A, Bf, Cf, nGh, nGq)
+        dbr = Cf if use_drop else Bf
+        first_enc_grad = True
+        enc = ws['enc']
+        for j in reversed(range(self.Ld)):
+            tag = f'dec{j}'
+            pre = dd + ('layer_zero_freq.' if j == 0 else f'layers_freq.{j - 1}.')
+            sites = ws['sites'][tag]
+            gam = self.P(pre + 'layer_norm.weight')
+            dgam, dbet = self.G(pre + 'layer_norm.weight'), self.G(pre + 'layer_norm.bias')
+            pc = pre + 'encoder_attention.'
+            self._ffn_bwd(plan, ws, tag, tag, pre, Sn, b[tag + '.cx'].data_ptr(), Gd, 0.0)
+            c_a, c_o = sites['cross']
+            self._lnb(plan, ws, Sn, A, b[tag + '.cr'].data_ptr(), b[tag + '.cm'].data_ptr(), b[tag + '.cs'].data_ptr(), gam,
+                      Bf, Cf if use_drop else 0, c_o, dgam, dbet, 1.0)
+            self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.cctx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_o.weight'), self.G(pc + 'fc_o.bias'))])
+            self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.ca.o_t'), 0, A, d)
+            kk = b[tag + '.ckv'].data_ptr()
+            if j > 0:
+                qaddr, qss = b[tag + '.cq'].data_ptr(), N * d
+            else:
+                qaddr, qss = b['dec0.q0'].data_ptr(), 0
+            # dq (per sequence) -> Q1 ; dk,dv -> eGq viewed as [Se, 2d]
+            self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + 4 * d, F * 2 * d, 2 * d,
+                       b[tag + '.cctx'].data_ptr(), N * d, d, b[tag + '.clse'].data_ptr(), drop_site=c_a, dout=A,
+                       dq=Q1, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + 4 * d, dvss=F * 2 * d, lddv=2 * d)
+            self._tn(plan, ws, Se, 2 * d, d, eGq, 2 * d, enc, d,
+                     [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))])
+            if first_enc_grad:
+                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d)
+                first_enc_grad = False
+            else:
+                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, residual=eGA, ldr=d)
+            if j > 0:
+                # q projection of the cross attention (input sx, which is also the residual of this block)
+                self._tn(plan, ws, Sn, d, d, Q1, d, b[tag + '.sx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
+                self._nt(plan, ws, Sn, d, d, Q1, d, self.Wp(tag + '.ca.q_t'), 0, A, d, residual=Bf, ldr=d)
+                # self-attention block (input trg = previous layer output)
+                s_a, s_o = sites['self']
+                ps = pre + 'self_attention.'
+                trg = ws['dec_out'][j - 1]
+                self._lnb(plan, ws, Sn, A, b[tag + '.sr'].data_ptr(), b[tag + '.sm'].data_ptr(), b[tag + '.ss'].data_ptr(), gam,
+                          Bf, Cf if use_drop else 0, s_o, dgam, dbet, 1.0)
+                self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.sctx'].data_ptr(), d, [(0, d, self.G(ps + 'fc_o.weight'), self.G(ps + 'fc_o.bias'))])
+                self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.sa.o_t'), 0, A, d)
+                q = b[tag + '.sqkv'].data_ptr()
+                self._attn(plan, ws, True, BT, H, N, N, q, N * 3 * d, 3 * d, q + 4 * d, N * 3 * d, 3 * d, q + 8 * d, N * 3 * d, 3 * d,
+                           b[tag + '.sctx'].data_ptr(), N * d, d, b[tag + '.slse'].data_ptr(), drop_site=s_a, dout=A,
+                           dq=nGq, dqss=N * 3 * d, lddq=3 * d, dk=nGq + 4 * d, dkss=N * 3 * d, lddk=3 * d, dv=nGq + 8 * d, dvss=N * 3 * d, lddv=3 * d)
+                self._tn(plan, ws, Sn, 3 * d, d, nGq, 3 * d, trg, d,
+                         [(0, d, self.G(ps + 'fc_q.weight'), self.G(ps + 'fc_q.bias')), (d, d, self.G(ps + 'fc_k.weight'), self.G(ps + 'fc_k.bias')),
+                          (2 * d, d, self.G(ps + 'fc_v.weight'), self.G(ps + 'fc_v.bias'))])
+                self._nt(plan, ws, Sn, d, 3 * d, nGq, 3 * d, self.Wp(tag + '.sa.qkv_t'), 0, A, d, residual=Bf, ldr=d)
+            else:
+                # layer zero: query = fc_q(pos_embedding_freq) shared by all sequences, residual = pos_embedding_freq
+                gpos = self.G(dd + 'pos_embedding_freq.weight')
+                plan.append(('colsum', (Bf, BT, N * d, N * d, gpos, 0.0, cs_ws), 'colsum'))       # residual path (undropped dr)
+                plan.append(('colsum', (Q1, BT, N * d, N * d, dq0s, 0.0, cs_ws), 'colsum'))       # sum of per-sequence dq
+                self._tn(plan, ws, N, d, d, dq0s, d, self.P(dd + 'pos_embedding_freq.weight'), d,
+                         [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
+                self._nt(plan, ws, N, d, d, dq0s, d, self.Wp(tag + '.ca.q_t'), 0, gpos, d, residual=gpos, ldr=d)
+        # ---- encoder layers ----
+        Ge = (eGA, eGB, eGC, eGh, eGq)
+        for i in reversed(range(self.Le)):
+            self._enc_layer_bwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, ws['enc_in'][i], Ge)
+        # ---- embedding ----
+        plan.append(('dropout_bwd', (eGA, Se * d, ws['sites']['embed']), 'dropout_bwd'))
+        plan.append(('colsum', (eGA, BT, F * d, F * d, self.G(e + 'pos_embedding_freq.weight'), 0.0, cs_ws), 'colsum'))
+        self._tn(plan, ws, Se, d, self.Kp, eGA, d, b['win'].data_ptr(), self.Kp, [(0, d, self.dweff.data_ptr(), self.dbeff.data_ptr())],
+                 out_scale=math.sqrt(d))
+        plan.append((self.lib.hftt_embed_fold_bwd, (C.byref(self.fold),), 'embed_fold_bwd'))
+        ws['bwd'] = plan
+
+    # ------------------------------------------------------------------ running plans
+    def _run(self, ws, plan, stream, outs=None, seed=0, p=0.0):
+        L = self.lib
+        B, T, N, V, d = ws['B'], self.T, self.N, self.V, self.d
+        inv_keep = 1.0 / (1.0 - p) if p > 0.0 else 1.0
+        for fn, args, name in plan:
+            if not isinstance(fn, str):
+                rc = fn(*args, stream)
+            elif fn == 'ln_reduce':
+                n_wg, n, dg, db, beta = args
+                rc = L.hftt_ln_bwd_reduce(ws['ln_ws_ptr'], n_wg, n, dg, db, beta, stream)
+            elif fn == 'heads':
+                logits, tm = args
+                o = outs[5:9] if tm else outs[0:4]
+                rc = L.hftt_heads_split(logits, self.NHp, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), B, T, N, V, tm, stream)
+            elif fn == 'heads_bwd':
+                side, dlog, tm = args
+                b = ws['bufs']
+                po = outs[5:8] if tm else outs[0:3]
+                rc = L.hftt_heads_split_bwd(po[0].data_ptr(), po[1].data_ptr(), po[2].data_ptr(),
+                                            b['d.onset_' + side].data_ptr(), b['d.offset_' + side].data_ptr(), b['d.mpe_' + side].data_ptr(),
+                                            b['d.velocity_' + side].data_ptr(), dlog, self.NHp, B, T, N, V, tm, stream)
+            elif fn == 'time_embed':
+                x, pos, y, site = args
+                rc = L.hftt_time_embed_fwd(x, pos, y, B, T, N, d, math.sqrt(d), p, site, seed, stream)
+            elif fn == 'time_embed_bwd':
+                dy, dx, dym, site = args
+                rc = L.hftt_time_embed_bwd(dy, dx, dym, B, T, N, d, math.sqrt(d), p, site, seed, 1, stream)
+            elif fn == 'colsum':
+                x, rows, n, ld, out, beta, wsp = args
+                rc = L.hftt_colsum(x, rows, n, ld, out, beta, wsp, stream)
+            elif fn == 'dropout_bwd':
+                g, n, site = args
+                rc = L.hftt_dropout_bwd(g, n, p, site, seed, stream) if p > 0.0 else 0
+            else:
+                raise _capi.HfttError('unknown plan op %s' % fn)
+            if rc != 0:
+                check(rc, name)
+
+    def _patch(self, ws, p, seed):
+        inv_keep = 1.0 / (1.0 - p) if p > 0.0 else 1.0
+        for dsc in ws['drop']:
+            dsc.drop_p = p
+            dsc.drop_seed = seed
+        for dsc in ws.get('gate_descs', ()):
+            dsc.gate_scale = inv_keep
+
+    def forward(self, spec, training=False, outputs=None):
+        """spec [B, n_bin, M+T+M] (any device/dtype/strides) -> 9-tuple of fresh fp32 tensors on the engine's device."""
+        if spec.dim() != 3 or spec.shape[1] != self.F or spec.shape[2] != self.W:
+            raise _capi.HfttError('input_spec must be [B, %d, %d], got %s' % (self.F, self.W, tuple(spec.shape)))
+        if not self.is_bound():
+            raise _capi.HfttError('engine parameters are not bound (call bind first)')
+        B = spec.shape[0]
+        ws = self.workspace(B)
+        self._cur_ws = ws
+        ws['bufs']['spec'].copy_(spec)
+        T, N, V = self.T, self.N, self.V
+        dev = self.device
+        outs = outputs
+        if outs is None:
+            outs = [torch.empty(B, T, N, device=dev) for _ in range(3)] + [torch.empty(B, T, N, V, device=dev)] \
+                + [torch.empty(B, T, self.Hd, N, self.F, device=dev)] \
+                + [torch.empty(B, T, N, device=dev) for _ in range(3)] + [torch.empty(B, T, N, V, device=dev)]
+        ws['attn_out_desc'].probs = outs[4].data_ptr()
+        p = self.dropout if training else 0.0
+        if training:
+            self.step_counter += 1
+        seed = (self.base_seed * 1000003 + self.step_counter) & 0xFFFFFFFFFFFFFFFF
+        ws['seed'], ws['p'], ws['outs'] = seed, p, outs
+        self._patch(ws, p, seed)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        self.prepare_weights(stream)
+        self._run(ws, ws['fwd'], stream, outs=outs, seed=seed, p=p)
+        self.generation += 1
+        ws['generation'] = self.generation
+        return tuple(outs)
+
+    def backward(self, B, generation=None):
+        """Backward through the most recent forward of batch size B; the gradients of the 8 outputs must be in
+        the 'd.*' workspace buffers.  Fills flat_grads (every parameter written exactly once)."""
+        ws = self._ws.get(B)
+        if ws is None or 'outs' not in ws:
+            raise _capi.HfttError('backward called without a forward')
+        if generation is not None and generation != ws['generation']:
+            raise _capi.HfttError('backward called for a stale forward (activations were overwritten by a later forward)')
+        self._cur_ws = ws
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._patch(ws, ws['p'], ws['seed'])
+        self._run(ws, ws['bwd'], stream, outs=ws['outs'], seed=ws['seed'], p=ws['p'])
+
+    # ------------------------------------------------------------------ fused loss (training/train.py:141-153)
+    def loss(self, B, labels, weight_A=1.0, weight_B=1.0, with_grad=True):
+        """labels: (onset, offset, mpe, velocity) device tensors [B,T,N] (fp32, fp32, fp32, int64).
+        Returns a [9] device tensor (total + 8 terms); with_grad fills the 'd.*' buffers."""
+        ws = self._ws[B]
+        outs = ws['outs']
+        b = ws['bufs']
+        n = B * self.T * self.N
+        if 'loss_ws' not in b:
+            b['loss_ws'] = torch.empty(self.lib.hftt_loss_ws_bytes(n) // 4 + 16, dtype=torch.float32, device=self.device)
+            b['loss_out'] = torch.zeros(16, dtype=torch.float32, device=self.device)
+        lo, lf, lm, lv = labels
+        for t, dt in ((lo, torch.float32), (lf, torch.float32), (lm, torch.float32), (lv, torch.int64)):
+            if t.dtype != dt or not t.is_contiguous() or t.device != self.device or t.numel() != n:
+                raise _capi.HfttError('labels must be contiguous device tensors [B,T,N] (fp32,fp32,fp32,int64)')
+        dsc = LossDesc()
+        dsc.n, dsc.V = n, self.V
+        for i, k in enumerate((0, 1, 2, 5, 6, 7)):
+            dsc.prob[i] = outs[k].data_ptr()
+        dsc.vel[0], dsc.vel[1] = outs[3].data_ptr(), outs[8].data_ptr()
+        dsc.label_onset, dsc.label_offset, dsc.label_mpe, dsc.label_velocity = lo.data_ptr(), lf.data_ptr(), lm.data_ptr(), lv.data_ptr()
+        dsc.weight_A, dsc.weight_B, dsc.grad_scale = weight_A, weight_B, 1.0
+        if with_grad:
+            for i, nm in enumerate(('onset_A', 'offset_A', 'mpe_A', 'onset_B', 'offset_B', 'mpe_B')):
+                dsc.d_prob[i] = b['d.' + nm].data_ptr()
+            dsc.d_vel[0], dsc.d_vel[1] = b['d.velocity_A'].data_ptr(), b['d.velocity_B'].data_ptr()
+        dsc.loss_out, dsc.ws = b['loss_out'].data_ptr(), b['loss_ws'].data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.hftt_loss(C.byref(dsc), stream), 'loss')
+        return b['loss_out'][:9]

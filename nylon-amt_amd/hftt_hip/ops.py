@@ -1,0 +1,250 @@
+"""Tensor-level wrappers of single C-ABI kernels (used by tests, by ``model.amt`` for the log-mel front end and by
+tools).  Each wrapper only builds the POD descriptor from torch tensors and enqueues the kernel on torch's
+current stream; results are torch tensors.  No arithmetic happens in Python/torch here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from ._capi import (AttnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, check, lib)
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and t.device.type != 'cuda':
+            raise HfttError('hftt ops need ROCm device tensors (got %s); there is no CPU fallback' % t.device)
+
+
+def _align(x, a):
+    return (x + a - 1) // a * a
+
+
+def split_weight(w: torch.Tensor, transposed=False, n_pad=64):
+    """fp32 [rows, cols] -> bf16 hi/lo planes (int16 tensors) [align(rows, n_pad), cols] (or the transpose)."""
+    _need_cuda(w)
+    w = w.contiguous().float()
+    rows, cols = w.shape
+    if transposed:
+        out_r, out_c = _align(cols, n_pad), _align(rows, 32)
+    else:
+        out_r, out_c = _align(rows, n_pad), cols
+    hi = torch.zeros(out_r, out_c, dtype=torch.int16, device=w.device)
+    lo = torch.zeros_like(hi)
+    ent = (PrepEntry * 1)(PrepEntry(0, 0, rows, cols, cols, out_c, 1 if transposed else 0, 0))
+    table = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).to(w.device)
+    check(lib().hftt_prep_weights(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), 0, table.data_ptr(), 1, _stream(w.device)), 'prep_weights')
+    return hi, lo
+
+
+def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_mod=0, gate=None, gate_scale=1.0,
+            drop_p=0.0, drop_site=0, drop_seed=0, residual=None, res_mod=0, ln=None, planes=None):
+    """C = epi(A @ W.T + bias); W fp32 [N, K].  ln = (gamma, beta) -> returns (C, pre_ln, mean, rstd)."""
+    _need_cuda(A, W)
+    M, K = A.shape
+    N = W.shape[0]
+    hi, lo = planes if planes is not None else split_weight(W)
+    Cout = torch.empty(M, N, device=A.device)
+    d = GemmNtDesc()
+    d.M, d.N, d.K, d.npass = M, N, K, npass
+    d.A, d.lda = A.data_ptr(), A.stride(0)
+    d.Whi, d.Wlo = hi.data_ptr(), lo.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else 0
+    d.C, d.ldc = Cout.data_ptr(), N
+    d.act, d.out_scale = act, out_scale
+    if add_table is not None:
+        d.add_table, d.add_mod = add_table.data_ptr(), add_mod
+    if gate is not None:
+        d.gate, d.ldg, d.gate_scale = gate.data_ptr(), gate.stride(0), gate_scale
+    d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
+    if residual is not None:
+        d.residual, d.ldr, d.res_mod = residual.data_ptr(), residual.stride(0), (res_mod or M)
+    extra = ()
+    if ln is not None:
+        pre = torch.empty(M, N, device=A.device)
+        mean = torch.empty(M, device=A.device)
+        rstd = torch.empty(M, device=A.device)
+        d.ln_gamma, d.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+        d.pre_ln_out, d.ln_mean, d.ln_rstd = pre.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        extra = (pre, mean, rstd)
+    check(lib().hftt_gemm_nt(C.byref(d), _stream(A.device)), 'gemm_nt')
+    return (Cout,) + extra if extra else Cout
+
+
+def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True):
+    """dW[N,K] = out_scale * dY[M,N].T @ X[M,K]; db[N] = colsum(dY)."""
+    _need_cuda(dY, X)
+    M, N = dY.shape
+    K = X.shape[1]
+    dW = torch.empty(N, K, device=dY.device)
+    db = torch.empty(N, device=dY.device)
+    L = lib()
+    wsb = L.hftt_gemm_tn_ws_bytes(M, N, K)
+    ws = torch.empty(wsb // 4 + 16, device=dY.device)
+    d = GemmTnDesc()
+    d.M, d.N, d.K, d.npass = M, N, K, npass
+    d.dY, d.lddy, d.X, d.ldx = dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0)
+    d.out_scale, d.beta, d.n_seg = out_scale, 0.0, 1
+    d.seg_row0[0], d.seg_rows[0], d.seg_dw[0], d.seg_db[0] = 0, N, dW.data_ptr(), (db.data_ptr() if with_bias else 0)
+    d.K_out = K
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    check(L.hftt_gemm_tn(C.byref(d), _stream(dY.device)), 'gemm_tn')
+    return dW, db
+
+
+def _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed):
+    n_seq, Lq, dm = q.shape
+    Lk = k.shape[1]
+    d = AttnDesc()
+    d.n_seq, d.n_heads, d.Lq, d.Lk, d.dh, d.npass = n_seq, n_heads, Lq, Lk, dm // n_heads, npass
+    d.q, d.q_seq_stride, d.ldq = q.data_ptr(), q.stride(0), q.stride(1)
+    d.k, d.k_seq_stride, d.ldk = k.data_ptr(), k.stride(0), k.stride(1)
+    d.v, d.v_seq_stride, d.ldv = v.data_ptr(), v.stride(0), v.stride(1)
+    d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
+    return d
+
+
+def attn_fwd(q, k, v, n_heads, npass=3, want_probs=False, drop_p=0.0, drop_site=0, drop_seed=0):
+    """q [n_seq, Lq, d], k/v [n_seq, Lk, d] (any row/seq strides) -> out [n_seq, Lq, d], lse [n_seq, H, Lq](, probs)."""
+    _need_cuda(q, k, v)
+    n_seq, Lq, dm = q.shape
+    Lk = k.shape[1]
+    out = torch.empty(n_seq, Lq, dm, device=q.device)
+    lse = torch.empty(n_seq, n_heads, Lq, device=q.device)
+    probs = torch.empty(n_seq, n_heads, Lq, Lk, device=q.device) if want_probs else None
+    d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed)
+    d.out, d.o_seq_stride, d.ldo = out.data_ptr(), out.stride(0), out.stride(1)
+    d.lse = lse.data_ptr()
+    d.probs = probs.data_ptr() if want_probs else 0
+    check(lib().hftt_attn_fwd(C.byref(d), _stream(q.device)), 'attn_fwd')
+    return (out, lse, probs) if want_probs else (out, lse)
+
+
+def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0, drop_seed=0):
+    _need_cuda(q, k, v, out, dout)
+    dq = torch.empty(q.shape, device=q.device)
+    dk = torch.empty(k.shape, device=q.device)
+    dv = torch.empty(v.shape, device=q.device)
+    d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed)
+    d.out, d.o_seq_stride, d.ldo = out.data_ptr(), out.stride(0), out.stride(1)
+    d.lse = lse.data_ptr()
+    assert dout.stride() == out.stride()
+    d.dout = dout.data_ptr()
+    d.dq, d.dq_seq_stride, d.lddq = dq.data_ptr(), dq.stride(0), dq.stride(1)
+    d.dk, d.dk_seq_stride, d.lddk = dk.data_ptr(), dk.stride(0), dk.stride(1)
+    d.dv, d.dv_seq_stride, d.lddv = dv.data_ptr(), dv.stride(0), dv.stride(1)
+    check(lib().hftt_attn_bwd(C.byref(d), _stream(q.device)), 'attn_bwd')
+    return dq, dk, dv
+
+
+def ln_bwd(dy, r, mean, rstd, gamma, drop_p=0.0, drop_site=0, drop_seed=0):
+    _need_cuda(dy, r)
+    M, N = dy.shape
+    L = lib()
+    n_wg = L.hftt_ln_bwd_wgs(M)
+    ws = torch.empty(n_wg * 2 * N, device=dy.device)
+    dr = torch.empty_like(dy)
+    drd = torch.empty_like(dy) if drop_p > 0 else None
+    d = LnBwdDesc()
+    d.M, d.N = M, N
+    d.dy, d.r, d.mean, d.rstd, d.gamma = dy.data_ptr(), r.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr()
+    d.dr, d.dr_drop = dr.data_ptr(), (drd.data_ptr() if drd is not None else 0)
+    d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
+    d.ws = ws.data_ptr()
+    st = _stream(dy.device)
+    check(L.hftt_ln_bwd(C.byref(d), st), 'ln_bwd')
+    dg = torch.empty(N, device=dy.device)
+    db = torch.empty(N, device=dy.device)
+    check(L.hftt_ln_bwd_reduce(ws.data_ptr(), n_wg, N, dg.data_ptr(), db.data_ptr(), 0.0, st), 'ln_bwd_reduce')
+    return dr, drd, dg, db
+
+
+def colsum(x, beta=0.0, out=None):
+    _need_cuda(x)
+    rows, n = x.shape
+    L = lib()
+    ws = torch.empty(L.hftt_colsum_ws_bytes(rows, n) // 4 + 16, device=x.device)
+    if out is None:
+        out = torch.zeros(n, device=x.device)
+    check(L.hftt_colsum(x.data_ptr(), rows, n, x.stride(0), out.data_ptr(), beta, ws.data_ptr(), _stream(x.device)), 'colsum')
+    return out
+
+
+def adam_step(p, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _need_cuda(p, g, m, v)
+    check(lib().hftt_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), step, lr, beta1, beta2, eps,
+                               grad_scale, _stream(p.device)), 'adam_step')
+
+
+# ------------------------------------------------------------------------------------------------
+# log-mel front end (model/amt.py:55-63)
+# ------------------------------------------------------------------------------------------------
+class LogMel:
+    """Device-resident tables (hann window, FFT twiddles, sparse slaney/htk mel filterbank) + the kernel launch."""
+
+    def __init__(self, device, sr=16000, n_fft=2048, hop=256, n_mels=256, log_offset=1e-8):
+        self.device = torch.device(device)
+        _need_cuda(torch.empty(0, device=self.device))
+        self.sr, self.n_fft, self.hop, self.n_mels, self.log_offset = sr, n_fft, hop, n_mels, log_offset
+        n = np.arange(n_fft, dtype=np.float64)
+        window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)                       # periodic hann
+        k = np.arange(n_fft // 2, dtype=np.float64)
+        tw = np.concatenate([np.cos(2.0 * np.pi * k / n_fft), np.sin(2.0 * np.pi * k / n_fft)])
+        fb = self.mel_filterbank(sr, n_fft, n_mels)                                # [n_freqs, n_mels] float64
+        starts, lens, offs, weights = [], [], [], []
+        for m in range(n_mels):
+            nz = np.nonzero(fb[:, m])[0]
+            if len(nz) == 0:
+                starts.append(0); lens.append(0); offs.append(len(weights)); continue
+            s, e = int(nz[0]), int(nz[-1]) + 1
+            starts.append(s); lens.append(e - s); offs.append(len(weights))
+            weights.extend(fb[s:e, m].tolist())
+        self.nnz = len(weights)
+        dev = self.device
+        self.window = torch.tensor(window, dtype=torch.float32, device=dev)
+        self.twiddle = torch.tensor(tw, dtype=torch.float32, device=dev)
+        self.fb_start = torch.tensor(starts, dtype=torch.int32, device=dev)
+        self.fb_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+        self.fb_off = torch.tensor(offs, dtype=torch.int32, device=dev)
+        self.fb_w = torch.tensor(weights if weights else [0.0], dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def mel_filterbank(sr, n_fft, n_mels):
+        """htk mel points, triangles on linspace(0, sr/2, n_fft/2+1), slaney area normalisation (float32 steps as
+        torchaudio.functional.melscale_fbanks computes them)."""
+        n_freqs = n_fft // 2 + 1
+        all_freqs = np.linspace(0, sr // 2, n_freqs, dtype=np.float32)
+        m_max = 2595.0 * math.log10(1.0 + (sr / 2.0) / 700.0)
+        m_pts = np.linspace(0.0, m_max, n_mels + 2, dtype=np.float32)
+        f_pts = (700.0 * (np.power(np.float32(10.0), m_pts / np.float32(2595.0)) - 1.0)).astype(np.float32)
+        f_diff = f_pts[1:] - f_pts[:-1]
+        slopes = f_pts[None, :] - all_freqs[:, None]
+        down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+        up = slopes[:, 2:] / f_diff[1:]
+        fb = np.maximum(0.0, np.minimum(down, up))
+        enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
+        return (fb * enorm[None, :]).astype(np.float64)
+
+    def __call__(self, wave_mono):
+        """wave [n_samples] fp32 at self.sr (device tensor) -> log-mel [n_frames, n_mels], n_frames = 1 + n//hop."""
+        _need_cuda(wave_mono)
+        wave = wave_mono.contiguous().float()
+        n = wave.numel()
+        n_frames = 1 + n // self.hop
+        feat = torch.empty(n_frames, self.n_mels, device=self.device)
+        d = LogmelDesc()
+        d.wave, d.n_samples = wave.data_ptr(), n
+        d.n_fft, d.hop, d.n_mels, d.n_frames = self.n_fft, self.hop, self.n_mels, n_frames
+        d.window, d.twiddle = self.window.data_ptr(), self.twiddle.data_ptr()
+        d.fb_start, d.fb_len, d.fb_off, d.fb_w = self.fb_start.data_ptr(), self.fb_len.data_ptr(), self.fb_off.data_ptr(), self.fb_w.data_ptr()
+        d.log_offset = self.log_offset
+        d.feat = feat.data_ptr()
+        check(lib().hftt_logmel(C.byref(d), _stream(self.device)), 'logmel')
+        return feat

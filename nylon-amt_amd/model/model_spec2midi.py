@@ -1,0 +1,219 @@
+"""Drop-in replacement of the reference's ``model/model_spec2midi.py`` (hFT-Transformer "1-F-D-T" model) whose
+arithmetic runs in hand-written HIP kernels for MI355X (libhftt_hip.so) instead of torch.nn ops.
+
+Kept from the reference (hftt_code/model/model_spec2midi.py):
+  * class names, module path ``model.model_spec2midi`` (pickle compatibility, amt.py:24-25),
+  * constructor signatures (:10, :42, :113, :223, :248, :275, :309, :363) and submodule/parameter names, so
+    ``state_dict()`` has the reference's 115/165 keys and ``model.apply(initialize_weights)`` (m_training.py:31-33,141)
+    touches exactly the same tensors,
+  * ``Model_SPEC2MIDI.forward(input_spec[B, n_bin, margin+n_frame+margin])`` -> the 9-tuple of :35.
+The sub-blocks only hold parameters; they execute fused inside ``Model_SPEC2MIDI.forward``.  There is no CPU path:
+calling the model with its parameters on the CPU (or without the built library) raises ``HfttError``.
+"""
+import copy
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from hftt_hip._capi import HfttError   # noqa: E402
+
+
+def _fused_only(self, *a, **k):
+    raise HfttError('%s holds parameters only; it runs fused inside Model_SPEC2MIDI.forward' % type(self).__name__)
+
+
+##
+## Model
+##
+class Model_SPEC2MIDI(nn.Module):
+    def __init__(self, encoder, decoder):
+        super().__init__()
+        self.encoder_spec2midi = encoder
+        self.decoder_spec2midi = decoder
+        self.hftt_precision = os.environ.get('HFTT_PRECISION', 'parity')   # 'parity' (split-bf16, <=1e-3) or 'bf16'
+        self.hftt_seed = 1234
+
+    # ---- engine management -------------------------------------------------------------------
+    def hftt_config(self):
+        e, d = self.encoder_spec2midi, self.decoder_spec2midi
+        if e.hid_dim != d.hid_dim or e.n_frame != d.n_frame or e.n_bin != d.n_bin:
+            raise HfttError('encoder/decoder shapes disagree')
+        return dict(n_margin=(e.n_proc - 1) // 2, n_frame=e.n_frame, n_bin=e.n_bin, cnn_channel=e.cnn_channel,
+                    cnn_kernel=e.cnn_kernel, hid_dim=e.hid_dim, pf_dim=e.pf_dim, enc_layer=len(e.layers_freq),
+                    dec_layer=len(d.layers_time), enc_head=e.n_heads, dec_head=d.n_heads, n_note=d.n_note,
+                    n_velocity=d.n_velocity)
+
+    def hftt_engine(self):
+        """Return the HIP engine bound to this module's parameters (built / rebound lazily)."""
+        from hftt_hip.engine import HfttEngine
+        p0 = next(self.parameters())
+        if p0.device.type != 'cuda':
+            raise HfttError('Model_SPEC2MIDI runs on MI355X only: move it to the GPU first (parameters are on %s); '
+                            'there is no CPU fallback' % p0.device)
+        eng = self.__dict__.get('_hftt')
+        drop = float(self.encoder_spec2midi.dropout.p)
+        if eng is None or eng.device != p0.device or eng.dropout != drop:
+            eng = HfttEngine(self.hftt_config(), p0.device, precision=self.hftt_precision, dropout=drop, seed=self.hftt_seed)
+            self.__dict__['_hftt'] = eng
+        if eng.precision != self.hftt_precision:
+            eng.set_precision(self.hftt_precision)
+        if not eng.is_bound():
+            eng.bind(self.named_parameters())
+        return eng
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_hftt', None)
+        # parameters are views into the engine's flat buffer: clone them out so each pickles its own storage
+        state['_modules'] = copy.deepcopy(state['_modules'])
+        return state
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        self.__dict__.pop('_hftt', None)     # .to()/.cuda()/.float() replace parameter storage: rebind on next use
+        return r
+
+    def forward(self, input_spec):
+        #input_spec = [batch_size, n_bin, margin+n_frame+margin] (8, 256, 192)
+        eng = self.hftt_engine()
+        params = [p for _, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            from hftt_hip.autograd import HfttModelFunction
+            return HfttModelFunction.apply(input_spec, eng, self.training, *params)
+        return eng.forward(input_spec, training=self.training)
+
+
+##
+## Encoder
+##
+class Encoder_SPEC2MIDI(nn.Module):
+    def __init__(self, n_margin, n_frame, n_bin, cnn_channel, cnn_kernel, hid_dim, n_layers, n_heads, pf_dim, dropout, device):
+        super().__init__()
+        self.device = device
+        self.n_frame = n_frame
+        self.n_bin = n_bin
+        self.cnn_channel = cnn_channel
+        self.cnn_kernel = cnn_kernel
+        self.hid_dim = hid_dim
+        self.n_heads = n_heads
+        self.pf_dim = pf_dim
+        self.conv = nn.Conv2d(1, self.cnn_channel, kernel_size=(1, self.cnn_kernel))
+        self.n_proc = n_margin * 2 + 1
+        self.cnn_dim = self.cnn_channel * (self.n_proc - (self.cnn_kernel - 1))
+        self.tok_embedding_freq = nn.Linear(self.cnn_dim, hid_dim)
+        self.pos_embedding_freq = nn.Embedding(n_bin, hid_dim)
+        self.layers_freq = nn.ModuleList([EncoderLayer(hid_dim, n_heads, pf_dim, dropout, device) for _ in range(n_layers)])
+        self.dropout = nn.Dropout(dropout)
+        self.scale_freq = float(hid_dim) ** 0.5
+
+    forward = _fused_only
+
+
+##
+## Decoder
+##
+class Decoder_SPEC2MIDI(nn.Module):
+    def __init__(self, n_frame, n_bin, n_note, n_velocity, hid_dim, n_layers, n_heads, pf_dim, dropout, device):
+        super().__init__()
+        self.device = device
+        self.n_note = n_note
+        self.n_frame = n_frame
+        self.n_velocity = n_velocity
+        self.n_bin = n_bin
+        self.hid_dim = hid_dim
+        self.n_heads = n_heads
+        self.pf_dim = pf_dim
+        self.sigmoid = nn.Sigmoid()
+        self.dropout = nn.Dropout(dropout)
+
+        # CAfreq
+        self.pos_embedding_freq = nn.Embedding(n_note, hid_dim)
+        self.layer_zero_freq = DecoderLayer_Zero(hid_dim, n_heads, pf_dim, dropout, device)
+        self.layers_freq = nn.ModuleList([DecoderLayer(hid_dim, n_heads, pf_dim, dropout, device) for _ in range(n_layers - 1)])
+
+        self.fc_onset_freq = nn.Linear(hid_dim, 1)
+        self.fc_offset_freq = nn.Linear(hid_dim, 1)
+        self.fc_mpe_freq = nn.Linear(hid_dim, 1)
+        self.fc_velocity_freq = nn.Linear(hid_dim, self.n_velocity)
+
+        # SAtime
+        self.scale_time = float(hid_dim) ** 0.5
+        self.pos_embedding_time = nn.Embedding(n_frame, hid_dim)
+        self.layers_time = nn.ModuleList([EncoderLayer(hid_dim, n_heads, pf_dim, dropout, device) for _ in range(n_layers)])
+
+        self.fc_onset_time = nn.Linear(hid_dim, 1)
+        self.fc_offset_time = nn.Linear(hid_dim, 1)
+        self.fc_mpe_time = nn.Linear(hid_dim, 1)
+        self.fc_velocity_time = nn.Linear(hid_dim, self.n_velocity)
+
+    forward = _fused_only
+
+
+##
+## sub functions (parameter containers; names and registration order as in the reference)
+##
+class EncoderLayer(nn.Module):
+    def __init__(self, hid_dim, n_heads, pf_dim, dropout, device):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(hid_dim)
+        self.self_attention = MultiHeadAttentionLayer(hid_dim, n_heads, dropout, device)
+        self.positionwise_feedforward = PositionwiseFeedforwardLayer(hid_dim, pf_dim, dropout)
+        self.dropout = nn.Dropout(dropout)
+
+    forward = _fused_only
+
+
+class DecoderLayer_Zero(nn.Module):
+    def __init__(self, hid_dim, n_heads, pf_dim, dropout, device):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(hid_dim)
+        self.encoder_attention = MultiHeadAttentionLayer(hid_dim, n_heads, dropout, device)
+        self.positionwise_feedforward = PositionwiseFeedforwardLayer(hid_dim, pf_dim, dropout)
+        self.dropout = nn.Dropout(dropout)
+
+    forward = _fused_only
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, hid_dim, n_heads, pf_dim, dropout, device):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(hid_dim)
+        self.self_attention = MultiHeadAttentionLayer(hid_dim, n_heads, dropout, device)
+        self.encoder_attention = MultiHeadAttentionLayer(hid_dim, n_heads, dropout, device)
+        self.positionwise_feedforward = PositionwiseFeedforwardLayer(hid_dim, pf_dim, dropout)
+        self.dropout = nn.Dropout(dropout)
+
+    forward = _fused_only
+
+
+class MultiHeadAttentionLayer(nn.Module):
+    def __init__(self, hid_dim, n_heads, dropout, device):
+        super().__init__()
+        assert hid_dim % n_heads == 0
+        self.hid_dim = hid_dim
+        self.n_heads = n_heads
+        self.head_dim = hid_dim // n_heads
+        self.fc_q = nn.Linear(hid_dim, hid_dim)
+        self.fc_k = nn.Linear(hid_dim, hid_dim)
+        self.fc_v = nn.Linear(hid_dim, hid_dim)
+        self.fc_o = nn.Linear(hid_dim, hid_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.scale = float(self.head_dim) ** 0.5
+
+    forward = _fused_only
+
+
+class PositionwiseFeedforwardLayer(nn.Module):
+    def __init__(self, hid_dim, pf_dim, dropout):
+        super().__init__()
+        self.fc_1 = nn.Linear(hid_dim, pf_dim)
+        self.fc_2 = nn.Linear(pf_dim, hid_dim)
+        self.dropout = nn.Dropout(dropout)
+
+    forward = _fused_only

@@ -1,0 +1,90 @@
+"""Shared helpers for the tests (test infrastructure; may import oracle/)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+for p in (ROOT, os.path.join(ROOT, 'nylon-amt_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import hftt_oracle as O   # noqa: E402
+
+MINI = O.HfttConfig(n_margin=4, n_frame=16, n_bin=48, cnn_channel=4, cnn_kernel=5, hid_dim=64, pf_dim=96,
+                    enc_layer=2, dec_layer=2, enc_head=2, dec_head=2, n_note=12, n_velocity=16)
+
+OUT_NAMES = ['onset_A', 'offset_A', 'mpe_A', 'velocity_A', 'attention', 'onset_B', 'offset_B', 'mpe_B', 'velocity_B']
+
+
+def initialize_weights(m):   # call restated from training/m_training.py:31-33
+    if hasattr(m, 'weight') and m.weight.dim() > 1:
+        nn.init.xavier_uniform_(m.weight.data)
+
+
+def build_model(cfg, seed, dropout=0.0, device='cpu'):
+    """Replays m_training.py:109-141: seed, positional construction, .to(device), apply(initialize_weights)."""
+    from model.model_spec2midi import Encoder_SPEC2MIDI, Decoder_SPEC2MIDI, Model_SPEC2MIDI
+    torch.manual_seed(seed)
+    enc = Encoder_SPEC2MIDI(cfg.n_margin, cfg.n_frame, cfg.n_bin, cfg.cnn_channel, cfg.cnn_kernel, cfg.hid_dim,
+                            cfg.enc_layer, cfg.enc_head, cfg.pf_dim, dropout, device)
+    dec = Decoder_SPEC2MIDI(cfg.n_frame, cfg.n_bin, cfg.n_note, cfg.n_velocity, cfg.hid_dim, cfg.dec_layer,
+                            cfg.dec_head, cfg.pf_dim, dropout, device)
+    model = Model_SPEC2MIDI(enc, dec)
+    model.apply(initialize_weights)      # on CPU, exactly like make_golden.py (same RNG stream as the reference)
+    return model
+
+
+def perturb(model, seed):
+    """Same perturbation as tests/golden/make_golden.py (non-trivial LayerNorm affine and biases)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 1:
+                if name.endswith('layer_norm.weight'):
+                    p.add_(0.2 * torch.randn(p.shape, generator=g))
+                else:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def cfg_from_golden(g):
+    keys = list(O.PAPER.as_dict().keys())
+    return O.HfttConfig(**{k: int(v) for k, v in zip(keys, g['cfg'])})
+
+
+def sd_cpu(model):
+    return {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
+
+
+# ---- numpy emulation of the device dropout RNG (csrc/hftt_common.h: hftt_hash / hftt_keep_thr) ----
+def keep_mask(seed, site, idx, p):
+    with np.errstate(over='ignore'):
+        x = idx.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(site + 1) + np.uint64(seed)
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    h = (x >> np.uint64(32)).astype(np.uint64)
+    k = (1.0 - float(np.float32(p))) * 4294967296.0
+    thr = 0xFFFFFFFF if k >= 4294967295.0 else int(k)
+    return h < np.uint64(thr)
+
+
+def keep_mask_t(seed, site, shape, p):
+    n = int(np.prod(shape))
+    return torch.from_numpy(keep_mask(seed, site, np.arange(n, dtype=np.uint64), p).reshape(shape))
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def max_err(a, b):
+    return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
