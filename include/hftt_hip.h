@@ -10,8 +10,10 @@
  *     the caller owns all buffers, including workspaces sized by the *_ws_bytes helpers;
  *   - return value 0 = ok, non-zero = error (message via hftt_last_error(), thread-local);
  *   - all activations / gradients are fp32 row-major in HBM; `npass` selects the MFMA arithmetic:
- *       1 = bf16 operands, fp32 accumulate ("bf16" throughput mode),
- *       3 = split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): the <=1e-3 parity mode.
+ *       1 = operands rounded to bf16, fp32 accumulate (v_mfma_f32_32x32x16_bf16): the "bf16" throughput mode,
+ *       3 = exact fp32 products and accumulation (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate): the <=1e-3
+ *           parity mode.  (A 3-pass split-bf16 scheme was measured first: its ~1e-5 relative error is not enough
+ *           for the reference's first encoder layer, whose attention logits reach ~1e4 on raw log-mel input.)
  */
 #ifndef HFTT_HIP_H
 #define HFTT_HIP_H
@@ -28,21 +30,22 @@ const char* hftt_last_error(void);
 int hftt_device_cus(void);
 
 /* ---------------------------------------------------------------------------------------------
- * Weight preparation.  fp32 parameters -> bf16 hi/lo planes in the layouts the GEMMs consume
+ * Weight preparation.  fp32 parameters -> the layouts the GEMMs consume (concatenated / transposed), as a bf16
+ * plane `wbf` (npass 1) and/or an fp32 copy `wf32` (npass 3); either may be NULL.
  * (replaces nothing in the reference: it is the operand format of the MFMA kernels).
  * Each entry copies a [rows, cols] fp32 matrix (row stride src_ld) from `params + src_off` to
- * planes `whi/wlo + dst_off`, either as-is (dst[r*dst_ld + c]) or transposed (dst[c*dst_ld + r]).
- * Entries may also write fp32 copies (bias concatenation): kind 2 copies `rows*cols` floats to
+ * `dst + dst_off`, either as-is (dst[r*dst_ld + c]) or transposed (dst[c*dst_ld + r]).
+ * Entries may also write fp32 vectors (bias concatenation): kind 2 copies `rows*cols` floats to
  * `fdst + dst_off`.
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
   int64_t src_off;   /* element offset into params */
   int64_t dst_off;   /* element offset into the destination plane(s) */
   int32_t rows, cols, src_ld, dst_ld;
-  int32_t kind;      /* 0 = split copy, 1 = split transposed copy, 2 = fp32 copy into fdst */
+  int32_t kind;      /* 0 = copy, 1 = transposed copy (both into wbf/wf32), 2 = fp32 copy into fdst */
   int32_t pad;
 } hftt_prep_entry;
-int hftt_prep_weights(const float* params, uint16_t* whi, uint16_t* wlo, float* fdst,
+int hftt_prep_weights(const float* params, uint16_t* wbf, float* wf32, float* fdst,
                       const hftt_prep_entry* table_dev, int n_entries, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -59,12 +62,14 @@ int hftt_prep_weights(const float* params, uint16_t* whi, uint16_t* wlo, float* 
  *   if ln_gamma:  pre_ln_out = v;  v = LayerNorm(v)*gamma+beta (eps 1e-5, over N; needs N in {64,128,256})
  *                 mean/rstd written per row                              (nn.LayerNorm, :225,236)
  *   C[row*ldc+col] = v
- * W is given as prepared bf16 planes [N_pad, K] (K % 32 == 0, N_pad % 64 == 0, rows >= N zero).
+ * W is the prepared matrix [N_pad, K] (K % 32 == 0, N_pad % 64 == 0, rows >= N zero): bf16 when npass == 1,
+ * fp32 when npass == 3 (passed through the same pointer).
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
   int32_t M, N, K, npass;
   const float* A; int64_t lda;
-  const uint16_t* Whi; const uint16_t* Wlo;      /* [N_pad, K] */
+  const void* W;                                  /* [N_pad, K] bf16 (npass 1) or fp32 (npass 3) */
+  const void* reserved0;
   const float* bias;                              /* [N] or NULL */
   float* C; int64_t ldc;
   int32_t act; float out_scale;
@@ -100,7 +105,7 @@ int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused multi-head attention, one workgroup per (sequence, head); Lq, Lk <= 256, dh in {32, 64}.
- * forward:  P = softmax(Q K^T / sqrt(dh));  out = dropout(P) V;  lse = logsumexp rows;
+ * forward:  P = softmax(Q K^T / sqrt(dh));  out = dropout(P) V;  lse = per-row (max score, 1/sum exp) pairs;
  *           probs (optional) = P (pre-dropout)         -- model_spec2midi.py:335-354, returned P :360
  * backward: recomputes P from (Q,K,lse); dQ,dK,dV      -- autograd of the same lines
  * Q/K/V/out element (seq, row, head, c) lives at  base + seq*seq_stride + row*ld + head*dh + c.
@@ -111,7 +116,7 @@ typedef struct {
   const float* k; int64_t k_seq_stride; int64_t ldk;
   const float* v; int64_t v_seq_stride; int64_t ldv;
   float* out; int64_t o_seq_stride; int64_t ldo;
-  float* lse;                 /* [n_seq, n_heads, Lq] */
+  float* lse;                 /* [n_seq, n_heads, Lq, 2]: row max of the scaled scores, 1 / sum(exp(score - max)) */
   float* probs;               /* [n_seq, n_heads, Lq, Lk] or NULL */
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   /* backward only */
@@ -128,7 +133,7 @@ int hftt_attn_bwd(const hftt_attn_desc* d, void* stream);
  * (model_spec2midi.py:65-85) into one Linear over the n_proc-wide window:
  *   tok[j] = sum_u Weff[j,u] * spec[f, t+u] + beff[j],
  *   Weff[j,u] = sum_{c, kk, w+kk=u} Wtok[j, c*nw + w] * wconv[c,kk],  beff[j] = btok[j] + sum_c bconv[c] sum_w Wtok[j,c*nw+w]
- * fold_fwd writes Weff as bf16 hi/lo planes [d_pad, Kp] (Kp = n_proc rounded up to 32, zero padded) + beff.
+ * fold_fwd writes Weff [d_pad, Kp] (Kp = n_proc rounded up to 32, zero padded) as bf16 and/or fp32, + beff.
  * fold_bwd maps (dWeff [d, Kp] fp32, dbeff [d]) back to the four reference parameters' gradients.
  * im2win materialises A[(b,t,f), u] = spec[b, f, t+u] (zero for u >= n_proc), row stride Kp.
  * --------------------------------------------------------------------------------------------- */
@@ -138,7 +143,7 @@ typedef struct {
   const float* bconv;   /* [C] */
   const float* wtok;    /* [d, C*(n_proc-kw+1)] */
   const float* btok;    /* [d] */
-  uint16_t* weff_hi; uint16_t* weff_lo;   /* [d_pad, Kp] */
+  uint16_t* weff_bf; float* weff_f32;     /* [d_pad, Kp]; either may be NULL */
   float* beff;          /* [d] */
   /* backward */
   const float* dweff;   /* [d, Kp] */

@@ -1,5 +1,5 @@
 // Fused multi-head attention backward (gfx950), one workgroup per (sequence, head), one wave per 32 keys.
-//   recompute P = exp(Q K^T/sqrt(dh) - lse);  dP = dO V^T;  dS = P*(dP - rowsum(dO*O))/sqrt(dh)
+//   recompute P = exp(Q K^T/sqrt(dh) - rowmax) * inv_rowsum (the forward's row statistics => the forward's P);  dP = dO V^T;  dS = P*(dP - rowsum(dO*O))/sqrt(dh)
 //   dV = Pd^T dO,  dK = dS^T Q,  dQ = dS K                                  -- include/hftt_hip.h (hftt_attn_bwd)
 // Layout choices (all lane maps verified by tools/probe_mfma):
 //   * S and dP are produced with the KEY on the MFMA lane (B operand = this wave's K / V rows, held in registers for
@@ -17,34 +17,42 @@ int hftt_attn_check(const hftt_attn_desc* d, bool bwd);
 
 namespace {
 
+// npass == 1: bf16 planes as described above.  npass == 3 (parity): every tile stays fp32 in LDS / registers and all
+// products run on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (one f32 per lane per operand; the accumulator tiles of P and dS are
+// fed back as B operands register-for-register).
 template <int KT, int DH, int NPASS>
 struct AbCfg {
+  static constexpr bool F32 = (NPASS == 3);
   static constexpr int LKP = KT * 32;
-  static constexpr int PL = (NPASS == 3) ? 2 : 1;
-  static constexpr int RSK = (DH == 64) ? 96 : 32;   // tr-read friendly (64 mod 128 bytes)
-  static constexpr int RSQ = DH + 8;                 // b128-read friendly
-  static constexpr int RSS = LKP + 8;
+  static constexpr int RSK = F32 ? DH + 1 : ((DH == 64) ? 96 : 32);   // bf16: tr-read friendly (64 mod 128 bytes)
+  static constexpr int RSQ = F32 ? DH + 1 : DH + 8;                   // bf16: b128-read friendly
+  static constexpr int RSS = F32 ? LKP + 1 : LKP + 8;
   static constexpr int K_ELEMS = LKP * RSK;
   static constexpr int Q_ELEMS = 32 * RSQ;
   static constexpr int S_ELEMS = 32 * RSS;
-  static constexpr int SHORTS = PL * (K_ELEMS + 2 * Q_ELEMS + S_ELEMS);
-  static constexpr int LDS_BYTES = SHORTS * 2 + 64 * 4;
+  static constexpr int ELEMS = K_ELEMS + 2 * Q_ELEMS + S_ELEMS;
+  static constexpr int LDS_BYTES = ELEMS * (F32 ? 4 : 2) + 96 * 4;
   static constexpr int NTHR = KT * 64;
 };
 
 template <int KT, int DH, int NPASS>
 __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc g) {
   using Cfg = AbCfg<KT, DH, NPASS>;
-  constexpr int PL = Cfg::PL, RSK = Cfg::RSK, RSQ = Cfg::RSQ, RSS = Cfg::RSS, LKP = Cfg::LKP, NTHR = Cfg::NTHR;
-  constexpr int KS = DH / 16, NT = DH / 32, F4R = DH / 4;
+  constexpr bool F32 = Cfg::F32;
+  constexpr int RSK = Cfg::RSK, RSQ = Cfg::RSQ, RSS = Cfg::RSS, LKP = Cfg::LKP, NTHR = Cfg::NTHR;
+  constexpr int KS = DH / 16, NT = DH / 32, F4R = DH / 4, HD = DH / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* sm = reinterpret_cast<unsigned short*>(smem);
-  unsigned short* Ks[2] = {sm, sm + (PL - 1) * Cfg::K_ELEMS};
-  unsigned short* Qs[2] = {sm + PL * Cfg::K_ELEMS, sm + PL * Cfg::K_ELEMS + (PL - 1) * Cfg::Q_ELEMS};
-  unsigned short* Os[2] = {Qs[0] + PL * Cfg::Q_ELEMS, Qs[0] + PL * Cfg::Q_ELEMS + (PL - 1) * Cfg::Q_ELEMS};
-  unsigned short* Ss[2] = {Os[0] + PL * Cfg::Q_ELEMS, Os[0] + PL * Cfg::Q_ELEMS + (PL - 1) * Cfg::S_ELEMS};
-  float* lse_s = reinterpret_cast<float*>(sm + Cfg::SHORTS);
+  unsigned short* Ks16 = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Qs16 = Ks16 + Cfg::K_ELEMS;
+  unsigned short* Os16 = Qs16 + Cfg::Q_ELEMS;
+  unsigned short* Ss16 = Os16 + Cfg::Q_ELEMS;
+  float* Ks32 = reinterpret_cast<float*>(smem);
+  float* Qs32 = Ks32 + Cfg::K_ELEMS;
+  float* Os32 = Qs32 + Cfg::Q_ELEMS;
+  float* Ss32 = Os32 + Cfg::Q_ELEMS;
+  float* lse_s = reinterpret_cast<float*>(smem + (size_t)Cfg::ELEMS * (F32 ? 4 : 2));
   float* delta_s = lse_s + 32;
+  float* inv_s = lse_s + 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -55,52 +63,55 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
 
-  auto pack4 = [&](const float4& f, uint2& ph, uint2& pl) {
-    const float v[4] = {f.x, f.y, f.z, f.w};
-    unsigned short hi[4], lo[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      if (PL == 2) split_bf16(v[e], hi[e], lo[e]); else hi[e] = f2bf(v[e]);
-    }
-    ph.x = hi[0] | ((unsigned)hi[1] << 16); ph.y = hi[2] | ((unsigned)hi[3] << 16);
-    pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16);
+  auto pack4 = [&](const float4& f) {
+    uint2 ph;
+    ph.x = f2bf(f.x) | ((unsigned)f2bf(f.y) << 16); ph.y = f2bf(f.z) | ((unsigned)f2bf(f.w) << 16);
+    return ph;
   };
+  auto put_row4 = [&](float* dst, const float4& f) { dst[0] = f.x; dst[1] = f.y; dst[2] = f.z; dst[3] = f.w; };
 
   const float* kb = g.k + (long)seq * g.k_seq_stride + head * DH;
   const float* vb = g.v + (long)seq * g.v_seq_stride + head * DH;
-  // ---- stage all of K (bf16 planes, row-major) for the dQ product ----
+  // ---- stage all of K (row-major) for the dQ product ----
   for (int i = tid; i < LKP * F4R; i += NTHR) {
     const int key = i / F4R, c4 = i % F4R;
     float4 kf = make_float4(0.f, 0.f, 0.f, 0.f);
     if (key < Lk) kf = *reinterpret_cast<const float4*>(kb + (long)key * g.ldk + c4 * 4);
-    uint2 ph, pl;
-    pack4(kf, ph, pl);
-    *reinterpret_cast<uint2*>(Ks[0] + key * RSK + c4 * 4) = ph;
-    if (PL == 2) *reinterpret_cast<uint2*>(Ks[PL - 1] + key * RSK + c4 * 4) = pl;
+    if (F32) put_row4(Ks32 + key * RSK + c4 * 4, kf);
+    else *reinterpret_cast<uint2*>(Ks16 + key * RSK + c4 * 4) = pack4(kf);
   }
   // ---- this wave's K and V rows as B-operand fragments (B[k = dh][col = key]) ----
   const int mykey = wave * 32 + lr;
-  bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];
+  bf16x8 kfh[KS], vfh[KS];        // bf16 path
+  float kf32[HD], vf32[HD];       // fp32 path: K/V[key][HD*lh + t]
+  if (F32) {
 #pragma unroll
-  for (int s = 0; s < KS; s++) {
-    float kv[8], vv[8];
-    if (mykey < Lk) {
-      const float4 a0 = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + 16 * s + 8 * lh);
-      const float4 a1 = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + 16 * s + 8 * lh + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + 16 * s + 8 * lh);
-      const float4 b1 = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + 16 * s + 8 * lh + 4);
-      kv[0] = a0.x; kv[1] = a0.y; kv[2] = a0.z; kv[3] = a0.w; kv[4] = a1.x; kv[5] = a1.y; kv[6] = a1.z; kv[7] = a1.w;
-      vv[0] = b0.x; vv[1] = b0.y; vv[2] = b0.z; vv[3] = b0.w; vv[4] = b1.x; vv[5] = b1.y; vv[6] = b1.z; vv[7] = b1.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
+    for (int t4 = 0; t4 < HD / 4; t4++) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (mykey < Lk) {
+        a = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + HD * lh + 4 * t4);
+        b = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + HD * lh + 4 * t4);
+      }
+      kf32[4 * t4] = a.x; kf32[4 * t4 + 1] = a.y; kf32[4 * t4 + 2] = a.z; kf32[4 * t4 + 3] = a.w;
+      vf32[4 * t4] = b.x; vf32[4 * t4 + 1] = b.y; vf32[4 * t4 + 2] = b.z; vf32[4 * t4 + 3] = b.w;
     }
+  } else {
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      unsigned short h1, l1 = 0, h2, l2 = 0;
-      if (PL == 2) { split_bf16(kv[e], h1, l1); split_bf16(vv[e], h2, l2); }
-      else { h1 = f2bf(kv[e]); h2 = f2bf(vv[e]); }
-      kfh[s][e] = (short)h1; kfl[s][e] = (short)l1; vfh[s][e] = (short)h2; vfl[s][e] = (short)l2;
+    for (int s = 0; s < KS; s++) {
+      float kv[8], vv[8];
+      if (mykey < Lk) {
+        const float4 a0 = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + 16 * s + 8 * lh);
+        const float4 a1 = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + 16 * s + 8 * lh + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + 16 * s + 8 * lh);
+        const float4 b1 = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + 16 * s + 8 * lh + 4);
+        kv[0] = a0.x; kv[1] = a0.y; kv[2] = a0.z; kv[3] = a0.w; kv[4] = a1.x; kv[5] = a1.y; kv[6] = a1.z; kv[7] = a1.w;
+        vv[0] = b0.x; vv[1] = b0.y; vv[2] = b0.z; vv[3] = b0.w; vv[4] = b1.x; vv[5] = b1.y; vv[6] = b1.z; vv[7] = b1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) { kfh[s][e] = (short)f2bf(kv[e]); vfh[s][e] = (short)f2bf(vv[e]); }
     }
   }
   f32x16 dKT[NT], dVT[NT];
@@ -127,19 +138,20 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         df = *reinterpret_cast<const float4*>(dobase + (long)q * g.ldo + c4 * 4);
         of = *reinterpret_cast<const float4*>(obase + (long)q * g.ldo + c4 * 4);
       }
-      uint2 ph, pl;
-      pack4(qf, ph, pl);
-      *reinterpret_cast<uint2*>(Qs[0] + row * RSQ + c4 * 4) = ph;
-      if (PL == 2) *reinterpret_cast<uint2*>(Qs[PL - 1] + row * RSQ + c4 * 4) = pl;
-      pack4(df, ph, pl);
-      *reinterpret_cast<uint2*>(Os[0] + row * RSQ + c4 * 4) = ph;
-      if (PL == 2) *reinterpret_cast<uint2*>(Os[PL - 1] + row * RSQ + c4 * 4) = pl;
+      if (F32) {
+        put_row4(Qs32 + row * RSQ + c4 * 4, qf);
+        put_row4(Os32 + row * RSQ + c4 * 4, df);
+      } else {
+        *reinterpret_cast<uint2*>(Qs16 + row * RSQ + c4 * 4) = pack4(qf);
+        *reinterpret_cast<uint2*>(Os16 + row * RSQ + c4 * 4) = pack4(df);
+      }
       float dot = df.x * of.x + df.y * of.y + df.z * of.z + df.w * of.w;
 #pragma unroll
       for (int o = F4R / 2; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
       if (c4 == 0) {
         delta_s[row] = dot;
-        lse_s[row] = (q < Lq) ? g.lse[sh * Lq + q] : 0.f;
+        lse_s[row] = (q < Lq) ? g.lse[(sh * Lq + q) * 2] : 0.f;
+        inv_s[row] = (q < Lq) ? g.lse[(sh * Lq + q) * 2 + 1] : 0.f;
       }
     }
     __syncthreads();   // (b)
@@ -148,22 +160,26 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
     f32x16 sacc, pacc;
 #pragma unroll
     for (int r = 0; r < 16; r++) { sacc[r] = 0.f; pacc[r] = 0.f; }
+    if (F32) {
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-      const int off = lr * RSQ + 16 * s + 8 * lh;
-      const bf16x8 qh = lds_read_b128(Qs[0] + off);
-      const bf16x8 ql = (PL == 2) ? lds_read_b128(Qs[PL - 1] + off) : qh;
-      sacc = mfma32_split<NPASS>(qh, ql, kfh[s], kfl[s], sacc);
-      const bf16x8 oh = lds_read_b128(Os[0] + off);
-      const bf16x8 ol = (PL == 2) ? lds_read_b128(Os[PL - 1] + off) : oh;
-      pacc = mfma32_split<NPASS>(oh, ol, vfh[s], vfl[s], pacc);
+      for (int t = 0; t < HD; t++) {
+        sacc = mfma32_f32(Qs32[lr * RSQ + HD * lh + t], kf32[t], sacc);
+        pacc = mfma32_f32(Os32[lr * RSQ + HD * lh + t], vf32[t], pacc);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        const int off = lr * RSQ + 16 * s + 8 * lh;
+        sacc = mfma32(lds_read_b128(Qs16 + off), kfh[s], sacc);
+        pacc = mfma32(lds_read_b128(Os16 + off), vfh[s], pacc);
+      }
     }
     const bool key_ok = mykey < Lk;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int ql_ = acc_row32(r, lh);
       const float arg = sacc[r] * scale - lse_s[ql_];
-      float p = (NPASS == 3) ? expf(arg) : __expf(arg);
+      float p = (F32 ? expf(arg) : __expf(arg)) * inv_s[ql_];
       if (!key_ok) p = 0.f;
       float pd = p, dp = pacc[r];
       if (g.drop_p > 0.f) {
@@ -176,54 +192,60 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       pacc[r] = p * (dp - delta_s[ql_]) * scale;           // dS (scaled): for dK, dQ
     }
     // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS ----
+    if (F32) {
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) {
-      bf16x8 ph, pl, sh_, sl_;
+      for (int r = 0; r < 16; r++) {
+        const int qrow = acc_row32(r, lh);
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        unsigned short h1, l1 = 0, h2, l2 = 0;
-        if (PL == 2) { split_bf16(sacc[8 * s2 + e], h1, l1); split_bf16(pacc[8 * s2 + e], h2, l2); }
-        else { h1 = f2bf(sacc[8 * s2 + e]); h2 = f2bf(pacc[8 * s2 + e]); }
-        ph[e] = (short)h1; pl[e] = (short)l1; sh_[e] = (short)h2; sl_[e] = (short)l2;
+        for (int n = 0; n < NT; n++) {
+          dVT[n] = mfma32_f32(Os32[qrow * RSQ + n * 32 + lr], sacc[r], dVT[n]);
+          dKT[n] = mfma32_f32(Qs32[qrow * RSQ + n * 32 + lr], pacc[r], dKT[n]);
+        }
       }
+    } else {
 #pragma unroll
-      for (int n = 0; n < NT; n++) {
-        const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
-        const int r0 = 16 * s2 + 4 * lh + qq;
-        const bf16x8 oh = join4(lds_read_tr16(Os[0] + r0 * RSQ + col), lds_read_tr16(Os[0] + (r0 + 8) * RSQ + col));
-        const bf16x8 ol = (PL == 2) ? join4(lds_read_tr16(Os[PL - 1] + r0 * RSQ + col), lds_read_tr16(Os[PL - 1] + (r0 + 8) * RSQ + col)) : oh;
-        dVT[n] = mfma32_split<NPASS>(oh, ol, ph, pl, dVT[n]);
-        const bf16x8 qh = join4(lds_read_tr16(Qs[0] + r0 * RSQ + col), lds_read_tr16(Qs[0] + (r0 + 8) * RSQ + col));
-        const bf16x8 ql = (PL == 2) ? join4(lds_read_tr16(Qs[PL - 1] + r0 * RSQ + col), lds_read_tr16(Qs[PL - 1] + (r0 + 8) * RSQ + col)) : qh;
-        dKT[n] = mfma32_split<NPASS>(qh, ql, sh_, sl_, dKT[n]);
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 ph, sh_;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { ph[e] = (short)f2bf(sacc[8 * s2 + e]); sh_[e] = (short)f2bf(pacc[8 * s2 + e]); }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+          const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
+          const int r0 = 16 * s2 + 4 * lh + qq;
+          const bf16x8 oh = join4(lds_read_tr16(Os16 + r0 * RSQ + col), lds_read_tr16(Os16 + (r0 + 8) * RSQ + col));
+          dVT[n] = mfma32(oh, ph, dVT[n]);
+          const bf16x8 qh = join4(lds_read_tr16(Qs16 + r0 * RSQ + col), lds_read_tr16(Qs16 + (r0 + 8) * RSQ + col));
+          dKT[n] = mfma32(qh, sh_, dKT[n]);
+        }
       }
     }
     // ---- (g) dS -> LDS [query][key] ----
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      unsigned short h1, l1 = 0;
-      if (PL == 2) split_bf16(pacc[r], h1, l1); else h1 = f2bf(pacc[r]);
       const int off = acc_row32(r, lh) * RSS + wave * 32 + lr;
-      Ss[0][off] = h1;
-      if (PL == 2) Ss[PL - 1][off] = l1;
+      if (F32) Ss32[off] = pacc[r];
+      else Ss16[off] = f2bf(pacc[r]);
     }
     __syncthreads();   // (h)
 
-    // ---- (i) dQ block = dS . K with 16x16x32 tiles spread over the waves ----
+    // ---- (i) dQ block = dS . K with 16x16 tiles spread over the waves ----
     constexpr int CT = DH / 16;
     for (int t = wave; t < 2 * CT; t += KT) {
       const int qh2 = t / CT, ct = t % CT;
       f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+      if (F32) {
+#pragma unroll 8
+        for (int k4 = 0; k4 < LKP / 4; k4++)
+          a4 = mfma16_f32(Ss32[(qh2 * 16 + (lane & 15)) * RSS + k4 * 4 + gi], Ks32[(k4 * 4 + gi) * RSK + ct * 16 + (lane & 15)], a4);
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < KT; ks++) {
-        const int aoff = (qh2 * 16 + (lane & 15)) * RSS + ks * 32 + 8 * gi;
-        const bf16x8 ah = lds_read_b128(Ss[0] + aoff);
-        const bf16x8 al = (PL == 2) ? lds_read_b128(Ss[PL - 1] + aoff) : ah;
-        const int krow = ks * 32 + 8 * gi + qq;
-        const int kcol = ct * 16 + 4 * pp;
-        const bf16x8 bh = join4(lds_read_tr16(Ks[0] + krow * RSK + kcol), lds_read_tr16(Ks[0] + (krow + 4) * RSK + kcol));
-        const bf16x8 bl = (PL == 2) ? join4(lds_read_tr16(Ks[PL - 1] + krow * RSK + kcol), lds_read_tr16(Ks[PL - 1] + (krow + 4) * RSK + kcol)) : bh;
-        a4 = mfma16_split<NPASS>(ah, al, bh, bl, a4);
+        for (int ks = 0; ks < KT; ks++) {
+          const bf16x8 ah = lds_read_b128(Ss16 + (qh2 * 16 + (lane & 15)) * RSS + ks * 32 + 8 * gi);
+          const int krow = ks * 32 + 8 * gi + qq;
+          const int kcol = ct * 16 + 4 * pp;
+          const bf16x8 bh = join4(lds_read_tr16(Ks16 + krow * RSK + kcol), lds_read_tr16(Ks16 + (krow + 4) * RSK + kcol));
+          a4 = mfma16(ah, bh, a4);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {

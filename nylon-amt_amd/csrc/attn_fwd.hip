@@ -13,29 +13,33 @@
 
 namespace {
 
+// npass == 1: K/V as bf16 planes (layout notes below).  npass == 3 (parity): K/V stay fp32 in LDS and every product runs on
+// v_mfma_f32_32x32x2_f32 (one f32 per lane per operand): K rows of DH+1 floats (conflict-free column reads), V row-major.
 template <int KT, int DH, int NPASS>
 struct AfCfg {
+  static constexpr bool F32 = (NPASS == 3);
   static constexpr int LKP = KT * 32;
-  static constexpr int PL = (NPASS == 3) ? 2 : 1;
-  static constexpr int RSK = DH + 8;   // bf16 elements: 144 B / 80 B rows, conflict-free ds_read_b128
-  // tr16 reads are conflict-free when the row stride is 64 (mod 128) bytes; the 256-key, dh=64 parity build
-  // falls back to 144 B rows (2-way conflicts) to fit 160 KiB.
-  static constexpr int RSV = (DH == 64) ? ((NPASS == 3 && KT == 8) ? 72 : 96) : 32;
+  static constexpr int RSK = F32 ? DH + 1 : DH + 8;   // bf16: 144 B / 80 B rows, conflict-free ds_read_b128
+  // bf16 tr16 reads are conflict-free when the row stride is 64 (mod 128) bytes
+  static constexpr int RSV = F32 ? DH : ((DH == 64) ? 96 : 32);
   static constexpr int K_ELEMS = LKP * RSK;
   static constexpr int V_ELEMS = LKP * RSV;
-  static constexpr int LDS_BYTES = PL * (K_ELEMS + V_ELEMS) * 2;
+  static constexpr int LDS_BYTES = (K_ELEMS + V_ELEMS) * (F32 ? 4 : 2);
 };
 
 template <int KT, int DH, int NPASS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
   using Cfg = AfCfg<KT, DH, NPASS>;
-  constexpr int PL = Cfg::PL, RSK = Cfg::RSK, RSV = Cfg::RSV, LKP = Cfg::LKP;
-  constexpr int KS = DH / 16;   // k-steps of the QK^T product
+  constexpr bool F32 = Cfg::F32;
+  constexpr int RSK = Cfg::RSK, RSV = Cfg::RSV, LKP = Cfg::LKP;
+  constexpr int KS = DH / 16;   // bf16 k-steps of the QK^T product
   constexpr int NT = DH / 32;   // output column tiles
+  constexpr int HD = DH / 2;    // fp32 path: dh elements per lane half
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* sm = reinterpret_cast<unsigned short*>(smem);
-  unsigned short* Ks[2] = {sm, sm + (PL - 1) * Cfg::K_ELEMS};
-  unsigned short* Vs[2] = {sm + PL * Cfg::K_ELEMS, sm + PL * Cfg::K_ELEMS + (PL - 1) * Cfg::V_ELEMS};
+  unsigned short* Ks16 = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Vs16 = Ks16 + Cfg::K_ELEMS;
+  float* Ks32 = reinterpret_cast<float*>(smem);
+  float* Vs32 = Ks32 + Cfg::K_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
   const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
   const int Lq = g.Lq, Lk = g.Lk;
 
-  // ---- stage K and V of this (seq, head) into LDS as bf16 planes ----
+  // ---- stage K and V of this (seq, head) into LDS ----
   {
     const float* kb = g.k + (long)seq * g.k_seq_stride + head * DH;
     const float* vb = g.v + (long)seq * g.v_seq_stride + head * DH;
@@ -55,24 +59,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
         kf = *reinterpret_cast<const float4*>(kb + (long)key * g.ldk + c4 * 4);
         vf = *reinterpret_cast<const float4*>(vb + (long)key * g.ldv + c4 * 4);
       }
-      const float kv[4] = {kf.x, kf.y, kf.z, kf.w};
-      const float vv[4] = {vf.x, vf.y, vf.z, vf.w};
-      unsigned short khi[4], klo[4], vhi[4], vlo[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (PL == 2) { split_bf16(kv[e], khi[e], klo[e]); split_bf16(vv[e], vhi[e], vlo[e]); }
-        else { khi[e] = f2bf(kv[e]); vhi[e] = f2bf(vv[e]); }
-      }
-      uint2 w;
-      w.x = khi[0] | ((unsigned)khi[1] << 16); w.y = khi[2] | ((unsigned)khi[3] << 16);
-      *reinterpret_cast<uint2*>(Ks[0] + key * RSK + c4 * 4) = w;
-      w.x = vhi[0] | ((unsigned)vhi[1] << 16); w.y = vhi[2] | ((unsigned)vhi[3] << 16);
-      *reinterpret_cast<uint2*>(Vs[0] + key * RSV + c4 * 4) = w;
-      if (PL == 2) {
-        w.x = klo[0] | ((unsigned)klo[1] << 16); w.y = klo[2] | ((unsigned)klo[3] << 16);
-        *reinterpret_cast<uint2*>(Ks[PL - 1] + key * RSK + c4 * 4) = w;
-        w.x = vlo[0] | ((unsigned)vlo[1] << 16); w.y = vlo[2] | ((unsigned)vlo[3] << 16);
-        *reinterpret_cast<uint2*>(Vs[PL - 1] + key * RSV + c4 * 4) = w;
+      if (F32) {
+        float* kd = Ks32 + key * RSK + c4 * 4;
+        kd[0] = kf.x; kd[1] = kf.y; kd[2] = kf.z; kd[3] = kf.w;
+        *reinterpret_cast<float4*>(Vs32 + key * RSV + c4 * 4) = vf;
+      } else {
+        uint2 w;
+        w.x = f2bf(kf.x) | ((unsigned)f2bf(kf.y) << 16); w.y = f2bf(kf.z) | ((unsigned)f2bf(kf.w) << 16);
+        *reinterpret_cast<uint2*>(Ks16 + key * RSK + c4 * 4) = w;
+        w.x = f2bf(vf.x) | ((unsigned)f2bf(vf.y) << 16); w.y = f2bf(vf.z) | ((unsigned)f2bf(vf.w) << 16);
+        *reinterpret_cast<uint2*>(Vs16 + key * RSV + c4 * 4) = w;
       }
     }
   }
@@ -88,33 +84,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
     const int qrow = qb * 32 + lr;                     // this lane's query (as the B-operand column)
     const int qrow_c = qrow < Lq ? qrow : Lq - 1;
     const float* qp = g.q + (long)seq * g.q_seq_stride + (long)qrow_c * g.ldq + head * DH;
-    bf16x8 qh[KS], ql[KS];
-#pragma unroll
-    for (int s = 0; s < KS; s++) {
-      const float4 f0 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * lh);
-      const float4 f1 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * lh + 4);
-      const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        unsigned short hi, lo = 0;
-        const float x = v[e] * scale;
-        if (PL == 2) split_bf16(x, hi, lo); else hi = f2bf(x);
-        qh[s][e] = (short)hi; ql[s][e] = (short)lo;
-      }
-    }
     // ---- S^T = K . Q^T  (rows = keys in registers, column = this lane's query) ----
     f32x16 sacc[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; kt++) {
+    for (int kt = 0; kt < KT; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) sacc[kt][r] = 0.f;
+    if (F32) {
+      float qf[HD];                                    // Q[q][HD*lh + t] * scale
+#pragma unroll
+      for (int t4 = 0; t4 < HD / 4; t4++) {
+        const float4 f = *reinterpret_cast<const float4*>(qp + HD * lh + 4 * t4);
+        qf[4 * t4] = f.x * scale; qf[4 * t4 + 1] = f.y * scale; qf[4 * t4 + 2] = f.z * scale; qf[4 * t4 + 3] = f.w * scale;
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int t = 0; t < HD; t++)
+          sacc[kt] = mfma32_f32(Ks32[(kt * 32 + lr) * RSK + HD * lh + t], qf[t], sacc[kt]);
+    } else {
+      bf16x8 qh[KS];
 #pragma unroll
       for (int s = 0; s < KS; s++) {
-        const int off = (kt * 32 + lr) * RSK + 16 * s + 8 * lh;
-        const bf16x8 kh = lds_read_b128(Ks[0] + off);
-        const bf16x8 kl = (PL == 2) ? lds_read_b128(Ks[PL - 1] + off) : kh;
-        sacc[kt] = mfma32_split<NPASS>(kh, kl, qh[s], ql[s], sacc[kt]);
+        const float4 f0 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * lh);
+        const float4 f1 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * lh + 4);
+        const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) qh[s][e] = (short)f2bf(v[e] * scale);
       }
+#pragma unroll
+      for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+          sacc[kt] = mfma32(lds_read_b128(Ks16 + (kt * 32 + lr) * RSK + 16 * s + 8 * lh), qh[s], sacc[kt]);
     }
     // ---- softmax over keys (register-local + one cross-half exchange) ----
     float mx = -INFINITY;
@@ -132,13 +134,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const float p = (NPASS == 3) ? expf(sacc[kt][r] - mx) : __expf(sacc[kt][r] - mx);
+        const float p = F32 ? expf(sacc[kt][r] - mx) : __expf(sacc[kt][r] - mx);
         sacc[kt][r] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (lh == 0 && qrow < Lq) g.lse[((long)seq * g.n_heads + head) * Lq + qrow] = mx + logf(sum);
+    if (lh == 0 && qrow < Lq) {      // row statistics for the backward recompute: P = exp(s - max) * inv  (bitwise the forward P)
+      float* st = g.lse + (((long)seq * g.n_heads + head) * Lq + qrow) * 2;
+      st[0] = mx; st[1] = inv;
+    }
 
     const long prow = (((long)seq * g.n_heads + head) * Lq + qrow) * (long)Lk;   // element index base of this query's row
 #pragma unroll
@@ -173,25 +178,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
     for (int n = 0; n < NT; n++)
 #pragma unroll
       for (int r = 0; r < 16; r++) oacc[n][r] = 0.f;
+    if (F32) {
+      // step r: k=0 <-> key row(r,0), k=1 <-> key row(r,1); each lane feeds its own P^T register as A[i=q][k=lh]
 #pragma unroll
-    for (int kt = 0; kt < KT; kt++) {
+      for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        bf16x8 xh, xl;
+        for (int r = 0; r < 16; r++) {
+          const int key = kt * 32 + acc_row32(r, lh);
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          unsigned short hi, lo = 0;
-          const float x = sacc[kt][8 * s2 + e];
-          if (PL == 2) split_bf16(x, hi, lo); else hi = f2bf(x);
-          xh[e] = (short)hi; xl[e] = (short)lo;
+          for (int n = 0; n < NT; n++) oacc[n] = mfma32_f32(sacc[kt][r], Vs32[key * RSV + n * 32 + lr], oacc[n]);
         }
+    } else {
 #pragma unroll
-        for (int n = 0; n < NT; n++) {
-          const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
-          const int r0 = kt * 32 + 16 * s2 + 4 * lh + qq;     // + 8 for the second half of the fragment
-          const bf16x8 vh = join4(lds_read_tr16(Vs[0] + r0 * RSV + col), lds_read_tr16(Vs[0] + (r0 + 8) * RSV + col));
-          const bf16x8 vl = (PL == 2) ? join4(lds_read_tr16(Vs[PL - 1] + r0 * RSV + col), lds_read_tr16(Vs[PL - 1] + (r0 + 8) * RSV + col)) : vh;
-          oacc[n] = mfma32_split<NPASS>(xh, xl, vh, vl, oacc[n]);
+      for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          bf16x8 xh;
+#pragma unroll
+          for (int e = 0; e < 8; e++) xh[e] = (short)f2bf(sacc[kt][8 * s2 + e]);
+#pragma unroll
+          for (int n = 0; n < NT; n++) {
+            const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
+            const int r0 = kt * 32 + 16 * s2 + 4 * lh + qq;     // + 8 for the second half of the fragment
+            const bf16x8 vh = join4(lds_read_tr16(Vs16 + r0 * RSV + col), lds_read_tr16(Vs16 + (r0 + 8) * RSV + col));
+            oacc[n] = mfma32(xh, vh, oacc[n]);
+          }
         }
       }
     }

@@ -10,7 +10,7 @@
 namespace {
 
 // ------------------------------------------------------------------ weight preparation
-__global__ void prep_weights_kernel(const float* __restrict__ params, uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo,
+__global__ void prep_weights_kernel(const float* __restrict__ params, uint16_t* __restrict__ wbf, float* __restrict__ wf32,
                                     float* __restrict__ fdst, const hftt_prep_entry* __restrict__ table) {
   const hftt_prep_entry e = table[blockIdx.x];
   const long total = (long)e.rows * e.cols;
@@ -21,10 +21,8 @@ __global__ void prep_weights_kernel(const float* __restrict__ params, uint16_t* 
       fdst[e.dst_off + (long)r * e.dst_ld + c] = x;
     } else {
       const long d = (e.kind == 1) ? (e.dst_off + (long)c * e.dst_ld + r) : (e.dst_off + (long)r * e.dst_ld + c);
-      unsigned short hi, lo;
-      split_bf16(x, hi, lo);
-      whi[d] = hi;
-      if (wlo != nullptr) wlo[d] = lo;
+      if (wbf != nullptr) wbf[d] = f2bf(x);
+      if (wf32 != nullptr) wf32[d] = x;
     }
   }
 }
@@ -44,10 +42,8 @@ __global__ void fold_fwd_kernel(const hftt_fold_desc f) {
           if (w >= 0 && w < nw) acc += f.wtok[(long)j * cd + c * nw + w] * f.wconv[c * f.kw + kk];
         }
     }
-    unsigned short hi, lo;
-    split_bf16(acc, hi, lo);
-    f.weff_hi[i] = hi;
-    if (f.weff_lo != nullptr) f.weff_lo[i] = lo;
+    if (f.weff_bf != nullptr) f.weff_bf[i] = f2bf(acc);
+    if (f.weff_f32 != nullptr) f.weff_f32[i] = acc;
     if (u == 0 && j < f.d) {
       float b = f.btok[j];
       for (int c = 0; c < f.C; c++) {
@@ -459,16 +455,16 @@ inline int grid_for(long work_items, int block, int cap = 4096) {
 
 }  // namespace
 
-extern "C" int hftt_prep_weights(const float* params, uint16_t* whi, uint16_t* wlo, float* fdst,
+extern "C" int hftt_prep_weights(const float* params, uint16_t* wbf, float* wf32, float* fdst,
                                  const hftt_prep_entry* table_dev, int n_entries, void* stream) {
-  HFTT_REQUIRE(params && whi && table_dev && n_entries > 0, "prep_weights: null operand");
-  hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)n_entries, 8), dim3(256), 0, (hipStream_t)stream, params, whi, wlo, fdst, table_dev);
+  HFTT_REQUIRE(params && (wbf || wf32 || fdst) && table_dev && n_entries > 0, "prep_weights: null operand");
+  hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)n_entries, 8), dim3(256), 0, (hipStream_t)stream, params, wbf, wf32, fdst, table_dev);
   HFTT_CHECK_LAUNCH("prep_weights");
   return 0;
 }
 
 extern "C" int hftt_embed_fold_fwd(const hftt_fold_desc* d, void* stream) {
-  HFTT_REQUIRE(d && d->wconv && d->bconv && d->wtok && d->btok && d->weff_hi && d->beff, "embed_fold_fwd: null operand");
+  HFTT_REQUIRE(d && d->wconv && d->bconv && d->wtok && d->btok && (d->weff_bf || d->weff_f32) && d->beff, "embed_fold_fwd: null operand");
   HFTT_REQUIRE(d->Kp % 32 == 0 && d->Kp >= d->n_proc && d->d_pad >= d->d && d->n_proc >= d->kw, "embed_fold_fwd: bad shape");
   hipLaunchKernelGGL(fold_fwd_kernel, dim3(grid_for((long)d->d_pad * d->Kp, 256)), dim3(256), 0, (hipStream_t)stream, *d);
   HFTT_CHECK_LAUNCH("embed_fold_fwd");

@@ -1,8 +1,11 @@
-// NT GEMM with fused epilogue on MFMA 32x32x16 bf16 (gfx950).
+// NT GEMM with fused epilogue on MFMA (gfx950).
 //   C[M,N] = epi(A[M,K] . W[N,K]^T + bias)        -- see include/hftt_hip.h (hftt_gemm_nt)
 // Tile: BM=128 x BN in {64,128,256} x BK=32, 512 threads (8 waves, 2 per SIMD), double-buffered LDS,
-// register-staged global->LDS (fp32 activations are split into bf16 hi/lo planes on the way in).
-// LDS rows are padded to 80 B so every ds_read_b128 of an MFMA fragment is bank-conflict free.
+// register-staged global->LDS.
+//   npass == 1 ("bf16"):  fp32 activations are rounded to bf16 on the way into LDS, weights come as a prepared bf16
+//                         plane; v_mfma_f32_32x32x16_bf16; LDS rows padded to 80 B (conflict-free ds_read_b128).
+//   npass == 3 ("parity"): operands stay fp32 in LDS (rows of 33 floats: conflict-free ds_read_b32), weights come as a
+//                         prepared fp32 matrix; v_mfma_f32_32x32x2_f32 = exact fp32 FMA chains (<= 1e-3 parity mode).
 #include "hftt_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
@@ -11,30 +14,31 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int RS = BK + 8;   // LDS row stride in bf16 elements (80 bytes)
 
-template <int BN, int NPASS>
+template <int BN, bool F32>
 struct NtCfg {
   static constexpr int WM = (BN == 64) ? 4 : 2;
   static constexpr int WN = 8 / WM;
   static constexpr int TM = BM / WM / 32;
   static constexpr int TN = BN / WN / 32;
-  static constexpr int PL = (NPASS == 3) ? 2 : 1;
+  static constexpr int RS = F32 ? 33 : 40;                 // row stride in elements (floats / bf16)
+  static constexpr int ESZ = F32 ? 4 : 2;
   static constexpr int A_ELEMS = BM * RS;
   static constexpr int W_ELEMS = BN * RS;
-  static constexpr int BUF_ELEMS = PL * (A_ELEMS + W_ELEMS);
-  static constexpr int LOOP_BYTES = 2 * BUF_ELEMS * 2;
+  static constexpr int BUF_ELEMS = A_ELEMS + W_ELEMS;
+  static constexpr int LOOP_BYTES = 2 * BUF_ELEMS * ESZ;
   static constexpr int STAGE_LD = BN + 4;
   static constexpr int STAGE_BYTES = BM * STAGE_LD * 4;
-  static constexpr int WCH = (BN * 4 + 511) / 512;   // 16-byte weight chunks per thread per plane
+  static constexpr int WCH = F32 ? (BN * 8 + 511) / 512 : (BN * 4 + 511) / 512;   // 16-byte weight chunks per thread
 };
 
-template <int BN, int NPASS, bool LN>
+template <int BN, bool F32, bool LN>
 __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g) {
-  using Cfg = NtCfg<BN, NPASS>;
-  constexpr int WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN, PL = Cfg::PL;
+  using Cfg = NtCfg<BN, F32>;
+  constexpr int WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN, RS = Cfg::RS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* sm = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
+  float* sm32 = reinterpret_cast<float*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -42,9 +46,6 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int nk = g.K / BK;
-
-  auto As = [&](int buf, int pl) { return sm + buf * Cfg::BUF_ELEMS + pl * Cfg::A_ELEMS; };
-  auto Ws = [&](int buf, int pl) { return sm + buf * Cfg::BUF_ELEMS + PL * Cfg::A_ELEMS + pl * Cfg::W_ELEMS; };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -55,7 +56,11 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   float4 areg[2];
-  uint4 wreg[PL][Cfg::WCH];
+  uint4 wreg[Cfg::WCH];
+#pragma unroll
+  for (int j = 0; j < Cfg::WCH; j++) wreg[j] = make_uint4(0u, 0u, 0u, 0u);
+  const float* Wf = reinterpret_cast<const float*>(g.W);
+  const unsigned short* Wb = reinterpret_cast<const unsigned short*>(g.W);
 
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
@@ -70,42 +75,59 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 #pragma unroll
     for (int j = 0; j < Cfg::WCH; j++) {
       const int i = tid + 512 * j;
-      if (i < BN * 4) {
-        const int row = i >> 2, ch = i & 3;
-        const long off = (long)(n0 + row) * g.K + k0 + ch * 8;
-        wreg[0][j] = *reinterpret_cast<const uint4*>(g.Whi + off);
-        if (PL == 2) wreg[PL - 1][j] = *reinterpret_cast<const uint4*>(g.Wlo + off);
+      if (F32) {
+        if (i < BN * 8) {
+          const int row = i >> 3, ch = i & 7;
+          wreg[j] = *reinterpret_cast<const uint4*>(Wf + (long)(n0 + row) * g.K + k0 + ch * 4);
+        }
+      } else {
+        if (i < BN * 4) {
+          const int row = i >> 2, ch = i & 3;
+          wreg[j] = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + row) * g.K + k0 + ch * 8);
+        }
       }
     }
   };
   auto sstore = [&](int buf) {
+    if (F32) {
+      float* As = sm32 + buf * Cfg::BUF_ELEMS;
+      float* Ws = As + Cfg::A_ELEMS;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int i = tid + 512 * j;
-      const int row = i >> 3, c4 = i & 7;
-      const float v[4] = {areg[j].x, areg[j].y, areg[j].z, areg[j].w};
-      unsigned short hi[4], lo[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (PL == 2) split_bf16(v[e], hi[e], lo[e]);
-        else hi[e] = f2bf(v[e]);
+      for (int j = 0; j < 2; j++) {
+        const int i = tid + 512 * j;
+        const int row = i >> 3, c4 = i & 7;
+        float* d = As + row * RS + c4 * 4;
+        d[0] = areg[j].x; d[1] = areg[j].y; d[2] = areg[j].z; d[3] = areg[j].w;
       }
-      uint2 ph;
-      ph.x = hi[0] | ((unsigned)hi[1] << 16); ph.y = hi[2] | ((unsigned)hi[3] << 16);
-      *reinterpret_cast<uint2*>(As(buf, 0) + row * RS + c4 * 4) = ph;
-      if (PL == 2) {
-        uint2 pl;
-        pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16);
-        *reinterpret_cast<uint2*>(As(buf, PL - 1) + row * RS + c4 * 4) = pl;
-      }
-    }
 #pragma unroll
-    for (int j = 0; j < Cfg::WCH; j++) {
-      const int i = tid + 512 * j;
-      if (i < BN * 4) {
-        const int row = i >> 2, ch = i & 3;
-        *reinterpret_cast<uint4*>(Ws(buf, 0) + row * RS + ch * 8) = wreg[0][j];
-        if (PL == 2) *reinterpret_cast<uint4*>(Ws(buf, PL - 1) + row * RS + ch * 8) = wreg[PL - 1][j];
+      for (int j = 0; j < Cfg::WCH; j++) {
+        const int i = tid + 512 * j;
+        if (i < BN * 8) {
+          const int row = i >> 3, ch = i & 7;
+          float* d = Ws + row * RS + ch * 4;
+          d[0] = __uint_as_float(wreg[j].x); d[1] = __uint_as_float(wreg[j].y);
+          d[2] = __uint_as_float(wreg[j].z); d[3] = __uint_as_float(wreg[j].w);
+        }
+      }
+    } else {
+      unsigned short* As = sm16 + buf * Cfg::BUF_ELEMS;
+      unsigned short* Ws = As + Cfg::A_ELEMS;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int i = tid + 512 * j;
+        const int row = i >> 3, c4 = i & 7;
+        uint2 ph;
+        ph.x = f2bf(areg[j].x) | ((unsigned)f2bf(areg[j].y) << 16);
+        ph.y = f2bf(areg[j].z) | ((unsigned)f2bf(areg[j].w) << 16);
+        *reinterpret_cast<uint2*>(As + row * RS + c4 * 4) = ph;
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::WCH; j++) {
+        const int i = tid + 512 * j;
+        if (i < BN * 4) {
+          const int row = i >> 2, ch = i & 3;
+          *reinterpret_cast<uint4*>(Ws + row * RS + ch * 8) = wreg[j];
+        }
       }
     }
   };
@@ -117,25 +139,36 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
   for (int kt = 0; kt < nk; kt++) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
+    if (F32) {
+      const float* As = sm32 + buf * Cfg::BUF_ELEMS;
+      const float* Ws = As + Cfg::A_ELEMS;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      for (int t = 0; t < 16; t++) {
+        float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) {
-        const int off = (wm * TM * 32 + i * 32 + lr) * RS + s * 16 + lh * 8;
-        ah[i] = lds_read_b128(As(buf, 0) + off);
-        al[i] = (PL == 2) ? lds_read_b128(As(buf, PL - 1) + off) : ah[i];
+        for (int i = 0; i < TM; i++) a[i] = As[(wm * TM * 32 + i * 32 + lr) * RS + 16 * lh + t];
+#pragma unroll
+        for (int j = 0; j < TN; j++) b[j] = Ws[(wn * TN * 32 + j * 32 + lr) * RS + 16 * lh + t];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = mfma32_f32(a[i], b[j], acc[i][j]);
       }
+    } else {
+      const unsigned short* As = sm16 + buf * Cfg::BUF_ELEMS;
+      const unsigned short* Ws = As + Cfg::A_ELEMS;
 #pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int off = (wn * TN * 32 + j * 32 + lr) * RS + s * 16 + lh * 8;
-        bh[j] = lds_read_b128(Ws(buf, 0) + off);
-        bl[j] = (PL == 2) ? lds_read_b128(Ws(buf, PL - 1) + off) : bh[j];
+      for (int s = 0; s < 2; s++) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) a[i] = lds_read_b128(As + (wm * TM * 32 + i * 32 + lr) * RS + s * 16 + lh * 8);
+#pragma unroll
+        for (int j = 0; j < TN; j++) b[j] = lds_read_b128(Ws + (wn * TN * 32 + j * 32 + lr) * RS + s * 16 + lh * 8);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
       }
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = mfma32_split<NPASS>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
     }
     if (kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
@@ -210,38 +243,38 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
   }
 }
 
-template <int BN, int NPASS, bool LN>
+template <int BN, bool F32, bool LN>
 int launch_nt(const hftt_gemm_nt_desc& d, hipStream_t st) {
-  using Cfg = NtCfg<BN, NPASS>;
+  using Cfg = NtCfg<BN, F32>;
   int lds = Cfg::LOOP_BYTES;
   if (LN && Cfg::STAGE_BYTES > lds) lds = Cfg::STAGE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BN, NPASS, LN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BN, F32, LN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { hftt_set_error("gemm_nt: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
   const int n_pad = ((d.N + 63) / 64) * 64;
   dim3 grid((unsigned)((d.M + BM - 1) / BM), (unsigned)((n_pad + BN - 1) / BN), 1);
-  hipLaunchKernelGGL((gemm_nt_kernel<BN, NPASS, LN>), grid, dim3(512), lds, st, d);
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, F32, LN>), grid, dim3(512), lds, st, d);
   HFTT_CHECK_LAUNCH("gemm_nt");
   return 0;
 }
 
-template <int NPASS>
+template <bool F32>
 int dispatch_nt(const hftt_gemm_nt_desc& d, hipStream_t st) {
   const int n_pad = ((d.N + 63) / 64) * 64;
   if (d.ln_gamma != nullptr) {
-    if (d.N == 256) return launch_nt<256, NPASS, true>(d, st);
-    if (d.N == 128) return launch_nt<128, NPASS, true>(d, st);
-    if (d.N == 64) return launch_nt<64, NPASS, true>(d, st);
+    if (d.N == 256) return launch_nt<256, F32, true>(d, st);
+    if (d.N == 128) return launch_nt<128, F32, true>(d, st);
+    if (d.N == 64) return launch_nt<64, F32, true>(d, st);
     hftt_set_error("gemm_nt: fused LayerNorm needs N in {64,128,256}, got %d", d.N);
     return 1;
   }
-  if (n_pad % 256 == 0) return launch_nt<256, NPASS, false>(d, st);
-  if (n_pad % 128 == 0) return launch_nt<128, NPASS, false>(d, st);
-  return launch_nt<64, NPASS, false>(d, st);
+  if (n_pad % 256 == 0) return launch_nt<256, F32, false>(d, st);
+  if (n_pad % 128 == 0) return launch_nt<128, F32, false>(d, st);
+  return launch_nt<64, F32, false>(d, st);
 }
 
 }  // namespace
@@ -251,15 +284,14 @@ extern "C" int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream) {
   HFTT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
   HFTT_REQUIRE(d->K % 32 == 0, "gemm_nt: K=%d must be a multiple of 32", d->K);
   HFTT_REQUIRE(d->lda % 4 == 0, "gemm_nt: lda=%ld must be a multiple of 4", (long)d->lda);
-  HFTT_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->Whi & 15) == 0, "gemm_nt: A/W must be 16-byte aligned");
-  HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "gemm_nt: npass must be 1 or 3");
-  HFTT_REQUIRE(d->npass == 1 || d->Wlo != nullptr, "gemm_nt: npass=3 needs Wlo");
-  HFTT_REQUIRE(d->A != nullptr && d->Whi != nullptr && d->C != nullptr, "gemm_nt: null operand");
+  HFTT_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->W & 15) == 0, "gemm_nt: A/W must be 16-byte aligned");
+  HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "gemm_nt: npass must be 1 (bf16) or 3 (fp32 parity)");
+  HFTT_REQUIRE(d->A != nullptr && d->W != nullptr && d->C != nullptr, "gemm_nt: null operand");
   HFTT_REQUIRE(d->add_table == nullptr || d->add_mod > 0, "gemm_nt: add_mod must be > 0");
   HFTT_REQUIRE(d->residual == nullptr || d->res_mod > 0, "gemm_nt: res_mod must be > 0");
   HFTT_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm_nt: drop_p out of range");
   HFTT_REQUIRE(d->ln_gamma == nullptr || (d->ln_beta != nullptr && d->ldc == d->N), "gemm_nt: LN needs beta and ldc == N");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->npass == 3) return dispatch_nt<3>(*d, st);
-  return dispatch_nt<1>(*d, st);
+  if (d->npass == 3) return dispatch_nt<true>(*d, st);
+  return dispatch_nt<false>(*d, st);
 }

@@ -3,6 +3,8 @@
 // The reduction runs over the (huge) token dimension M, so both operands are needed "token-major" in the
 // MFMA fragments.  Tiles of dY and X are staged ROW-major in LDS (coalesced 16-byte global loads) and the
 // fragments are fetched with ds_read_b64_tr_b16 (hardware transpose; lane map verified by tools/probe_mfma T5).
+// npass == 3 (parity): tiles stay fp32 in LDS and the product runs on v_mfma_f32_32x32x2_f32 (one f32 per lane per
+// operand, so the row-major tile IS the fragment layout: plain conflict-free ds_read_b32, no transpose needed).
 // M is split over workgroups; partial tiles go to a slab workspace and a second kernel reduces them in a fixed
 // order (bitwise reproducible; no float atomics).
 #include "hftt_common.h"
@@ -47,15 +49,17 @@ TnPlan tn_plan(int M, int N, int K) {
 
 template <int TM, int TN, int NPASS>
 struct TnCfg {
+  static constexpr bool F32 = (NPASS == 3);
   static constexpr int TILE_N = 128 * TM;
   static constexpr int TILE_K = 64 * TN;
-  static constexpr int RSY = TILE_N + 32;   // shorts; bytes = 2*TILE_N + 64 == 64 (mod 128): conflict-free tr reads
-  static constexpr int RSX = TILE_K + 32;
-  static constexpr int PL = (NPASS == 3) ? 2 : 1;
+  // bf16: row stride in shorts, bytes = 2*TILE + 64 == 64 (mod 128): conflict-free tr reads.  fp32: floats, 16-byte aligned rows.
+  static constexpr int RSY = F32 ? TILE_N + 4 : TILE_N + 32;
+  static constexpr int RSX = F32 ? TILE_K + 4 : TILE_K + 32;
+  static constexpr int ESZ = F32 ? 4 : 2;
   static constexpr int Y_ELEMS = BMT * RSY;
   static constexpr int X_ELEMS = BMT * RSX;
-  static constexpr int BUF_ELEMS = PL * (Y_ELEMS + X_ELEMS);
-  static constexpr int LDS_BYTES = 2 * BUF_ELEMS * 2;
+  static constexpr int BUF_ELEMS = Y_ELEMS + X_ELEMS;
+  static constexpr int LDS_BYTES = 2 * BUF_ELEMS * ESZ;
   static constexpr int YL = TILE_N / 64;    // float4 loads per thread (dY)
   static constexpr int XL = (TILE_K + 63) / 64;   // float4 loads per thread (X)
 };
@@ -64,11 +68,11 @@ template <int TM, int TN, int NPASS>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g, const int k_tiles, const int rows_per_split,
                                                      const long nws, const long kws) {
   using Cfg = TnCfg<TM, TN, NPASS>;
-  constexpr int PL = Cfg::PL, RSY = Cfg::RSY, RSX = Cfg::RSX, TILE_N = Cfg::TILE_N, TILE_K = Cfg::TILE_K;
+  constexpr bool F32 = Cfg::F32;
+  constexpr int RSY = Cfg::RSY, RSX = Cfg::RSX, TILE_N = Cfg::TILE_N, TILE_K = Cfg::TILE_K;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* sm = reinterpret_cast<unsigned short*>(smem);
-  auto Ys = [&](int buf, int pl) { return sm + buf * Cfg::BUF_ELEMS + pl * Cfg::Y_ELEMS; };
-  auto Xs = [&](int buf, int pl) { return sm + buf * Cfg::BUF_ELEMS + PL * Cfg::Y_ELEMS + pl * Cfg::X_ELEMS; };
+  unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
+  float* sm32 = reinterpret_cast<float*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn4 = wave >> 1, wk2 = wave & 1;
@@ -118,21 +122,15 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       else xreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto put4 = [&](unsigned short* hi_p, unsigned short* lo_p, const float4& f) {
-    const float v[4] = {f.x, f.y, f.z, f.w};
-    unsigned short hi[4], lo[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      if (PL == 2) split_bf16(v[e], hi[e], lo[e]);
-      else hi[e] = f2bf(v[e]);
-    }
-    uint2 ph;
-    ph.x = hi[0] | ((unsigned)hi[1] << 16); ph.y = hi[2] | ((unsigned)hi[3] << 16);
-    *reinterpret_cast<uint2*>(hi_p) = ph;
-    if (PL == 2) {
-      uint2 pl;
-      pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16);
-      *reinterpret_cast<uint2*>(lo_p) = pl;
+  auto put4 = [&](int buf, int which, int off, const float4& f) {      // which: 0 = dY tile, 1 = X tile
+    if (F32) {
+      float* base = sm32 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
+      *reinterpret_cast<float4*>(base + off) = f;
+    } else {
+      unsigned short* base = sm16 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
+      uint2 ph;
+      ph.x = f2bf(f.x) | ((unsigned)f2bf(f.y) << 16); ph.y = f2bf(f.z) | ((unsigned)f2bf(f.w) << 16);
+      *reinterpret_cast<uint2*>(base + off) = ph;
     }
   };
   auto sstore = [&](int buf) {
@@ -141,17 +139,17 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       const int i = tid + 512 * j;
       const int row = i / YF4R;
       csum[0] += yreg[j].x; csum[1] += yreg[j].y; csum[2] += yreg[j].z; csum[3] += yreg[j].w;
-      put4(Ys(buf, 0) + row * RSY + yc4 * 4, Ys(buf, PL - 1) + row * RSY + yc4 * 4, yreg[j]);
+      put4(buf, 0, row * RSY + yc4 * 4, yreg[j]);
     }
 #pragma unroll
     for (int j = 0; j < Cfg::XL; j++) {
       const int i = tid + 512 * j;
       const int row = i / XF4R, c4 = i % XF4R;
-      if (row < BMT) put4(Xs(buf, 0) + row * RSX + c4 * 4, Xs(buf, PL - 1) + row * RSX + c4 * 4, xreg[j]);
+      if (row < BMT) put4(buf, 1, row * RSX + c4 * 4, xreg[j]);
     }
   };
 
-  // transposed-fragment addressing (probe T5): 16-lane group gi, block row qq, column quad p
+  // transposed-fragment addressing for the bf16 path (probe T5): 16-lane group gi, block row qq, column quad p
   const int gi = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   const int frag_col = 16 * (gi & 1) + 4 * pp;   // column inside a 32-wide tile
   const int frag_row = 8 * (gi >> 1) + qq;       // + 16*s + 4*half
@@ -164,27 +162,45 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   for (int step = 0; step < nsteps; step++) {
     const int buf = step & 1;
     if (step + 1 < nsteps) gload(step + 1);
+    if (F32) {
+      const float* Ys = sm32 + buf * Cfg::BUF_ELEMS;
+      const float* Xs = Ys + Cfg::Y_ELEMS;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      for (int t = 0; t < 16; t++) {
+        const int m = 16 * lh + t;          // token row handled by this lane half in MFMA step t
+        float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) {
-        const int c = wn4 * TM * 32 + i * 32 + frag_col;
-        const int r0 = 16 * s + frag_row;
-        ah[i] = join4(lds_read_tr16(Ys(buf, 0) + r0 * RSY + c), lds_read_tr16(Ys(buf, 0) + (r0 + 4) * RSY + c));
-        al[i] = (PL == 2) ? join4(lds_read_tr16(Ys(buf, PL - 1) + r0 * RSY + c), lds_read_tr16(Ys(buf, PL - 1) + (r0 + 4) * RSY + c)) : ah[i];
+        for (int i = 0; i < TM; i++) a[i] = Ys[m * RSY + wn4 * TM * 32 + i * 32 + lr];
+#pragma unroll
+        for (int j = 0; j < TN; j++) b[j] = Xs[m * RSX + wk2 * TN * 32 + j * 32 + lr];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = mfma32_f32(a[i], b[j], acc[i][j]);
       }
+    } else {
+      const unsigned short* Ys = sm16 + buf * Cfg::BUF_ELEMS;
+      const unsigned short* Xs = Ys + Cfg::Y_ELEMS;
 #pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int c = wk2 * TN * 32 + j * 32 + frag_col;
-        const int r0 = 16 * s + frag_row;
-        bh[j] = join4(lds_read_tr16(Xs(buf, 0) + r0 * RSX + c), lds_read_tr16(Xs(buf, 0) + (r0 + 4) * RSX + c));
-        bl[j] = (PL == 2) ? join4(lds_read_tr16(Xs(buf, PL - 1) + r0 * RSX + c), lds_read_tr16(Xs(buf, PL - 1) + (r0 + 4) * RSX + c)) : bh[j];
+      for (int s = 0; s < 2; s++) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          const int c = wn4 * TM * 32 + i * 32 + frag_col;
+          const int r0 = 16 * s + frag_row;
+          a[i] = join4(lds_read_tr16(Ys + r0 * RSY + c), lds_read_tr16(Ys + (r0 + 4) * RSY + c));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const int c = wk2 * TN * 32 + j * 32 + frag_col;
+          const int r0 = 16 * s + frag_row;
+          b[j] = join4(lds_read_tr16(Xs + r0 * RSX + c), lds_read_tr16(Xs + (r0 + 4) * RSX + c));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
       }
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = mfma32_split<NPASS>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
     }
     if (step + 1 < nsteps) sstore(buf ^ 1);
     __syncthreads();

@@ -49,6 +49,16 @@ __device__ __forceinline__ f32x4 mfma16_split(bf16x8 ah, bf16x8 al, bf16x8 bh, b
   return mfma16(ah, bh, c);
 }
 
+// exact-fp32 MFMA (parity mode): D = A*B + C with ONE f32 per lane per operand,
+//   32x32x2: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31];  16x16x4: A[i = lane&15][k = lane>>4], B[k][j = lane&15]
+// (bit-for-bit a k-ordered fmaf chain; runs at the fp32 vector rate = 1/16 of the bf16 MFMA rate)
+__device__ __forceinline__ f32x16 mfma32_f32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16_f32(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 // row index inside a 32x32 accumulator tile for register g of lane-half h (col = lane&31)
 __device__ __forceinline__ int acc_row32(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 

@@ -24,7 +24,7 @@ class PrepEntry(C.Structure):
 class GemmNtDesc(C.Structure):
     _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('npass', C.c_int32),
                 ('A', c_f32p), ('lda', C.c_int64),
-                ('Whi', c_u16p), ('Wlo', c_u16p),
+                ('W', C.c_void_p), ('reserved0', C.c_void_p),
                 ('bias', c_f32p),
                 ('C', c_f32p), ('ldc', C.c_int64),
                 ('act', C.c_int32), ('out_scale', C.c_float),
@@ -64,7 +64,7 @@ class AttnDesc(C.Structure):
 class FoldDesc(C.Structure):
     _fields_ = [('d', C.c_int32), ('C', C.c_int32), ('kw', C.c_int32), ('n_proc', C.c_int32), ('Kp', C.c_int32), ('d_pad', C.c_int32),
                 ('wconv', c_f32p), ('bconv', c_f32p), ('wtok', c_f32p), ('btok', c_f32p),
-                ('weff_hi', c_u16p), ('weff_lo', c_u16p), ('beff', c_f32p),
+                ('weff_bf', c_u16p), ('weff_f32', c_f32p), ('beff', c_f32p),
                 ('dweff', c_f32p), ('dbeff', c_f32p),
                 ('g_wconv', c_f32p), ('g_bconv', c_f32p), ('g_wtok', c_f32p), ('g_btok', c_f32p)]
 

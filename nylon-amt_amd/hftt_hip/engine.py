@@ -89,6 +89,8 @@ class HfttEngine:
         self.precision = precision
         self.npass = PRECISION_NPASS[precision]
         self._ws = {}
+        if getattr(self, '_bound', None) is not None:
+            self._build_prep()
 
     def bind(self, named_params):
         """Flatten the module's parameters into one buffer (reference state_dict order) and rebind .data as views."""
@@ -221,8 +223,10 @@ class HfttEngine:
         heads('time', 'heads_t')
 
         self.Woff = W
-        self.whi = torch.zeros(_align(wl.off, 64), dtype=torch.int16, device=self.device)
-        self.wlo = torch.zeros_like(self.whi)
+        # prepared matrices: bf16 plane (npass 1) or fp32 copy (npass 3, parity) -- same element offsets
+        n_w = _align(wl.off, 64)
+        self.wbf = torch.zeros(n_w if self.npass == 1 else 8, dtype=torch.int16, device=self.device)
+        self.wf32 = torch.zeros(n_w if self.npass == 3 else 8, dtype=torch.float32, device=self.device)
         self.fprep = torch.zeros(_align(fl.off, 8), dtype=torch.float32, device=self.device)
         arr = (PrepEntry * len(entries))()
         for i, (so, do, r, c_, sld, dld, kind) in enumerate(entries):
@@ -237,21 +241,23 @@ class HfttEngine:
         self.fold = FoldDesc(self.d, self.cfg['cnn_channel'], self.cfg['cnn_kernel'], self.n_proc, self.Kp, _align(self.d, 64),
                              self.P(e + 'conv.weight'), self.P(e + 'conv.bias'), self.P(e + 'tok_embedding_freq.weight'),
                              self.P(e + 'tok_embedding_freq.bias'),
-                             self.whi.data_ptr() + 2 * W['embed'], self.wlo.data_ptr() + 2 * W['embed'],
+                             (self.wbf.data_ptr() + 2 * W['embed']) if self.npass == 1 else 0,
+                             (self.wf32.data_ptr() + 4 * W['embed']) if self.npass == 3 else 0,
                              self.fprep.data_ptr() + 4 * W['embed_b'],
                              self.dweff.data_ptr(), self.dbeff.data_ptr(),
                              self.G(e + 'conv.weight'), self.G(e + 'conv.bias'), self.G(e + 'tok_embedding_freq.weight'),
                              self.G(e + 'tok_embedding_freq.bias'))
 
-    def Wp(self, key):   # (hi, lo) device addresses of a prepared matrix
+    def Wp(self, key):   # device address of a prepared matrix (bf16 plane or fp32 copy, by precision)
         o = self.Woff[key]
-        return (self.whi.data_ptr() + 2 * o, self.wlo.data_ptr() + 2 * o)
+        return (self.wbf.data_ptr() + 2 * o) if self.npass == 1 else (self.wf32.data_ptr() + 4 * o)
 
     def Fp(self, key):
         return self.fprep.data_ptr() + 4 * self.Woff[key]
 
     def prepare_weights(self, stream):
-        check(self.lib.hftt_prep_weights(self.flat_params.data_ptr(), self.whi.data_ptr(), self.wlo.data_ptr(),
+        check(self.lib.hftt_prep_weights(self.flat_params.data_ptr(), self.wbf.data_ptr() if self.npass == 1 else 0,
+                                         self.wf32.data_ptr() if self.npass == 3 else 0,
                                          self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights')
         check(self.lib.hftt_embed_fold_fwd(C.byref(self.fold), stream), 'embed_fold_fwd')
 
@@ -270,7 +276,7 @@ class HfttEngine:
         dsc = GemmNtDesc()
         dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, self.npass
         dsc.A, dsc.lda = A, lda
-        dsc.Whi, dsc.Wlo = W
+        dsc.W = W
         dsc.bias = bias
         dsc.C, dsc.ldc = Cp, ldc
         dsc.act, dsc.out_scale = act, out_scale
@@ -368,7 +374,7 @@ class HfttEngine:
         b = ws['bufs']
         qkv = self._buf(ws, tag + '.qkv', S, 3 * d)
         ctx = self._buf(ws, tag + '.ctx', S, d)
-        lse = self._buf(ws, tag + '.lse', n_seq * H * L)
+        lse = self._buf(ws, tag + '.lse', n_seq * H * L * 2)
         r1 = self._buf(ws, tag + '.r1', S, d); x1 = self._buf(ws, tag + '.x1', S, d)
         m1 = self._buf(ws, tag + '.m1', S); s1 = self._buf(ws, tag + '.s1', S)
         h = self._buf(ws, tag + '.h', S, p)
@@ -440,7 +446,7 @@ class HfttEngine:
             if j > 0:
                 sqkv = self._buf(ws, tag + '.sqkv', Sn, 3 * d)
                 sctx = self._buf(ws, tag + '.sctx', Sn, d)
-                slse = self._buf(ws, tag + '.slse', BT * H * N)
+                slse = self._buf(ws, tag + '.slse', BT * H * N * 2)
                 sr = self._buf(ws, tag + '.sr', Sn, d); sx = self._buf(ws, tag + '.sx', Sn, d)
                 sm = self._buf(ws, tag + '.sm', Sn); ss = self._buf(ws, tag + '.ss', Sn)
                 s_a, s_o = self._new_site(), self._new_site()
@@ -462,7 +468,7 @@ class HfttEngine:
                 res, res_mod = pos_dec, N
             ckv = self._buf(ws, tag + '.ckv', Se, 2 * d)
             cctx = self._buf(ws, tag + '.cctx', Sn, d)
-            clse = self._buf(ws, tag + '.clse', BT * H * N)
+            clse = self._buf(ws, tag + '.clse', BT * H * N * 2)
             cr = self._buf(ws, tag + '.cr', Sn, d); cx = self._buf(ws, tag + '.cx', Sn, d)
             cm = self._buf(ws, tag + '.cm', Sn); cs = self._buf(ws, tag + '.cs', Sn)
             c_a, c_o = self._new_site(), self._new_site()

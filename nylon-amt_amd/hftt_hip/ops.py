@@ -27,8 +27,9 @@ def _align(x, a):
     return (x + a - 1) // a * a
 
 
-def split_weight(w: torch.Tensor, transposed=False, n_pad=64):
-    """fp32 [rows, cols] -> bf16 hi/lo planes (int16 tensors) [align(rows, n_pad), cols] (or the transpose)."""
+def prepare_weight(w: torch.Tensor, npass=3, transposed=False, n_pad=64):
+    """fp32 [rows, cols] -> the GEMM operand [align(rows, n_pad), cols] (or its transpose): bf16 (int16 tensor) for npass 1,
+    fp32 for npass 3."""
     _need_cuda(w)
     w = w.contiguous().float()
     rows, cols = w.shape
@@ -36,12 +37,12 @@ def split_weight(w: torch.Tensor, transposed=False, n_pad=64):
         out_r, out_c = _align(cols, n_pad), _align(rows, 32)
     else:
         out_r, out_c = _align(rows, n_pad), cols
-    hi = torch.zeros(out_r, out_c, dtype=torch.int16, device=w.device)
-    lo = torch.zeros_like(hi)
+    out = torch.zeros(out_r, out_c, dtype=torch.int16 if npass == 1 else torch.float32, device=w.device)
     ent = (PrepEntry * 1)(PrepEntry(0, 0, rows, cols, cols, out_c, 1 if transposed else 0, 0))
     table = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).to(w.device)
-    check(lib().hftt_prep_weights(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), 0, table.data_ptr(), 1, _stream(w.device)), 'prep_weights')
-    return hi, lo
+    check(lib().hftt_prep_weights(w.data_ptr(), out.data_ptr() if npass == 1 else 0, out.data_ptr() if npass == 3 else 0, 0,
+                                  table.data_ptr(), 1, _stream(w.device)), 'prep_weights')
+    return out
 
 
 def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_mod=0, gate=None, gate_scale=1.0,
@@ -50,12 +51,12 @@ def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_
     _need_cuda(A, W)
     M, K = A.shape
     N = W.shape[0]
-    hi, lo = planes if planes is not None else split_weight(W)
+    Wprep = planes if planes is not None else prepare_weight(W, npass)
     Cout = torch.empty(M, N, device=A.device)
     d = GemmNtDesc()
     d.M, d.N, d.K, d.npass = M, N, K, npass
     d.A, d.lda = A.data_ptr(), A.stride(0)
-    d.Whi, d.Wlo = hi.data_ptr(), lo.data_ptr()
+    d.W = Wprep.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc = Cout.data_ptr(), N
     d.act, d.out_scale = act, out_scale
@@ -112,12 +113,12 @@ def _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed):
 
 
 def attn_fwd(q, k, v, n_heads, npass=3, want_probs=False, drop_p=0.0, drop_site=0, drop_seed=0):
-    """q [n_seq, Lq, d], k/v [n_seq, Lk, d] (any row/seq strides) -> out [n_seq, Lq, d], lse [n_seq, H, Lq](, probs)."""
+    """q [n_seq, Lq, d], k/v [n_seq, Lk, d] (any row/seq strides) -> out [n_seq, Lq, d], row stats [n_seq, H, Lq, 2](, probs)."""
     _need_cuda(q, k, v)
     n_seq, Lq, dm = q.shape
     Lk = k.shape[1]
     out = torch.empty(n_seq, Lq, dm, device=q.device)
-    lse = torch.empty(n_seq, n_heads, Lq, device=q.device)
+    lse = torch.empty(n_seq, n_heads, Lq, 2, device=q.device)     # (row max, 1/row sum)
     probs = torch.empty(n_seq, n_heads, Lq, Lk, device=q.device) if want_probs else None
     d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed)
     d.out, d.o_seq_stride, d.ldo = out.data_ptr(), out.stride(0), out.stride(1)

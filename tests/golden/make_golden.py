@@ -144,8 +144,81 @@ def make_big(name, cfg, bsz, seed, with_grads=True):
     print(name, ': loss', loss.item(), 'keys', len(d))
 
 
+class _EchoModel:
+    """Stand-in 'model' for the windowing goldens: a deterministic function of the clip's centre frames."""
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def eval(self):
+        return self
+
+    def __call__(self, spec):
+        c = self.cfg
+        ctr = spec[:, :c['midi']['num_note'], c['input']['margin_b']:c['input']['margin_b'] + c['input']['num_frame']].transpose(1, 2)
+        edge = spec[:, :c['midi']['num_note'], :c['input']['num_frame']].transpose(1, 2)     # looks into the left margin
+        nv = c['midi']['num_velocity']
+        vel = torch.stack([(ctr * (k + 1)).sin() for k in range(nv)], dim=-1)
+        return (ctr, ctr * 0.5 + edge, ctr - 1.0, vel, None, edge, ctr + edge, ctr * 2.0, vel.flip(-1))
+
+
+def make_amt():
+    """AMT.transcript / transcript_stride / mpe2note goldens.  model/amt.py imports torchaudio and pretty_midi at module
+    top (amt.py:6-7); neither is installed here and neither is touched by the three methods exercised, so EMPTY
+    placeholder modules satisfy the import statements (they implement nothing)."""
+    import types
+    for name in ('torchaudio', 'pretty_midi'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    from model.amt import AMT
+    assert importlib.import_module('model.amt').__file__.startswith('/root/reference/')
+    cfg = {'feature': {'sr': 16000, 'hop_sample': 256, 'mel_bins': 12, 'n_bins': 12}, 'input': {'margin_b': 2, 'margin_f': 2, 'num_frame': 8, 'min_value': -18.5},
+           'midi': {'note_min': 21, 'note_max': 28, 'num_note': 8, 'num_velocity': 4}}
+    amt = AMT(cfg, None)
+    amt.model = _EchoModel(cfg)
+    amt.device = 'cpu'
+    d = {}
+    rng = np.random.RandomState(7)
+    for n in (8, 21, 30):
+        feat = rng.randn(n, 12).astype(np.float32)
+        d[f'tr.{n}.feature'] = feat
+        for i, o in enumerate(amt.transcript(feat)):
+            d[f'tr.{n}.out{i}'] = o
+        for n_off in (0, 2, 4):
+            for i, o in enumerate(amt.transcript_stride(feat, n_off)):
+                d[f'trs.{n}.{n_off}.out{i}'] = o
+    # mpe2note: smooth random posteriorgrams with plateaus and ties, full-size config constants
+    cfg2 = {'feature': {'sr': 16000, 'hop_sample': 256}, 'midi': {'note_min': 21, 'num_note': 88}}
+    amt2 = AMT(cfg2, None)
+    for case in range(2):
+        r = np.random.RandomState(100 + case)
+        n = 160
+        def track():
+            x = r.rand(n + 8, 88).astype(np.float32)
+            k = np.ones(5, np.float32) / 5
+            x = np.stack([np.convolve(x[:, j], k, mode='valid') for j in range(88)], 1)[:n]
+            x = (x - x.min()) / (x.max() - x.min())
+            x = np.round(x * 20) / 20            # quantise -> plateaus and exact ties
+            return x.astype(np.float32)
+        on, off, mpe = track(), track(), track()
+        vel = r.randint(0, 128, size=(n, 88)).astype(np.int8)
+        vel[r.rand(n, 88) < 0.1] = 0
+        d[f'm2n.{case}.onset'], d[f'm2n.{case}.offset'], d[f'm2n.{case}.mpe'], d[f'm2n.{case}.velocity'] = on, off, mpe, vel
+        for mv in ('ignore_zero', 'org'):
+            for mo in ('shorter', 'longer', 'offset'):
+                notes = amt2.mpe2note(a_onset=on, a_offset=off, a_mpe=mpe, a_velocity=vel, thred_onset=0.6, thred_offset=0.55, thred_mpe=0.5,
+                                      mode_velocity=mv, mode_offset=mo)
+                arr = np.array([[x['pitch'], x['onset'], x['offset'], x['velocity']] for x in notes], dtype=np.float64).reshape(-1, 4)
+                d[f'm2n.{case}.{mv}.{mo}'] = arr
+    np.savez_compressed(os.path.join(HERE, 'amt.npz'), **d)
+    print('amt: keys', len(d), 'notes in case0:', len(d['m2n.0.ignore_zero.shorter']))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if '--amt-only' in sys.argv:
+        make_amt()
+        sys.exit(0)
+    make_amt()
     make_micro()
     make_big('tiny_b2', TINY, 2, 4321)
     make_big('paper_b1', PAPER, 1, 2468)
