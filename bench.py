@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training clips/sec of the paper-size hFT-Transformer (d=256, ff=512, 3+3 layers, 4 heads),
+batch 8 per GPU, 128-frame x 256-bin clips, dropout 0.1, on N MI355X GPUs (BASELINE.json configs[2]/[3]).
+
+A "step" = forward + fused loss + backward + (gradient all-reduce when N > 1) + fused Adam over one synthetic batch that
+is already resident in HBM.  One JSON line on rank 0 (see the driver contract in the task statement), with two extra
+objects: "roofline" (dominant kernel, measured with HIP events inside the timed region) and "cpu_baseline" (the CPU
+oracle = a port of the reference algorithm, timed on the host cores, rank 0 at N=1 only).
+
+Launch: python bench.py --gpus 1 --steps 20 --warmup 5
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'nylon-amt_amd'), os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch   # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+FWD_GFLOP_PER_CLIP = 249.44    # SURVEY.md section 8(d), paper size, forward; training = 3x
+
+
+def build_model(cfg, seed, dropout, dev):
+    import util
+    model = util.build_model(cfg, seed, dropout=dropout)
+    return model.to(dev)
+
+
+def cpu_baseline(cfg, threads):
+    """CPU oracle (port of the reference algorithm), one training step of batch 1 at the SAME model config."""
+    from oracle import hftt_oracle as O
+    import util
+    torch.set_num_threads(threads)
+    model = util.build_model(cfg, 1234)
+    sd = {k: v.clone().requires_grad_(True) for k, v in util.sd_cpu(model).items()}
+    names = list(sd.keys())
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    x = O.synth_spec(1, cfg, salt=1)
+    labels = O.synth_labels(1, cfg, salt=2)
+    times = []
+    for step in (1, 2):
+        t0 = time.time()
+        for t in sd.values():
+            t.grad = None
+        out = O.model_forward(sd, x, cfg, p=0.1, training=True)
+        loss = O.spec2midi_loss(out, *labels)
+        loss.backward()
+        with torch.no_grad():
+            O.adam_step([sd[k] for k in names], [sd[k].grad for k in names], m, v, step)
+        times.append(time.time() - t0)
+    return {'value': 1.0 / times[-1], 'unit': 'clips/s', 'cores': threads, 'kind': 'port',
+            'sample': 'paper-size hFT, batch 1, fp32, dropout 0.1: 1 warm-up + 1 timed step of forward+loss+backward+Adam '
+                      '(%.1f s) with the pure-PyTorch CPU oracle' % times[-1]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='clips per GPU')
+    ap.add_argument('--config', default='paper', choices=['paper', 'tiny'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'parity'])
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='skip per-launch HIP events (roofline object becomes null)')
+    args = ap.parse_args()
+
+    from oracle import hftt_oracle as O       # cpu_baseline leg + synthetic data generators only
+    from hftt_hip.trainer import TrainStep
+    from hftt_hip.profiler import LaunchProfiler
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch N>1 through torch.distributed.run' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    cfg = O.PAPER if args.config == 'paper' else O.TINY
+    B = args.batch
+    model = build_model(cfg, 1234, args.dropout, dev)
+    model.hftt_precision = args.precision
+    model.hftt_seed = 1234 + rank
+    model.train()
+    grad_sync = None
+    if world > 1:
+        from hftt_hip.ddp import FlatGradSync
+        eng = model.hftt_engine()
+        dist.broadcast(eng.flat_params, 0)
+        grad_sync = FlatGradSync(eng, world)
+    ts = TrainStep(model, lr=1e-4, grad_sync=grad_sync)
+
+    # synthetic MAESTRO-format clips, resident in HBM before the timed region (per-rank shard: seed 1234 + rank)
+    n_batches = 4
+    data = []
+    for i in range(n_batches):
+        x = O.synth_spec(B, cfg, salt=1000 * (rank + 1) + i).to(dev)
+        lab = tuple(t.to(dev).contiguous() for t in O.synth_labels(B, cfg, salt=5000 * (rank + 1) + i))
+        data.append((x, lab))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        x, lab = data[i % n_batches]
+        ts(x, *lab)
+    prof = None if args.no_profile else LaunchProfiler()
+    ts.engine.profiler = prof
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x, lab = data[i % n_batches]
+        loss = ts(x, *lab)
+    sync()
+    dt = time.perf_counter() - t0
+    ts.engine.profiler = None
+    loss_val = float(loss[0].item())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        clips = B * world * args.steps
+        value = clips / dt
+        roof = None
+        if prof is not None:
+            summ = prof.summary()
+            total_ms = sum(v['ms'] for v in summ.values())
+            key, dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
+            avg_ms = dom['ms'] / dom['launches']
+            ai = dom['flops'] / max(dom['bytes'], 1.0)
+            peak_tf = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+            ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+            if dom['flops'] > 0 and ai >= ridge:
+                ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+                roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': ach / peak_tf, 'traffic': None}
+            else:
+                ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['bytes'] > 0 else 0.0
+                roof = {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None}
+            roof.update({'kernel': key, 'launches_per_step': dom['launches'] / args.steps, 'avg_launch_ms': avg_ms,
+                         'share_of_step_device_time': dom['ms'] / max(total_ms, 1e-9),
+                         'algorithmic_flops_per_launch': dom['flops'] / dom['launches'], 'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
+                         'tflops': dom['flops'] / (dom['ms'] * 1e-3) / 1e12})
+            top = sorted(summ.items(), key=lambda kv: -kv[1]['ms'])[:12]
+            kernels = [{'kernel': k, 'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
+                        'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else None,
+                        'gbs': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['bytes'] else None} for k, v in top]
+        else:
+            kernels = None
+        result = {
+            'metric': 'training clips/sec (128-frame x 256-bin)', 'value': value, 'unit': 'clips/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s-size hFT-Transformer training step (d=%d, ff=%d, %d+%d layers, %d heads), batch %d clips/GPU, '
+                                   'dropout %.2f, forward+loss+backward+Adam' % (args.config, cfg.hid_dim, cfg.pf_dim, cfg.enc_layer, cfg.dec_layer,
+                                                                                cfg.enc_head, B, args.dropout),
+                       'global_batch': B * world, 'frames': cfg.n_frame, 'bins': cfg.n_bin, 'parallelism': 'dp%d' % world,
+                       'precision_mode': args.precision},
+            'model_tflops': 3 * FWD_GFLOP_PER_CLIP * value / 1e3 if args.config == 'paper' else None,
+            'final_loss': loss_val,
+            'roofline': roof,
+            'kernels': kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            result['cpu_baseline'] = cpu_baseline(cfg, threads)
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

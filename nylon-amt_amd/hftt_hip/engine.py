@@ -81,6 +81,7 @@ class HfttEngine:
         self._bound = None                          # list of (name, param, offset, numel)
         self._ws = {}
         self._site = 0
+        self.profiler = None                        # optional per-launch HIP-event timer (bench.py)
 
     # ------------------------------------------------------------------ precision / parameters
     def set_precision(self, precision):
@@ -292,7 +293,13 @@ class HfttEngine:
         if drop_site:
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
-        plan.append((self.lib.hftt_gemm_nt, (C.byref(dsc),), 'gemm_nt'))
+        n_pad = _align(N, 64)
+        bn = N if ln is not None else (256 if n_pad % 256 == 0 else (128 if n_pad % 128 == 0 else 64))
+        esz = 2 if self.npass == 1 else 4
+        nbytes = 4 * M * K + 4 * M * N + esz * N * K + (4 * M * N if residual else 0) + (4 * M * N if ln is not None else 0) + (4 * M * N if gate else 0)
+        meta = {'kernel': 'gemm_nt_kernel<%d, %s, %s>' % (bn, 'true' if self.npass == 3 else 'false', 'true' if ln is not None else 'false'),
+                'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
+        plan.append((self.lib.hftt_gemm_nt, (C.byref(dsc),), 'gemm_nt', meta))
         return dsc
 
     def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0):
@@ -309,7 +316,10 @@ class HfttEngine:
         dsc.K_out = K_out or K
         ws['tn'].append(dsc)
         ws['keep'].append(dsc)
-        plan.append((self.lib.hftt_gemm_tn, (C.byref(dsc),), 'gemm_tn'))
+        tile = '2, 4' if (N >= 256 and K >= 256) else ('1, 2' if (N >= 128 and K >= 128) else '1, 1')
+        meta = {'kernel': 'gemm_tn_kernel<%s, %d>' % (tile, self.npass), 'flops': 2.0 * M * N * K, 'bytes': 4.0 * M * (N + K) + 4.0 * N * K,
+                'shape': (M, N, K)}
+        plan.append((self.lib.hftt_gemm_tn, (C.byref(dsc),), 'gemm_tn', meta))
         return dsc
 
     def _attn(self, plan, ws, bwd, n_seq, H, Lq, Lk, q, qss, ldq, k, kss, ldk, v, vss, ldv, out, oss, ldo, lse, probs=0,
@@ -329,7 +339,17 @@ class HfttEngine:
         if drop_site:
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
-        plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd'))
+        dh = self.d // H
+        kt = (Lk + 31) // 32
+        kt = kt if kt <= 4 else 8
+        qkv_bytes = 4.0 * n_seq * (Lq + 2 * Lk) * self.d
+        if bwd:
+            meta = {'kernel': 'attn_bwd_kernel<%d, %d, %d>' % (kt, dh, self.npass), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
+                    'bytes': 2 * qkv_bytes + 2 * 4.0 * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
+        else:
+            meta = {'kernel': 'attn_fwd_kernel<%d, %d, %d>' % (kt, dh, self.npass), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
+                    'bytes': qkv_bytes + 4.0 * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
+        plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd', meta))
         return dsc
 
     def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta):
@@ -344,8 +364,8 @@ class HfttEngine:
         if drop_site:
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
-        plan.append((self.lib.hftt_ln_bwd, (C.byref(dsc),), 'ln_bwd'))
-        plan.append(('ln_reduce', (n_wg, self.d, dgamma, dbeta, beta), 'ln_bwd_reduce'))
+        plan.append((self.lib.hftt_ln_bwd, (C.byref(dsc),), 'ln_bwd', None))
+        plan.append(('ln_reduce', (n_wg, self.d, dgamma, dbeta, beta), 'ln_bwd_reduce', None))
 
     # ------------------------------------------------------------------ workspace + plans for one batch size
     def workspace(self, B):
@@ -419,7 +439,7 @@ class HfttEngine:
         win = self._buf(ws, 'win', Se, self.Kp)
         x0 = self._buf(ws, 'x0', Se, d)
         e = 'encoder_spec2midi.'
-        plan.append((self.lib.hftt_im2win, (spec.data_ptr(), win.data_ptr(), B, F, T, self.n_proc, self.Kp), 'im2win'))
+        plan.append((self.lib.hftt_im2win, (spec.data_ptr(), win.data_ptr(), B, F, T, self.n_proc, self.Kp), 'im2win', None))
         s_emb = self._new_site()
         ws['sites']['embed'] = s_emb
         self._nt(plan, ws, Se, d, self.Kp, win.data_ptr(), self.Kp, self.Wp('embed'), self.Fp('embed_b'), x0.data_ptr(), d,
@@ -486,12 +506,12 @@ class HfttEngine:
         # ---------------- heads A ----------------
         logits_f = self._buf(ws, 'logits_f', Sn, self.NHp)
         self._nt(plan, ws, Sn, self.NH, d, trg, d, self.Wp('heads_f'), self.Fp('heads_f_b'), logits_f.data_ptr(), self.NHp)
-        plan.append(('heads', (logits_f.data_ptr(), 0), 'heads_split'))
+        plan.append(('heads', (logits_f.data_ptr(), 0), 'heads_split', None))
         # ---------------- decoder, time axis ----------------
         y0 = self._buf(ws, 'y0', Sn, d)
         s_t = self._new_site()
         ws['sites']['time_embed'] = s_t
-        plan.append(('time_embed', (trg, self.P(dd + 'pos_embedding_time.weight'), y0.data_ptr(), s_t), 'time_embed_fwd'))
+        plan.append(('time_embed', (trg, self.P(dd + 'pos_embedding_time.weight'), y0.data_ptr(), s_t), 'time_embed_fwd', None))
         y = y0.data_ptr()
         ws['time_in'] = [y]
         for i in range(self.Ld):
@@ -499,7 +519,7 @@ class HfttEngine:
             ws['time_in'].append(y)
         logits_t = self._buf(ws, 'logits_t', Sn, self.NHp)
         self._nt(plan, ws, Sn, self.NH, d, y, d, self.Wp('heads_t'), self.Fp('heads_t_b'), logits_t.data_ptr(), self.NHp)
-        plan.append(('heads', (logits_t.data_ptr(), 1), 'heads_split'))
+        plan.append(('heads', (logits_t.data_ptr(), 1), 'heads_split', None))
         ws['fwd'] = plan
         ws['enc'] = enc
 
@@ -592,7 +612,7 @@ class HfttEngine:
                     (V + 2, 1, self.G(f'{dd}fc_mpe_{tag}.weight'), self.G(f'{dd}fc_mpe_{tag}.bias'))]
 
         # ---- heads B + time layers ----
-        plan.append(('heads_bwd', ('B', dlog, 1), 'heads_split_bwd'))
+        plan.append(('heads_bwd', ('B', dlog, 1), 'heads_split_bwd', None))
         y_last = ws['time_in'][-1]
         self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, y_last, d, head_segs('time'))
         self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_t_t'), 0, nGA, d)
@@ -600,12 +620,12 @@ class HfttEngine:
         for i in reversed(range(self.Ld)):
             self._enc_layer_bwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, ws['time_in'][i], Gn)
         # ---- heads A, then the time-embedding transpose back onto the note-major gradient ----
-        plan.append(('heads_bwd', ('A', dlog, 0), 'heads_split_bwd'))
+        plan.append(('heads_bwd', ('A', dlog, 0), 'heads_split_bwd', None))
         f_last = ws['dec_out'][-1]
         self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, f_last, d, head_segs('freq'))
         self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_f_t'), 0, nGD, d)
-        plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed']), 'time_embed_bwd'))
-        plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws), 'colsum'))
+        plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed']), 'time_embed_bwd', None))
+        plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws), 'colsum', None))
         # ---- frequency decoder layers, last to first.  Gradient stream lives in A (= nGD), per-sequence dq in Q1 (= nGA);
         #      the encoder-output gradient accumulates in eGA ----
         A, Bf, Cf, Q1 = nGD, nGB, nGC, nGA
@@ -665,8 +685,8 @@ class HfttEngine:
             else:
                 # layer zero: query = fc_q(pos_embedding_freq) shared by all sequences, residual = pos_embedding_freq
                 gpos = self.G(dd + 'pos_embedding_freq.weight')
-                plan.append(('colsum', (Bf, BT, N * d, N * d, gpos, 0.0, cs_ws), 'colsum'))       # residual path (undropped dr)
-                plan.append(('colsum', (Q1, BT, N * d, N * d, dq0s, 0.0, cs_ws), 'colsum'))       # sum of per-sequence dq
+                plan.append(('colsum', (Bf, BT, N * d, N * d, gpos, 0.0, cs_ws), 'colsum', None))       # residual path (undropped dr)
+                plan.append(('colsum', (Q1, BT, N * d, N * d, dq0s, 0.0, cs_ws), 'colsum', None))       # sum of per-sequence dq
                 self._tn(plan, ws, N, d, d, dq0s, d, self.P(dd + 'pos_embedding_freq.weight'), d,
                          [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
                 self._nt(plan, ws, N, d, d, dq0s, d, self.Wp(tag + '.ca.q_t'), 0, gpos, d, residual=gpos, ldr=d)
@@ -675,11 +695,11 @@ class HfttEngine:
         for i in reversed(range(self.Le)):
             self._enc_layer_bwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, ws['enc_in'][i], Ge)
         # ---- embedding ----
-        plan.append(('dropout_bwd', (eGA, Se * d, ws['sites']['embed']), 'dropout_bwd'))
-        plan.append(('colsum', (eGA, BT, F * d, F * d, self.G(e + 'pos_embedding_freq.weight'), 0.0, cs_ws), 'colsum'))
+        plan.append(('dropout_bwd', (eGA, Se * d, ws['sites']['embed']), 'dropout_bwd', None))
+        plan.append(('colsum', (eGA, BT, F * d, F * d, self.G(e + 'pos_embedding_freq.weight'), 0.0, cs_ws), 'colsum', None))
         self._tn(plan, ws, Se, d, self.Kp, eGA, d, b['win'].data_ptr(), self.Kp, [(0, d, self.dweff.data_ptr(), self.dbeff.data_ptr())],
                  out_scale=math.sqrt(d))
-        plan.append((self.lib.hftt_embed_fold_bwd, (C.byref(self.fold),), 'embed_fold_bwd'))
+        plan.append((self.lib.hftt_embed_fold_bwd, (C.byref(self.fold),), 'embed_fold_bwd', None))
         ws['bwd'] = plan
 
     # ------------------------------------------------------------------ running plans
@@ -687,7 +707,10 @@ class HfttEngine:
         L = self.lib
         B, T, N, V, d = ws['B'], self.T, self.N, self.V, self.d
         inv_keep = 1.0 / (1.0 - p) if p > 0.0 else 1.0
-        for fn, args, name in plan:
+        prof = self.profiler
+        for fn, args, name, meta in plan:
+            if prof is not None:
+                prof.begin(name, meta)
             if not isinstance(fn, str):
                 rc = fn(*args, stream)
             elif fn == 'ln_reduce':
@@ -718,6 +741,8 @@ class HfttEngine:
                 rc = L.hftt_dropout_bwd(g, n, p, site, seed, stream) if p > 0.0 else 0
             else:
                 raise _capi.HfttError('unknown plan op %s' % fn)
+            if prof is not None:
+                prof.end()
             if rc != 0:
                 check(rc, name)
 

@@ -60,9 +60,10 @@ class TrainStep:
 
     def __call__(self, spec, label_onset, label_offset, label_mpe, label_velocity):
         loss = self.forward_backward(spec, label_onset, label_offset, label_mpe, label_velocity)
+        scale = 1.0
         if self.grad_sync is not None:
-            self.grad_sync(self.engine.flat_grads)
-        self.opt.step()
+            scale = self.grad_sync(self.engine.flat_grads) or 1.0     # all-reduce(sum); the 1/world factor goes into Adam
+        self.opt.step(grad_scale=scale)
         return loss            # [9] device tensor: total + 8 terms (no host sync here)
 
     def expose_grads(self):
