@@ -21,7 +21,8 @@ class FlatGradSync:
     def __init__(self, engine, world, buckets=1):
         self.engine = engine
         self.world = world
-        self.stream = torch.cuda.Stream(device=engine.device)
+        self.cuda = engine.flat_grads.is_cuda
+        self.stream = torch.cuda.Stream(device=engine.flat_grads.device) if self.cuda else None
         n = engine.flat_grads.numel()
         step = (n + buckets - 1) // buckets
         step = (step + 1023) // 1024 * 1024
@@ -29,7 +30,11 @@ class FlatGradSync:
         self.scale = 1.0 / world
 
     def __call__(self, flat_grads):
-        cur = torch.cuda.current_stream(self.engine.device)
+        if not self.cuda:                      # gloo / CPU tensors (tests): same bucketing, no streams
+            for a, b in self.slices:
+                dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM)
+            return self.scale
+        cur = torch.cuda.current_stream(flat_grads.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             for a, b in self.slices:

@@ -14,7 +14,8 @@ from ._capi import HfttError
 class FusedAdam:
     """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) over the engine's flat buffers."""
 
-    def __init__(self, engine, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, model_or_engine, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        engine = model_or_engine.hftt_engine() if hasattr(model_or_engine, 'hftt_engine') else model_or_engine
         self.engine = engine
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
@@ -41,10 +42,12 @@ class FusedAdam:
 class TrainStep:
     """One object per (model, optimizer): ``loss = step(spec, onset, offset, mpe, velocity)``."""
 
-    def __init__(self, model, lr=1e-4, weight_A=1.0, weight_B=1.0, grad_sync=None):
+    def __init__(self, model, lr=1e-4, weight_A=1.0, weight_B=1.0, grad_sync=None, optimizer=None):
         self.model = model
         self.engine = model.hftt_engine()
-        self.opt = FusedAdam(self.engine, lr=lr)
+        self.opt = optimizer if optimizer is not None else FusedAdam(self.engine, lr=lr)
+        if self.opt.engine is not self.engine:
+            raise HfttError('FusedAdam was built for a different engine binding')
         self.weight_A, self.weight_B = weight_A, weight_B
         self.grad_sync = grad_sync          # callable(flat_grads) -> None (DDP all-reduce), or None
 

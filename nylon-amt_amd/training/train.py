@@ -1,0 +1,130 @@
+"""Drop-in replacement of the reference's ``training/train.py`` hot loops (``train`` :63-162, ``valid`` :168-254) for the
+MI355X HIP model.  Same call signatures and return values, so ``m_training.py`` can ``import train`` unchanged.
+
+Two execution paths, same kernels underneath:
+  * fast path -- when ``optimizer`` is ``hftt_hip.trainer.FusedAdam`` (Adam defaults of m_training.py:146) and the eight
+    criteria are the reference's (6x nn.BCELoss, 2x nn.CrossEntropyLoss, mean reduction): forward plan -> fused loss kernel
+    -> backward plan -> fused Adam on the flat parameter buffer, no autograd graph, no per-step host sync;
+  * compatibility path -- any other optimizer / criterion: the model's autograd.Function + torch criteria + ``optimizer.step()``
+    exactly as training/train.py:89-160 does.
+The mir_eval metrics branch of ``valid`` (train.py:9-57,193-200: SURVEY section 2 #15, a metric artefact) is out of scope:
+``metrics=True`` raises.
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from hftt_hip._capi import HfttError           # noqa: E402
+from hftt_hip.trainer import FusedAdam, TrainStep   # noqa: E402
+
+try:
+    from tqdm import tqdm
+except Exception:      # pragma: no cover
+    def tqdm(x, **k):
+        return x
+
+
+def _reference_criteria(cs):
+    a = cs[:4] + cs[4:]
+    return (all(isinstance(c, nn.BCELoss) and c.reduction == 'mean' and c.weight is None for c in (a[0], a[1], a[2], a[4], a[5], a[6]))
+            and all(isinstance(c, nn.CrossEntropyLoss) and c.reduction == 'mean' and c.weight is None and c.ignore_index == -100
+                    and c.label_smoothing == 0.0 for c in (a[3], a[7])))
+
+
+def train(model, iterator, optimizer,
+          criterion_onset_A, criterion_offset_A, criterion_mpe_A, criterion_velocity_A,
+          criterion_onset_B, criterion_offset_B, criterion_mpe_B, criterion_velocity_B,
+          weight_A, weight_B,
+          device, verbose_flag):
+    model.train()
+    crits = (criterion_onset_A, criterion_offset_A, criterion_mpe_A, criterion_velocity_A,
+             criterion_onset_B, criterion_offset_B, criterion_mpe_B, criterion_velocity_B)
+    fast = isinstance(optimizer, FusedAdam) and _reference_criteria(crits)
+    step = None
+    if fast:
+        step = getattr(optimizer, '_train_step', None)
+        if step is None or step.model is not model:
+            step = TrainStep(model, weight_A=weight_A, weight_B=weight_B, optimizer=optimizer)
+            optimizer._train_step = step
+        step.weight_A, step.weight_B = weight_A, weight_B
+    epoch_loss = torch.zeros((), device=device, dtype=torch.float64) if fast else 0
+    n = 0
+    for i, (input_spec, label_onset, label_offset, label_mpe, label_velocity) in tqdm(enumerate(iterator), total=len(iterator)):
+        input_spec = input_spec.to(device, non_blocking=True)
+        label_onset = label_onset.to(device, non_blocking=True)
+        label_offset = label_offset.to(device, non_blocking=True)
+        label_mpe = label_mpe.to(device, non_blocking=True)
+        label_velocity = label_velocity.to(device, non_blocking=True)
+        n += 1
+        if fast:
+            loss9 = step(input_spec, label_onset.float().contiguous(), label_offset.float().contiguous(), label_mpe.float().contiguous(),
+                         label_velocity.long().contiguous())
+            epoch_loss += loss9[0].double()          # stays on the device: one host sync per epoch instead of per step (train.py:160)
+            continue
+        optimizer.zero_grad()
+        (output_onset_A, output_offset_A, output_mpe_A, output_velocity_A, attention,
+         output_onset_B, output_offset_B, output_mpe_B, output_velocity_B) = model(input_spec)
+        output_velocity_A = output_velocity_A.contiguous().view(-1, output_velocity_A.shape[-1])
+        output_velocity_B = output_velocity_B.contiguous().view(-1, output_velocity_B.shape[-1])
+        label_onset = label_onset.contiguous().view(-1)
+        label_offset = label_offset.contiguous().view(-1)
+        label_mpe = label_mpe.contiguous().view(-1)
+        label_velocity = label_velocity.contiguous().view(-1)
+        loss_A = (criterion_onset_A(output_onset_A.contiguous().view(-1), label_onset) + criterion_offset_A(output_offset_A.contiguous().view(-1), label_offset)
+                  + criterion_mpe_A(output_mpe_A.contiguous().view(-1), label_mpe) + criterion_velocity_A(output_velocity_A, label_velocity))
+        loss_B = (criterion_onset_B(output_onset_B.contiguous().view(-1), label_onset) + criterion_offset_B(output_offset_B.contiguous().view(-1), label_offset)
+                  + criterion_mpe_B(output_mpe_B.contiguous().view(-1), label_mpe) + criterion_velocity_B(output_velocity_B, label_velocity))
+        loss = weight_A * loss_A + weight_B * loss_B
+        if verbose_flag is True:
+            print('(5) loss:' + str(loss.size()))
+            print(loss)
+        loss.backward()
+        optimizer.step()
+        epoch_loss += loss.item()
+    if fast:
+        epoch_loss = float(epoch_loss.item())
+    return epoch_loss / len(iterator)
+
+
+def valid(model, iterator,
+          criterion_onset_A, criterion_offset_A, criterion_mpe_A, criterion_velocity_A,
+          criterion_onset_B, criterion_offset_B, criterion_mpe_B, criterion_velocity_B,
+          weight_A, weight_B,
+          device,
+          metrics=False):
+    if metrics:
+        raise HfttError('valid(metrics=True): the mir_eval scoring branch of the reference (train.py:193-200) is out of scope')
+    model.eval()
+    crits = (criterion_onset_A, criterion_offset_A, criterion_mpe_A, criterion_velocity_A,
+             criterion_onset_B, criterion_offset_B, criterion_mpe_B, criterion_velocity_B)
+    fast = _reference_criteria(crits)
+    epoch_loss = 0
+    with torch.no_grad():
+        for i, (input_spec, label_onset, label_offset, label_mpe, label_velocity) in enumerate(tqdm(iterator)):
+            input_spec = input_spec.to(device, non_blocking=True)
+            label_onset = label_onset.to(device, non_blocking=True)
+            label_offset = label_offset.to(device, non_blocking=True)
+            label_mpe = label_mpe.to(device, non_blocking=True)
+            label_velocity = label_velocity.to(device, non_blocking=True)
+            out = model(input_spec)
+            if fast:
+                eng = model.hftt_engine()
+                loss9 = eng.loss(input_spec.shape[0], (label_onset.float().contiguous(), label_offset.float().contiguous(),
+                                                       label_mpe.float().contiguous(), label_velocity.long().contiguous()),
+                                 weight_A, weight_B, with_grad=False)
+                epoch_loss += loss9[0].item()
+                continue
+            oa, fa, ma, va, _att, ob, fb, mb, vb = out
+            lo, lf, lm, lv = (t.contiguous().view(-1) for t in (label_onset, label_offset, label_mpe, label_velocity))
+            loss_A = (criterion_onset_A(oa.contiguous().view(-1), lo) + criterion_offset_A(fa.contiguous().view(-1), lf)
+                      + criterion_mpe_A(ma.contiguous().view(-1), lm) + criterion_velocity_A(va.contiguous().view(-1, va.shape[-1]), lv))
+            loss_B = (criterion_onset_B(ob.contiguous().view(-1), lo) + criterion_offset_B(fb.contiguous().view(-1), lf)
+                      + criterion_mpe_B(mb.contiguous().view(-1), lm) + criterion_velocity_B(vb.contiguous().view(-1, vb.shape[-1]), lv))
+            epoch_loss += (weight_A * loss_A + weight_B * loss_B).item()
+    return epoch_loss, len(iterator)

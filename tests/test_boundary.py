@@ -1,0 +1,85 @@
+"""Drop-in boundary without a GPU: class paths, constructor signatures, parameter names / shapes,
+initialisation stream, pickling, and the refusal to compute on the CPU."""
+import inspect
+import io
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from util import O
+
+
+def test_constructor_signatures_match_the_reference():
+    from model import model_spec2midi as M
+    sig = lambda f: list(inspect.signature(f).parameters)[1:]
+    assert sig(M.Encoder_SPEC2MIDI.__init__) == ['n_margin', 'n_frame', 'n_bin', 'cnn_channel', 'cnn_kernel', 'hid_dim', 'n_layers',
+                                                 'n_heads', 'pf_dim', 'dropout', 'device']              # model_spec2midi.py:42
+    assert sig(M.Decoder_SPEC2MIDI.__init__) == ['n_frame', 'n_bin', 'n_note', 'n_velocity', 'hid_dim', 'n_layers', 'n_heads', 'pf_dim',
+                                                 'dropout', 'device']                                    # :113
+    assert sig(M.Model_SPEC2MIDI.__init__) == ['encoder', 'decoder']                                     # :10
+    assert sig(M.EncoderLayer.__init__) == ['hid_dim', 'n_heads', 'pf_dim', 'dropout', 'device']
+    assert sig(M.MultiHeadAttentionLayer.__init__) == ['hid_dim', 'n_heads', 'dropout', 'device']
+    assert sig(M.PositionwiseFeedforwardLayer.__init__) == ['hid_dim', 'pf_dim', 'dropout']
+    from model.amt import AMT
+    assert sig(AMT.__init__) == ['config', 'model_path', 'batch_size', 'verbose_flag']
+    assert sig(AMT.transcript) == ['a_feature', 'mode', 'ablation_flag']
+    assert sig(AMT.transcript_stride) == ['a_feature', 'n_offset', 'mode', 'ablation_flag']
+    assert sig(AMT.mpe2note) == ['a_onset', 'a_offset', 'a_mpe', 'a_velocity', 'thred_onset', 'thred_offset', 'thred_mpe',
+                                 'mode_velocity', 'mode_offset']
+    with pytest.raises(AssertionError):
+        M.MultiHeadAttentionLayer(10, 3, 0.0, 'cpu')                                                     # :311
+
+
+@pytest.mark.parametrize('name,n_keys,n_params', [('tiny_b2', 115, 279646), ('paper_b1', 165, 5516574)])
+def test_state_dict_names_shapes_and_init_stream(name, n_keys, n_params):
+    g = util.golden(name)
+    cfg = util.cfg_from_golden(g)
+    model = util.build_model(cfg, int(g['seed']))
+    sd = model.state_dict()
+    ref_names = [k[len('sdsum.'):] for k in g.files if k.startswith('sdsum.')]
+    assert list(sd.keys()) == ref_names                        # same names, same order as the reference's state_dict
+    assert len(sd) == n_keys and sum(p.numel() for p in model.parameters()) == n_params
+    assert model.encoder_spec2midi.layers_freq[0].self_attention.fc_q.weight.shape == (cfg.hid_dim, cfg.hid_dim)
+    assert model.decoder_spec2midi.fc_velocity_time.weight.shape == (cfg.n_velocity, cfg.hid_dim)
+    # apply(initialize_weights) touched exactly the >1-dim weights: their checksums equal the reference's
+    for k, v in sd.items():
+        if v.dim() > 1:
+            assert abs(v.double().sum().item() - g['sdsum.' + k][0]) < 1e-9 * max(1.0, g['sdsum.' + k][1]), k
+    # load_state_dict of an oracle-side dict works, with strict key matching
+    model.load_state_dict({k: torch.zeros_like(v) for k, v in sd.items()})
+    assert all((p == 0).all() for p in model.parameters())
+
+
+def test_pickle_and_torch_save_roundtrip_on_cpu():
+    model = util.build_model(util.MINI, 3, dropout=0.1)
+    blob = pickle.dumps(model, protocol=4)
+    import pickletools
+    globs = {arg for op, arg, _ in pickletools.genops(blob) if op.name in ('GLOBAL', 'STACK_GLOBAL') and arg}
+    m2 = pickle.loads(blob)
+    assert type(m2).__module__ == 'model.model_spec2midi' and type(m2).__name__ == 'Model_SPEC2MIDI'
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert m2.encoder_spec2midi.dropout.p == 0.1
+    buf = io.BytesIO()
+    torch.save({'model_dict': model.state_dict(), 'model': model}, buf)
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    assert torch.equal(ck['model'].decoder_spec2midi.fc_mpe_time.weight, model.decoder_spec2midi.fc_mpe_time.weight)
+
+
+def test_no_cpu_fallback():
+    from hftt_hip import HfttError
+    from hftt_hip import ops
+    model = util.build_model(util.MINI, 1)
+    with pytest.raises(HfttError, match='no CPU fallback'):
+        model(torch.zeros(1, util.MINI.n_bin, util.MINI.n_frame + 2 * util.MINI.n_margin))
+    with pytest.raises(HfttError):
+        model.encoder_spec2midi(torch.zeros(1, 48, 24))
+    with pytest.raises(HfttError):
+        ops.gemm_nt(torch.zeros(4, 32), torch.zeros(8, 32))
+    import os
+    src = open(os.path.join(util.ROOT, 'nylon-amt_amd', 'hftt_hip', 'engine.py')).read() + open(os.path.join(util.ROOT, 'nylon-amt_amd', 'model', 'model_spec2midi.py')).read()
+    assert 'oracle' not in src                      # the product path never touches the oracle

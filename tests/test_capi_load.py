@@ -1,0 +1,79 @@
+"""The C-ABI library builds for gfx950, loads on a CPU-only box and exports every symbol include/hftt_hip.h declares;
+ctypes struct layouts match the C compiler's.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import util
+
+HDR = os.path.join(util.ROOT, 'include', 'hftt_hip.h')
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('hftt_build', os.path.join(util.ROOT, 'nylon-amt_amd', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(verbose=False)            # hipcc cross-compiles gfx950 without a GPU
+    from hftt_hip import _capi
+    return _capi.lib()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from hftt_hip import _capi
+    src = open(HDR).read()
+    declared = set(re.findall(r'\b(hftt_[a-z0-9_]+)\s*\(', src))
+    assert len(declared) >= 25
+    assert declared == set(_capi.SIGNATURES.keys()), declared ^ set(_capi.SIGNATURES.keys())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hftt_abi_version() == 1
+    assert lib.hftt_last_error() is not None
+    # pure host helpers can be called without a GPU
+    assert lib.hftt_gemm_tn_ws_bytes(1000, 256, 256) > 0
+    assert lib.hftt_ln_bwd_wgs(100000) == 1024
+    assert lib.hftt_loss_ws_bytes(1000) > 0 and lib.hftt_colsum_ws_bytes(10, 100) == 16 * 100 * 4
+
+
+def test_argument_validation_without_gpu(lib):
+    """Descriptor checks run before any launch, so error behaviour is testable on the CPU."""
+    from hftt_hip import _capi
+    d = _capi.GemmNtDesc()
+    assert lib.hftt_gemm_nt(C.byref(d), None) != 0
+    assert b'bad shape' in lib.hftt_last_error()
+    d.M, d.N, d.K, d.npass = 8, 8, 7, 1
+    assert lib.hftt_gemm_nt(C.byref(d), None) != 0
+    assert b'multiple of 32' in lib.hftt_last_error()
+    a = _capi.AttnDesc()
+    a.n_seq, a.n_heads, a.Lq, a.Lk, a.dh, a.npass = 1, 1, 300, 10, 64, 1
+    assert lib.hftt_attn_fwd(C.byref(a), None) != 0
+    assert b'1..256' in lib.hftt_last_error()
+    with pytest.raises(_capi.HfttError):
+        _capi.check(1, 'x')
+
+
+def test_struct_layouts_match_the_c_compiler(lib, tmp_path):
+    from hftt_hip import _capi
+    structs = {'hftt_prep_entry': _capi.PrepEntry, 'hftt_gemm_nt_desc': _capi.GemmNtDesc, 'hftt_gemm_tn_desc': _capi.GemmTnDesc,
+               'hftt_attn_desc': _capi.AttnDesc, 'hftt_fold_desc': _capi.FoldDesc, 'hftt_ln_bwd_desc': _capi.LnBwdDesc,
+               'hftt_loss_desc': _capi.LossDesc, 'hftt_logmel_desc': _capi.LogmelDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HDR, 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    lines += ['return 0; }']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split('\n')
+    got = dict(l.split() for l in out if l)
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f in cls._fields_:
+            assert int(got['%s.%s' % (cname, f[0])]) == getattr(cls, f[0]).offset, (cname, f[0])

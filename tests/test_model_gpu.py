@@ -262,3 +262,33 @@ def test_cpu_call_fails_loudly():
     model = util.build_model(MINI, 1)
     with pytest.raises(HfttError):
         model(torch.zeros(1, MINI.n_bin, MINI.n_frame + 2 * MINI.n_margin))
+
+
+def test_training_train_mirror_fast_and_compat_paths(dev):
+    """training.train.train()/valid() (signature of training/train.py:63,168): torch.optim.Adam + nn criteria (what
+    m_training.py passes) and the fused path give the same parameters after two steps (dropout 0)."""
+    import torch.nn as nn
+    from training import train as T
+    from hftt_hip.trainer import FusedAdam
+    cfg, B = MINI, 2
+    batches = []
+    for i in range(2):
+        x = O.synth_spec(B, cfg, salt=40 + i) * 0.5
+        lo, lf, lm, lv = O.synth_labels(B, cfg, salt=50 + i)
+        batches.append((x, lo, lf, lm, lv))
+    crits = [nn.BCELoss(), nn.BCELoss(), nn.BCELoss(), nn.CrossEntropyLoss(), nn.BCELoss(), nn.BCELoss(), nn.BCELoss(), nn.CrossEntropyLoss()]
+    res = {}
+    for mode in ('compat', 'fast'):
+        model = util.build_model(cfg, 21).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3) if mode == 'compat' else FusedAdam(model, lr=1e-3)
+        l1 = T.train(model, batches, opt, *crits, 1.0, 1.0, dev, False)
+        lv_, n = T.valid(model, batches, *crits, 1.0, 1.0, dev, False)
+        assert n == 2 and np.isfinite(l1) and np.isfinite(lv_)
+        res[mode] = (l1, lv_, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+    assert abs(res['compat'][0] - res['fast'][0]) < 1e-4
+    assert abs(res['compat'][1] - res['fast'][1]) < 2e-3
+    # Adam's first steps move every element by ~lr regardless of gradient size: noise-level gradients may take opposite signs
+    assert (res['compat'][2] - res['fast'][2]).abs().max().item() <= 4.1e-3
+    assert (res['compat'][2] - res['fast'][2]).abs().mean().item() < 2e-5
+    with pytest.raises(Exception):
+        T.valid(model, batches, *crits, 1.0, 1.0, dev, True)
