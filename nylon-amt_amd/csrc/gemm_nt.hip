@@ -243,6 +243,474 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 mode, A-stationary persistent form (N a multiple of 256, K <= 768).  These GEMMs are tall and short-K
+// (M ~ 10^5 tokens): the kernel is a streaming kernel with MFMA work hidden underneath.
+//   * persistent workgroups (2 per CU) walk the 32-row blocks of A;
+//   * a block of A (32 x K fp32) is read from HBM ONCE, converted to bf16 and kept in LDS; with DBUF the NEXT block's loads
+//     are issued before the current block's MFMA loop and land in the other LDS buffer afterwards (HBM latency hidden);
+//   * the (L2-resident) weight tiles of the current 256-wide N tile stream through a double-buffered LDS ring shared by the
+//     8 waves (a per-wave L2->register stream was measured 30 % slower: twice the L2 traffic in 32-byte pieces);
+//   * every N tile is finished through LDS: accumulators -> stage (the weight ring's space) -> one wave per row, 16 B per
+//     lane: table add, gate, dropout, residual, LayerNorm, float4 stores.  (Direct 4-byte stores from the accumulator
+//     layout were measured at 2.8 TB/s; the staged float4 form reaches > 4 TB/s.)
+// A is read once per GEMM regardless of N.
+// ------------------------------------------------------------------------------------------------------------------
+template <int APF, bool DBUF>
+__global__ __launch_bounds__(512, 4) void gemm_nt_as_kernel(const hftt_gemm_nt_desc g) {
+  constexpr int BM_ = 32;
+  constexpr int BN = 256;
+  constexpr int RSW = 40;                          // W tile row stride (bf16): 80 B
+  constexpr int W_ELEMS = BN * RSW;
+  constexpr int WCH = 2;                           // 16-byte chunks per thread per W tile (256 rows x 4 chunks / 512)
+  constexpr int STAGE_LD = BN + 4;
+  static_assert(BM_ * STAGE_LD * 4 <= 2 * W_ELEMS * 2, "stage must fit the weight ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int K = g.K;
+  const int RSA = K + 8;                           // A row stride (bf16): 2K+16 bytes, conflict-free ds_read_b128
+  const int A_ELEMS = BM_ * RSA;
+  unsigned short* As0 = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Ws = As0 + (DBUF ? 2 : 1) * A_ELEMS;
+  float* stage = reinterpret_cast<float*>(Ws);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int KT = K / 32;
+  const int NT = (g.N + BN - 1) / BN;
+  const int steps = NT * KT;
+  const int f4r = K >> 2;
+  const int a_total = BM_ * f4r;
+  const long nblk = (g.M + BM_ - 1) / BM_;
+  const unsigned short* Wb = reinterpret_cast<const unsigned short*>(g.W);
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+
+  uint4 wreg[WCH] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  auto wload = [&](int s) {
+    const int nt = s / KT, kt = s - nt * KT;
+#pragma unroll
+    for (int j = 0; j < WCH; j++) {
+      const int i = tid + 512 * j;
+      const int row = i >> 2, ch = i & 3;
+      wreg[j] = *reinterpret_cast<const uint4*>(Wb + (long)(nt * BN + row) * K + kt * 32 + ch * 8);
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < WCH; j++) {
+      const int i = tid + 512 * j;
+      const int row = i >> 2, ch = i & 3;
+      *reinterpret_cast<uint4*>(Ws + buf * W_ELEMS + row * RSW + ch * 8) = wreg[j];
+    }
+  };
+  float4 apf[APF];
+  auto aload = [&](long blk) {                     // HBM -> registers (APF x 16 B in flight per thread)
+#pragma unroll
+    for (int u = 0; u < APF; u++) {
+      const int i = tid + 512 * u;
+      apf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < a_total) {
+        const int row = i / f4r, c4 = i - row * f4r;
+        const long grow = blk * BM_ + row;
+        if (grow < g.M) apf[u] = *reinterpret_cast<const float4*>(g.A + grow * g.lda + c4 * 4);
+      }
+    }
+  };
+  auto astore = [&](unsigned short* As) {          // registers -> bf16 -> LDS
+#pragma unroll
+    for (int u = 0; u < APF; u++) {
+      const int i = tid + 512 * u;
+      if (i < a_total) {
+        const int row = i / f4r, c4 = i - row * f4r;
+        uint2 ph;
+        ph.x = f2bf(apf[u].x) | ((unsigned)f2bf(apf[u].y) << 16);
+        ph.y = f2bf(apf[u].z) | ((unsigned)f2bf(apf[u].w) << 16);
+        *reinterpret_cast<uint2*>(As + row * RSA + c4 * 4) = ph;
+      }
+    }
+  };
+
+  long blk = blockIdx.x;
+  if (blk >= nblk) return;
+  wload(0);
+  aload(blk);
+  astore(As0);
+  wstore(0);
+  __syncthreads();
+
+  int cur = 0;
+  for (; blk < nblk; blk += gridDim.x) {
+    const unsigned short* As = As0 + (DBUF ? cur : 0) * A_ELEMS;
+    const long m0 = blk * BM_;
+    const long nxt = blk + gridDim.x;
+    if (DBUF && nxt < nblk) aload(nxt);            // in flight during the whole MFMA loop of this block
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    int nt = 0, kt = 0;
+    for (int s = 0; s < steps; s++) {
+      const int buf = s & 1;
+      const bool last = (s + 1 == steps);
+      if (!last) wload(s + 1);
+      else if (nxt < nblk) wload(0);               // first weight tile of the next block
+      const unsigned short* Wt = Ws + buf * W_ELEMS;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const bf16x8 a = lds_read_b128(As + lr * RSA + kt * 32 + ks * 16 + lh * 8);
+        const bf16x8 b = lds_read_b128(Wt + (wave * 32 + lr) * RSW + ks * 16 + lh * 8);
+        acc = mfma32(a, b, acc);
+      }
+      if (kt != KT - 1) {
+        wstore(buf ^ 1);
+        kt++;
+      } else {
+        // ---------------- epilogue of N tile nt: accumulators -> stage (weight ring) -> row pass ----------------
+        const int n0 = nt * BN;
+        __syncthreads();                             // all MFMA reads of the weight ring are done
+        {
+          const int col_l = wave * 32 + lr;
+          const int col = n0 + col_l;
+          const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            float v = acc[r] + bv;
+            acc[r] = 0.f;
+            if (g.act == 1) v = fmaxf(v, 0.f);
+            stage[acc_row32(r, lh) * STAGE_LD + col_l] = v * g.out_scale;
+          }
+        }
+        __syncthreads();
+        {
+          constexpr int RPW = BM_ / 8;               // 4 rows per wave, finished two at a time
+          constexpr int RB = 2;
+          const int c4 = n0 + lane * 4;
+          float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (g.ln_gamma != nullptr) {
+            ga = *reinterpret_cast<const float4*>(g.ln_gamma + c4);
+            be = *reinterpret_cast<const float4*>(g.ln_beta + c4);
+          }
+#pragma unroll 1
+          for (int rb = 0; rb < RPW; rb += RB) {
+          float4 tab[RB], gat[RB], res[RB];
+#pragma unroll
+          for (int rr = 0; rr < RB; rr++) {
+            const long row = m0 + wave * RPW + rb + rr;
+            tab[rr] = make_float4(0.f, 0.f, 0.f, 0.f); gat[rr] = tab[rr]; res[rr] = tab[rr];
+            if (row < g.M) {
+              if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(row % g.add_mod) * g.N + c4);
+              if (g.gate != nullptr) gat[rr] = *reinterpret_cast<const float4*>(g.gate + row * g.ldg + c4);
+              if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(row % g.res_mod) * g.ldr + c4);
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < RB; rr++) {
+            const int row_l = wave * RPW + rb + rr;
+            const long row = m0 + row_l;
+            if (row < g.M) {         // wave-uniform
+              const float4 sv = *reinterpret_cast<const float4*>(stage + row_l * STAGE_LD + lane * 4);
+              float v[4] = {sv.x + tab[rr].x, sv.y + tab[rr].y, sv.z + tab[rr].z, sv.w + tab[rr].w};
+              if (g.gate != nullptr) {
+                v[0] = gat[rr].x > 0.f ? v[0] * g.gate_scale : 0.f; v[1] = gat[rr].y > 0.f ? v[1] * g.gate_scale : 0.f;
+                v[2] = gat[rr].z > 0.f ? v[2] * g.gate_scale : 0.f; v[3] = gat[rr].w > 0.f ? v[3] * g.gate_scale : 0.f;
+              }
+              if (g.drop_p > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                  v[e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)row * g.N + c4 + e, thr) ? v[e] * inv_keep : 0.f;
+              }
+              v[0] += res[rr].x; v[1] += res[rr].y; v[2] += res[rr].z; v[3] += res[rr].w;
+              if (g.ln_gamma != nullptr) {              // N == 256: the row is complete
+                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / BN);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float dlt = v[e] - mean; q += dlt * dlt; }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / BN) + 1e-5f);
+                if (g.pre_ln_out != nullptr) *reinterpret_cast<float4*>(g.pre_ln_out + row * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+                v[0] = (v[0] - mean) * rstd * ga.x + be.x; v[1] = (v[1] - mean) * rstd * ga.y + be.y;
+                v[2] = (v[2] - mean) * rstd * ga.z + be.z; v[3] = (v[3] - mean) * rstd * ga.w + be.w;
+                if (lane == 0) {
+                  if (g.ln_mean != nullptr) g.ln_mean[row] = mean;
+                  if (g.ln_rstd != nullptr) g.ln_rstd[row] = rstd;
+                }
+              }
+              *reinterpret_cast<float4*>(g.C + row * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+          }
+        }
+        __syncthreads();                             // row pass finished reading the stage (= weight ring)
+        if (!last || nxt < nblk) wstore(last ? 0 : (buf ^ 1));
+        kt = 0;
+        nt++;
+      }
+      __syncthreads();
+    }
+    // ---- next block of A ----
+    if (nxt < nblk) {
+      if (DBUF) {
+        astore(As0 + (cur ^ 1) * A_ELEMS);
+        cur ^= 1;
+      } else {
+        aload(nxt);
+        astore(As0);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int APF, bool DBUF>
+int launch_nt_as(const hftt_gemm_nt_desc& d, hipStream_t st) {
+  const int lds = ((DBUF ? 2 : 1) * 32 * (d.K + 8) + 2 * 256 * 40) * 2;
+  if (lds > 160 * 1024) { hftt_set_error("gemm_nt: K=%d too large for the A-stationary tile (%d B LDS)", d.K, lds); return 1; }
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_as_kernel<APF, DBUF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { hftt_set_error("gemm_nt: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e)); return 2; }
+    attr_lds = lds;
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { hftt_set_error("gemm_nt: device query failed"); return 2; }
+    n_cu = prop.multiProcessorCount;
+  }
+  const long nblk = ((long)d.M + 31) / 32;
+  const int per_cu = (lds <= 80 * 1024) ? 2 : 1;
+  long grid = (long)n_cu * per_cu;
+  if (grid > nblk) grid = nblk;
+  hipLaunchKernelGGL((gemm_nt_as_kernel<APF, DBUF>), dim3((unsigned)grid), dim3(512), lds, st, d);
+  HFTT_CHECK_LAUNCH("gemm_nt");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 mode, A-stationary one-shot form for K <= 256 (measured faster there than the persistent form below): one
+// workgroup per BM-row block, A block loaded once (all loads in flight), weight tiles through a double-buffered LDS ring.
+//   MODE 0  plain (bias / ReLU / scale): stores straight from the accumulators;
+//   MODE 1  staged, single N tile (N == 256): tile -> LDS -> one wave per row, 16 B per lane (table add, gate, dropout,
+//           residual, LayerNorm with float4 traffic);
+//   MODE 2  staged, several N tiles (BM = 32): same row pass per N tile, staged in the weight ring.
+// ------------------------------------------------------------------------------------------------------------------
+template <int BM_, int MODE>
+__global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_desc g) {
+  constexpr int BN = 256;
+  constexpr int WM = (BM_ == 32) ? 1 : 2;
+  constexpr int WN = 8 / WM;
+  constexpr int TN = BN / (32 * WN);
+  static_assert(BM_ == 32 * WM, "one 32-row MFMA tile per wave row");
+  constexpr int RSW = 40;
+  constexpr int W_ELEMS = BN * RSW;
+  constexpr int WCH = 2;
+  constexpr int STAGE_LD = BN + 4;
+  static_assert(MODE != 2 || BM_ * STAGE_LD * 4 <= 2 * W_ELEMS * 2, "stage must fit the weight ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int K = g.K;
+  const int RSA = K + 8;
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Ws = As + BM_ * RSA;
+  float* stage = (MODE == 2) ? reinterpret_cast<float*>(Ws) : reinterpret_cast<float*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const long m0 = (long)blockIdx.x * BM_;
+  const int KT = K / 32;
+  const int NT = (g.N + BN - 1) / BN;
+  const int steps = NT * KT;
+  const unsigned short* Wb = reinterpret_cast<const unsigned short*>(g.W);
+
+  uint4 wreg[WCH] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  auto wload = [&](int s) {
+    const int nt = s / KT, kt = s - nt * KT;
+#pragma unroll
+    for (int j = 0; j < WCH; j++) {
+      const int i = tid + 512 * j;
+      const int row = i >> 2, ch = i & 3;
+      wreg[j] = *reinterpret_cast<const uint4*>(Wb + (long)(nt * BN + row) * K + kt * 32 + ch * 8);
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < WCH; j++) {
+      const int i = tid + 512 * j;
+      const int row = i >> 2, ch = i & 3;
+      *reinterpret_cast<uint4*>(Ws + buf * W_ELEMS + row * RSW + ch * 8) = wreg[j];
+    }
+  };
+  wload(0);
+  {
+    const int f4r = K >> 2;
+    const int total = BM_ * f4r;
+    for (int base = 0; base < total; base += 512 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = base + tid + 512 * u;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total) {
+          const int row = i / f4r, c4 = i - row * f4r;
+          const long grow = m0 + row;
+          if (grow < g.M) v[u] = *reinterpret_cast<const float4*>(g.A + grow * g.lda + c4 * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = base + tid + 512 * u;
+        if (i < total) {
+          const int row = i / f4r, c4 = i - row * f4r;
+          uint2 ph;
+          ph.x = f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
+          ph.y = f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
+          *reinterpret_cast<uint2*>(As + row * RSA + c4 * 4) = ph;
+        }
+      }
+    }
+  }
+  wstore(0);
+  __syncthreads();
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+
+  int nt = 0, kt = 0;
+  for (int s = 0; s < steps; s++) {
+    const int buf = s & 1;
+    if (s + 1 < steps) wload(s + 1);
+    const unsigned short* Wt = Ws + buf * W_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const bf16x8 a = lds_read_b128(As + (wm * 32 + lr) * RSA + kt * 32 + ks * 16 + lh * 8);
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const bf16x8 b = lds_read_b128(Wt + (wn * TN * 32 + j * 32 + lr) * RSW + ks * 16 + lh * 8);
+        acc[j] = mfma32(a, b, acc[j]);
+      }
+    }
+    const bool tile_end = (kt == KT - 1);
+    if ((!tile_end || MODE == 0) && s + 1 < steps) wstore(buf ^ 1);
+    if (tile_end) {
+      const int n0 = nt * BN;
+      if (MODE != 0) __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int col_l = wn * TN * 32 + j * 32 + lr;
+        const int col = n0 + col_l;
+        const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row_l = wm * 32 + acc_row32(r, lh);
+          float v = acc[j][r] + bv;
+          acc[j][r] = 0.f;
+          if (g.act == 1) v = fmaxf(v, 0.f);
+          v *= g.out_scale;
+          if (MODE != 0) {
+            stage[row_l * STAGE_LD + col_l] = v;
+          } else {
+            const long row = m0 + row_l;
+            if (row < g.M && col < g.N) g.C[row * g.ldc + col] = v;
+          }
+        }
+      }
+      if (MODE != 0) {
+        __syncthreads();
+        constexpr int RPW = BM_ / 8;
+        constexpr int RB = RPW < 4 ? RPW : 4;
+        const int c4 = n0 + lane * 4;
+        float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.ln_gamma != nullptr) {
+          ga = *reinterpret_cast<const float4*>(g.ln_gamma + c4);
+          be = *reinterpret_cast<const float4*>(g.ln_beta + c4);
+        }
+#pragma unroll 1
+        for (int rb = 0; rb < RPW; rb += RB) {
+          float4 tab[RB], gat[RB], res[RB];
+#pragma unroll
+          for (int rr = 0; rr < RB; rr++) {
+            const long row = m0 + wave * RPW + rb + rr;
+            tab[rr] = make_float4(0.f, 0.f, 0.f, 0.f); gat[rr] = tab[rr]; res[rr] = tab[rr];
+            if (row < g.M) {
+              if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(row % g.add_mod) * g.N + c4);
+              if (g.gate != nullptr) gat[rr] = *reinterpret_cast<const float4*>(g.gate + row * g.ldg + c4);
+              if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(row % g.res_mod) * g.ldr + c4);
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < RB; rr++) {
+            const int row_l = wave * RPW + rb + rr;
+            const long row = m0 + row_l;
+            if (row < g.M) {
+              const float4 sv = *reinterpret_cast<const float4*>(stage + row_l * STAGE_LD + lane * 4);
+              float v[4] = {sv.x + tab[rr].x, sv.y + tab[rr].y, sv.z + tab[rr].z, sv.w + tab[rr].w};
+              if (g.gate != nullptr) {
+                v[0] = gat[rr].x > 0.f ? v[0] * g.gate_scale : 0.f; v[1] = gat[rr].y > 0.f ? v[1] * g.gate_scale : 0.f;
+                v[2] = gat[rr].z > 0.f ? v[2] * g.gate_scale : 0.f; v[3] = gat[rr].w > 0.f ? v[3] * g.gate_scale : 0.f;
+              }
+              if (g.drop_p > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                  v[e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)row * g.N + c4 + e, thr) ? v[e] * inv_keep : 0.f;
+              }
+              v[0] += res[rr].x; v[1] += res[rr].y; v[2] += res[rr].z; v[3] += res[rr].w;
+              if (g.ln_gamma != nullptr) {
+                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / BN);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float dlt = v[e] - mean; q += dlt * dlt; }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / BN) + 1e-5f);
+                if (g.pre_ln_out != nullptr) *reinterpret_cast<float4*>(g.pre_ln_out + row * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+                v[0] = (v[0] - mean) * rstd * ga.x + be.x; v[1] = (v[1] - mean) * rstd * ga.y + be.y;
+                v[2] = (v[2] - mean) * rstd * ga.z + be.z; v[3] = (v[3] - mean) * rstd * ga.w + be.w;
+                if (lane == 0) {
+                  if (g.ln_mean != nullptr) g.ln_mean[row] = mean;
+                  if (g.ln_rstd != nullptr) g.ln_rstd[row] = rstd;
+                }
+              }
+              *reinterpret_cast<float4*>(g.C + row * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+        if (s + 1 < steps) {
+          __syncthreads();
+          wstore(buf ^ 1);
+        }
+      }
+      kt = 0;
+      nt++;
+    } else {
+      kt++;
+    }
+    __syncthreads();
+  }
+}
+
+template <int BM_, int MODE>
+int launch_nt_as1(const hftt_gemm_nt_desc& d, hipStream_t st) {
+  int lds = (BM_ * (d.K + 8) + 2 * 256 * 40) * 2;
+  const int stage = BM_ * 260 * 4;
+  if (MODE == 1 && stage > lds) lds = stage;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_as1_kernel<BM_, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { hftt_set_error("gemm_nt: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e)); return 2; }
+    attr_lds = lds;
+  }
+  dim3 grid((unsigned)((d.M + BM_ - 1) / BM_), 1, 1);
+  hipLaunchKernelGGL((gemm_nt_as1_kernel<BM_, MODE>), grid, dim3(512), lds, st, d);
+  HFTT_CHECK_LAUNCH("gemm_nt");
+  return 0;
+}
+
 template <int BN, bool F32, bool LN>
 int launch_nt(const hftt_gemm_nt_desc& d, hipStream_t st) {
   using Cfg = NtCfg<BN, F32>;
@@ -277,6 +745,27 @@ int dispatch_nt(const hftt_gemm_nt_desc& d, hipStream_t st) {
   return launch_nt<64, F32, false>(d, st);
 }
 
+// bf16-mode dispatch
+int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
+  const bool vec_ok = (d.ldc % 4 == 0) && (((uintptr_t)d.C & 15) == 0) &&
+                      (!d.residual || (d.ldr % 4 == 0 && ((uintptr_t)d.residual & 15) == 0)) &&
+                      (!d.gate || (d.ldg % 4 == 0 && ((uintptr_t)d.gate & 15) == 0)) &&
+                      (!d.add_table || ((uintptr_t)d.add_table & 15) == 0) &&
+                      (!d.pre_ln_out || ((uintptr_t)d.pre_ln_out & 15) == 0) &&
+                      (!d.ln_gamma || d.N == 256);
+  if (d.N % 256 == 0 && d.K <= 768 && d.M >= 256 && vec_ok) {
+    if (d.K <= 256) {       // one-shot form (measured: qkv 391 vs 518 us, o+LN 256 vs 300 us against the persistent form)
+      const bool rich = d.add_table || d.gate || d.drop_p > 0.f || d.residual || d.ln_gamma;
+      if (!rich) return launch_nt_as1<64, 0>(d, st);
+      if (d.N == 256) return launch_nt_as1<64, 1>(d, st);
+      return launch_nt_as1<32, 2>(d, st);
+    }
+    if (d.K <= 512) return launch_nt_as<8, false>(d, st);     // persistent form: 33 KB + 40 KB, 2 workgroups / CU
+    return launch_nt_as<12, false>(d, st);
+  }
+  return dispatch_nt<false>(d, st);      // small / ragged shapes: the k-tiled streaming kernel
+}
+
 }  // namespace
 
 extern "C" int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream) {
@@ -293,5 +782,5 @@ extern "C" int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream) {
   HFTT_REQUIRE(d->ln_gamma == nullptr || (d->ln_beta != nullptr && d->ldc == d->N), "gemm_nt: LN needs beta and ldc == N");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->npass == 3) return dispatch_nt<true>(*d, st);
-  return dispatch_nt<false>(*d, st);
+  return dispatch_nt_bf16(*d, st);
 }

@@ -297,8 +297,15 @@ class HfttEngine:
         bn = N if ln is not None else (256 if n_pad % 256 == 0 else (128 if n_pad % 128 == 0 else 64))
         esz = 2 if self.npass == 1 else 4
         nbytes = 4 * M * K + 4 * M * N + esz * N * K + (4 * M * N if residual else 0) + (4 * M * N if ln is not None else 0) + (4 * M * N if gate else 0)
-        meta = {'kernel': 'gemm_nt_kernel<%d, %s, %s>' % (bn, 'true' if self.npass == 3 else 'false', 'true' if ln is not None else 'false'),
-                'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
+        rich = bool(add_table or gate or drop_site or residual or ln is not None)
+        if self.npass == 1 and N % 256 == 0 and K <= 768 and M >= 256:      # mirrors dispatch_nt_bf16 in csrc/gemm_nt.hip
+            if K <= 256:
+                kname = 'gemm_nt_as1_kernel<%s>' % ('64, 0' if not rich else ('64, 1' if N == 256 else '32, 2'))
+            else:
+                kname = 'gemm_nt_as_kernel<%s>' % ('8, false' if K <= 512 else '12, false')
+        else:
+            kname = 'gemm_nt_kernel<%d, %s, %s>' % (bn, 'true' if self.npass == 3 else 'false', 'true' if ln is not None else 'false')
+        meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_gemm_nt, (C.byref(dsc),), 'gemm_nt', meta))
         return dsc
 

@@ -46,7 +46,7 @@ def prepare_weight(w: torch.Tensor, npass=3, transposed=False, n_pad=64):
 
 
 def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_mod=0, gate=None, gate_scale=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, residual=None, res_mod=0, ln=None, planes=None):
+            drop_p=0.0, drop_site=0, drop_seed=0, residual=None, res_mod=0, ln=None, planes=None, debug=0):
     """C = epi(A @ W.T + bias); W fp32 [N, K].  ln = (gamma, beta) -> returns (C, pre_ln, mean, rstd)."""
     _need_cuda(A, W)
     M, K = A.shape
@@ -57,6 +57,7 @@ def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_
     d.M, d.N, d.K, d.npass = M, N, K, npass
     d.A, d.lda = A.data_ptr(), A.stride(0)
     d.W = Wprep.data_ptr()
+    d.reserved0 = debug
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc = Cout.data_ptr(), N
     d.act, d.out_scale = act, out_scale
