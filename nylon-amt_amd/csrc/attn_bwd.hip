@@ -75,23 +75,23 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   // ---- stage all of K (row-major) for the dQ product ----
   for (int i = tid; i < LKP * F4R; i += NTHR) {
     const int key = i / F4R, c4 = i % F4R;
-    float4 kf = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (key < Lk) kf = *reinterpret_cast<const float4*>(kb + (long)key * g.ldk + c4 * 4);
+    const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
+    float4 kf = *reinterpret_cast<const float4*>(kb + (long)kc * g.ldk + c4 * 4);
+    if (key >= Lk) kf = make_float4(0.f, 0.f, 0.f, 0.f);
     if (F32) put_row4(Ks32 + key * RSK + c4 * 4, kf);
     else *reinterpret_cast<uint2*>(Ks16 + key * RSK + c4 * 4) = pack4(kf);
   }
   // ---- this wave's K and V rows as B-operand fragments (B[k = dh][col = key]) ----
   const int mykey = wave * 32 + lr;
+  const int mykey_c = mykey < Lk ? mykey : Lk - 1;     // clamped address for unconditional loads
   bf16x8 kfh[KS], vfh[KS];        // bf16 path
   float kf32[HD], vf32[HD];       // fp32 path: K/V[key][HD*lh + t]
   if (F32) {
 #pragma unroll
     for (int t4 = 0; t4 < HD / 4; t4++) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (mykey < Lk) {
-        a = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + HD * lh + 4 * t4);
-        b = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + HD * lh + 4 * t4);
-      }
+      float4 a = *reinterpret_cast<const float4*>(kb + (long)mykey_c * g.ldk + HD * lh + 4 * t4);
+      float4 b = *reinterpret_cast<const float4*>(vb + (long)mykey_c * g.ldv + HD * lh + 4 * t4);
+      if (mykey >= Lk) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
       kf32[4 * t4] = a.x; kf32[4 * t4 + 1] = a.y; kf32[4 * t4 + 2] = a.z; kf32[4 * t4 + 3] = a.w;
       vf32[4 * t4] = b.x; vf32[4 * t4 + 1] = b.y; vf32[4 * t4 + 2] = b.z; vf32[4 * t4 + 3] = b.w;
     }
@@ -99,14 +99,15 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
 #pragma unroll
     for (int s = 0; s < KS; s++) {
       float kv[8], vv[8];
-      if (mykey < Lk) {
-        const float4 a0 = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + 16 * s + 8 * lh);
-        const float4 a1 = *reinterpret_cast<const float4*>(kb + (long)mykey * g.ldk + 16 * s + 8 * lh + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + 16 * s + 8 * lh);
-        const float4 b1 = *reinterpret_cast<const float4*>(vb + (long)mykey * g.ldv + 16 * s + 8 * lh + 4);
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(kb + (long)mykey_c * g.ldk + 16 * s + 8 * lh);
+        const float4 a1 = *reinterpret_cast<const float4*>(kb + (long)mykey_c * g.ldk + 16 * s + 8 * lh + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(vb + (long)mykey_c * g.ldv + 16 * s + 8 * lh);
+        const float4 b1 = *reinterpret_cast<const float4*>(vb + (long)mykey_c * g.ldv + 16 * s + 8 * lh + 4);
         kv[0] = a0.x; kv[1] = a0.y; kv[2] = a0.z; kv[3] = a0.w; kv[4] = a1.x; kv[5] = a1.y; kv[6] = a1.z; kv[7] = a1.w;
         vv[0] = b0.x; vv[1] = b0.y; vv[2] = b0.z; vv[3] = b0.w; vv[4] = b1.x; vv[5] = b1.y; vv[6] = b1.z; vv[7] = b1.w;
-      } else {
+      }
+      if (mykey >= Lk) {
 #pragma unroll
         for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
       }
@@ -132,12 +133,11 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
     for (int i = tid; i < 32 * F4R; i += NTHR) {
       const int row = i / F4R, c4 = i % F4R;
       const int q = qb * 32 + row;
-      float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), df = qf, of = qf;
-      if (q < Lq) {
-        qf = *reinterpret_cast<const float4*>(qbase + (long)q * g.ldq + c4 * 4);
-        df = *reinterpret_cast<const float4*>(dobase + (long)q * g.ldo + c4 * 4);
-        of = *reinterpret_cast<const float4*>(obase + (long)q * g.ldo + c4 * 4);
-      }
+      const int qc = q < Lq ? q : Lq - 1;
+      float4 qf = *reinterpret_cast<const float4*>(qbase + (long)qc * g.ldq + c4 * 4);
+      float4 df = *reinterpret_cast<const float4*>(dobase + (long)qc * g.ldo + c4 * 4);
+      float4 of = *reinterpret_cast<const float4*>(obase + (long)qc * g.ldo + c4 * 4);
+      if (q >= Lq) { qf = make_float4(0.f, 0.f, 0.f, 0.f); df = qf; of = qf; }
       if (F32) {
         put_row4(Qs32 + row * RSQ + c4 * 4, qf);
         put_row4(Os32 + row * RSQ + c4 * 4, df);
@@ -150,8 +150,9 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       for (int o = F4R / 2; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
       if (c4 == 0) {
         delta_s[row] = dot;
-        lse_s[row] = (q < Lq) ? g.lse[(sh * Lq + q) * 2] : 0.f;
-        inv_s[row] = (q < Lq) ? g.lse[(sh * Lq + q) * 2 + 1] : 0.f;
+        const float l0 = g.lse[(sh * Lq + qc) * 2], l1 = g.lse[(sh * Lq + qc) * 2 + 1];
+        lse_s[row] = (q < Lq) ? l0 : 0.f;
+        inv_s[row] = (q < Lq) ? l1 : 0.f;
       }
     }
     __syncthreads();   // (b)

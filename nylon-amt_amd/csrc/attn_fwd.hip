@@ -54,11 +54,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
     constexpr int F4R = DH / 4;
     for (int i = tid; i < LKP * F4R; i += 256) {
       const int key = i / F4R, c4 = i % F4R;
-      float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
-      if (key < Lk) {
-        kf = *reinterpret_cast<const float4*>(kb + (long)key * g.ldk + c4 * 4);
-        vf = *reinterpret_cast<const float4*>(vb + (long)key * g.ldv + c4 * 4);
-      }
+      // unconditional loads from a clamped key + select (no branch around the loads: they all stay in flight)
+      const int kc = key < Lk ? key : Lk - 1;
+      float4 kf = *reinterpret_cast<const float4*>(kb + (long)kc * g.ldk + c4 * 4);
+      float4 vf = *reinterpret_cast<const float4*>(vb + (long)kc * g.ldv + c4 * 4);
+      if (key >= Lk) { kf = make_float4(0.f, 0.f, 0.f, 0.f); vf = kf; }
       if (F32) {
         float* kd = Ks32 + key * RSK + c4 * 4;
         kd[0] = kf.x; kd[1] = kf.y; kd[2] = kf.z; kd[3] = kf.w;

@@ -69,8 +69,10 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
       const int i = tid + 512 * j;
       const int row = i >> 3, c4 = i & 7;
       const long grow = m0 + row;
-      if (grow < g.M) areg[j] = *reinterpret_cast<const float4*>(g.A + grow * g.lda + k0 + c4 * 4);
-      else areg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // unconditional load from a clamped row + select (a branch around the load makes hipcc serialise the loads)
+      const long gr = grow < g.M ? grow : (long)g.M - 1;
+      const float4 t = *reinterpret_cast<const float4*>(g.A + gr * g.lda + k0 + c4 * 4);
+      areg[j] = grow < g.M ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int j = 0; j < Cfg::WCH; j++) {
@@ -308,12 +310,12 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as_kernel(const hftt_gemm_nt_d
 #pragma unroll
     for (int u = 0; u < APF; u++) {
       const int i = tid + 512 * u;
-      apf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < a_total) {
-        const int row = i / f4r, c4 = i - row * f4r;
-        const long grow = blk * BM_ + row;
-        if (grow < g.M) apf[u] = *reinterpret_cast<const float4*>(g.A + grow * g.lda + c4 * 4);
-      }
+      const int ic = i < a_total ? i : a_total - 1;        // clamped: loads stay unconditional
+      const int row = ic / f4r, c4 = ic - row * f4r;
+      const long grow = blk * BM_ + row;
+      const long gr = grow < g.M ? grow : (long)g.M - 1;
+      const float4 t = *reinterpret_cast<const float4*>(g.A + gr * g.lda + c4 * 4);
+      apf[u] = (i < a_total && grow < g.M) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto astore = [&](unsigned short* As) {          // registers -> bf16 -> LDS
@@ -397,11 +399,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as_kernel(const hftt_gemm_nt_d
           for (int rr = 0; rr < RB; rr++) {
             const long row = m0 + wave * RPW + rb + rr;
             tab[rr] = make_float4(0.f, 0.f, 0.f, 0.f); gat[rr] = tab[rr]; res[rr] = tab[rr];
-            if (row < g.M) {
-              if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(row % g.add_mod) * g.N + c4);
-              if (g.gate != nullptr) gat[rr] = *reinterpret_cast<const float4*>(g.gate + row * g.ldg + c4);
-              if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(row % g.res_mod) * g.ldr + c4);
-            }
+            const long rc = row < g.M ? row : (long)g.M - 1;      // clamped row: the (wave-uniform) pointer tests are the only branches
+            if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(rc % g.add_mod) * g.N + c4);
+            if (g.gate != nullptr) gat[rr] = *reinterpret_cast<const float4*>(g.gate + rc * g.ldg + c4);
+            if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(rc % g.res_mod) * g.ldr + c4);
           }
 #pragma unroll
           for (int rr = 0; rr < RB; rr++) {
@@ -550,12 +551,12 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int i = base + tid + 512 * u;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < total) {
-          const int row = i / f4r, c4 = i - row * f4r;
-          const long grow = m0 + row;
-          if (grow < g.M) v[u] = *reinterpret_cast<const float4*>(g.A + grow * g.lda + c4 * 4);
-        }
+        const int ic = i < total ? i : total - 1;          // clamped: loads stay unconditional (no branch, no early vmcnt wait)
+        const int row = ic / f4r, c4 = ic - row * f4r;
+        const long grow = m0 + row;
+        const long gr = grow < g.M ? grow : (long)g.M - 1;
+        const float4 t = *reinterpret_cast<const float4*>(g.A + gr * g.lda + c4 * 4);
+        v[u] = (i < total && grow < g.M) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -638,11 +639,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
           for (int rr = 0; rr < RB; rr++) {
             const long row = m0 + wave * RPW + rb + rr;
             tab[rr] = make_float4(0.f, 0.f, 0.f, 0.f); gat[rr] = tab[rr]; res[rr] = tab[rr];
-            if (row < g.M) {
-              if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(row % g.add_mod) * g.N + c4);
-              if (g.gate != nullptr) gat[rr] = *reinterpret_cast<const float4*>(g.gate + row * g.ldg + c4);
-              if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(row % g.res_mod) * g.ldr + c4);
-            }
+            const long rc = row < g.M ? row : (long)g.M - 1;      // clamped row: the (wave-uniform) pointer tests are the only branches
+            if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(rc % g.add_mod) * g.N + c4);
+            if (g.gate != nullptr) gat[rr] = *reinterpret_cast<const float4*>(g.gate + rc * g.ldg + c4);
+            if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(rc % g.res_mod) * g.ldr + c4);
           }
 #pragma unroll
           for (int rr = 0; rr < RB; rr++) {

@@ -7,6 +7,7 @@
 // operand, so the row-major tile IS the fragment layout: plain conflict-free ds_read_b32, no transpose needed).
 // M is split over workgroups; partial tiles go to a slab workspace and a second kernel reduces them in a fixed
 // order (bitwise reproducible; no float atomics).
+#include <stdlib.h>
 #include "hftt_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
@@ -24,7 +25,9 @@ struct TnPlan {
 
 TnPlan tn_plan(int M, int N, int K) {
   TnPlan p;
-  if (N >= 256 && K >= 256) { p.tm = 2; p.tn = 4; }
+  static int force_small = -1;
+  if (force_small < 0) { const char* e = getenv("HFTT_TN_SMALL"); force_small = (e && e[0] == '1') ? 1 : 0; }
+  if (N >= 256 && K >= 256 && !force_small) { p.tm = 2; p.tn = 4; }
   else if (N >= 128 && K >= 128) { p.tm = 1; p.tn = 2; }
   else { p.tm = 1; p.tn = 1; }
   p.tile_n = 128 * p.tm;
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   const int yc4 = tid % YF4R;
   const int ycol = n0 + yc4 * 4;
   const bool ycol_ok = ycol < g.N;    // N % 4 == 0
+  const int ycol_c = ycol_ok ? ycol : g.N - 4;
 
   auto gload = [&](int step) {
     const long mb = mbeg + (long)step * BMT;
@@ -109,8 +113,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       const int i = tid + 512 * j;
       const int row = i / YF4R;
       const long m = mb + row;
-      if (ycol_ok && m < mend) yreg[j] = *reinterpret_cast<const float4*>(g.dY + m * g.lddy + ycol);
-      else yreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // unconditional load from a clamped address + select: a branch around the load would make hipcc wait vmcnt(0) per load
+      const long mc = m < mend ? m : mend - 1;
+      const float4 t = *reinterpret_cast<const float4*>(g.dY + mc * g.lddy + ycol_c);
+      yreg[j] = (ycol_ok && m < mend) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int j = 0; j < Cfg::XL; j++) {
@@ -118,8 +124,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       const int row = i / XF4R, c4 = i % XF4R;
       const long m = mb + row;
       const int col = k0 + c4 * 4;
-      if (row < BMT && col < g.K && m < mend) xreg[j] = *reinterpret_cast<const float4*>(g.X + m * g.ldx + col);
-      else xreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const long mc = m < mend ? m : mend - 1;
+      const int cc = col < g.K ? col : g.K - 4;
+      const float4 t = *reinterpret_cast<const float4*>(g.X + mc * g.ldx + cc);
+      xreg[j] = (row < BMT && col < g.K && m < mend) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto put4 = [&](int buf, int which, int off, const float4& f) {      // which: 0 = dY tile, 1 = X tile
