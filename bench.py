@@ -85,13 +85,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch N>1 through torch.distributed.run' % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # HFTT_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses cuda:0 and the collective runs over gloo
+    share = os.environ.get('HFTT_BENCH_SHARE_GPU') == '1'
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     cfg = O.PAPER if args.config == 'paper' else O.TINY
     B = args.batch
@@ -116,6 +122,7 @@ def main():
         data.append((x, lab))
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -21,7 +21,8 @@ struct AfCfg {
   static constexpr int LKP = KT * 32;
   static constexpr int RSK = F32 ? DH + 1 : DH + 8;   // bf16: 144 B / 80 B rows, conflict-free ds_read_b128
   // bf16 tr16 reads are conflict-free when the row stride is 64 (mod 128) bytes
-  static constexpr int RSV = F32 ? DH : ((DH == 64) ? 96 : 32);
+  // (256 keys, dh 64: 144 B rows instead -- 2-way conflicts on some tr reads, but K+V then fit 74 KB = two workgroups per CU)
+  static constexpr int RSV = F32 ? DH : ((DH == 64) ? ((KT == 8) ? 72 : 96) : 32);
   static constexpr int K_ELEMS = LKP * RSK;
   static constexpr int V_ELEMS = LKP * RSV;
   static constexpr int LDS_BYTES = (K_ELEMS + V_ELEMS) * (F32 ? 4 : 2);

@@ -292,3 +292,40 @@ def test_training_train_mirror_fast_and_compat_paths(dev):
     assert (res['compat'][2] - res['fast'][2]).abs().mean().item() < 2e-5
     with pytest.raises(Exception):
         T.valid(model, batches, *crits, 1.0, 1.0, dev, True)
+
+
+def test_inference_wave_to_midi_end_to_end(dev, tmp_path):
+    """BASELINE config 5 in miniature: synthetic 16 kHz audio -> HIP log-mel -> clip windows batched through the model ->
+    posteriorgrams (vs the oracle on the same features) -> mpe2note -> MIDI file."""
+    import json as _json
+    from model.amt import AMT
+    cfg = O.TINY
+    model = util.build_model(cfg, 9)
+    util.perturb(model, 10)
+    f = tmp_path / 'model.pkl'
+    with open(f, 'wb') as fh:
+        pickle.dump(model, fh, protocol=4)
+    config = _json.loads('{"feature": {"sr": 16000, "hop_sample": 256, "mel_bins": 256, "n_bins": 256, "fft_bins": 2048, "window_length": 2048,'
+                         ' "log_offset": 1e-8, "window": "hann", "pad_mode": "constant"}, "input": {"margin_b": 32, "margin_f": 32, "num_frame": 128,'
+                         ' "min_value": -18.420681}, "midi": {"note_min": 21, "note_max": 108, "num_note": 88, "num_velocity": 128}}')
+    amt = AMT(config, str(f), batch_size=8)
+    sr, dur = 16000, 2.5
+    t = torch.arange(int(sr * dur)) / sr
+    wave = sum(0.2 * torch.sin(2 * np.pi * f0 * t) * torch.exp(-3.0 * (t - t0).clamp(min=0)) * (t >= t0)
+               for f0, t0 in ((196.0, 0.1), (246.9, 0.6), (329.6, 1.2), (440.0, 1.7)))
+    feat = amt.wave2feature(wave.unsqueeze(0), sr)
+    assert feat.shape == (1 + len(t) // 256, 256)
+    assert max_err(feat, O.logmel_dft(wave)) < 5e-3      # log domain; near-silent bins carry fp32 FFT noise
+    outs = amt.transcript(feat.numpy())
+    sd = util.sd_cpu(amt.model)
+    ref = O.transcript(feat.numpy(), lambda s: O.model_forward(sd, s, cfg), cfg, min_value=-18.420681)
+    for k, (a, b) in enumerate(zip(outs, ref)):
+        assert a.shape == b.shape == (256, 88)
+        if k % 4 != 3:
+            assert np.abs(a - b).max() < TOL_OUT, k
+    notes = amt.mpe2note(a_onset=outs[4], a_offset=outs[5], a_mpe=outs[6], a_velocity=outs[7], thred_onset=0.3, thred_offset=0.3, thred_mpe=0.3)
+    notes_ref = amt.mpe2note(a_onset=ref[4], a_offset=ref[5], a_mpe=ref[6], a_velocity=ref[7], thred_onset=0.3, thred_offset=0.3, thred_mpe=0.3)
+    assert abs(len(notes) - len(notes_ref)) <= max(2, len(notes_ref) // 50)      # untrained weights: only near-threshold frames may differ
+    mid = tmp_path / 'out.mid'
+    amt.note2midi(notes, str(mid))
+    assert mid.read_bytes()[:4] == b'MThd'
