@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  float4 yreg[Cfg::YL], xreg[Cfg::XL];
+  float4 yregA[Cfg::YL], xregA[Cfg::XL], yregB[Cfg::YL], xregB[Cfg::XL];   // two staging sets: loads run two steps ahead
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   constexpr int YF4R = TILE_N / 4;   // float4 per row
   constexpr int XF4R = TILE_K / 4;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   const bool ycol_ok = ycol < g.N;    // N % 4 == 0
   const int ycol_c = ycol_ok ? ycol : g.N - 4;
 
-  auto gload = [&](int step) {
+  auto gload = [&](int step, float4 (&yreg)[Cfg::YL], float4 (&xreg)[Cfg::XL]) {
     const long mb = mbeg + (long)step * BMT;
 #pragma unroll
     for (int j = 0; j < Cfg::YL; j++) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       *reinterpret_cast<uint2*>(base + off) = ph;
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const float4 (&yreg)[Cfg::YL], const float4 (&xreg)[Cfg::XL]) {
 #pragma unroll
     for (int j = 0; j < Cfg::YL; j++) {
       const int i = tid + 512 * j;
@@ -163,13 +163,16 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   const int frag_row = 8 * (gi >> 1) + qq;       // + 16*s + 4*half
 
   if (nsteps > 0) {
-    gload(0);
-    sstore(0);
+    gload(0, yregA, xregA);
+    sstore(0, yregA, xregA);
+    if (nsteps > 1) gload(1, yregB, xregB);
   }
   __syncthreads();
-  for (int step = 0; step < nsteps; step++) {
+  // step s computes from LDS buffer (s&1); set `cur` (stored to LDS one step ago) is refilled with step s+2, set `nxt`
+  // (holding step s+1, issued one step ago) is converted into the other LDS buffer after the MFMAs
+  auto body = [&](int step, float4 (&ycur)[Cfg::YL], float4 (&xcur)[Cfg::XL], const float4 (&ynxt)[Cfg::YL], const float4 (&xnxt)[Cfg::XL]) {
     const int buf = step & 1;
-    if (step + 1 < nsteps) gload(step + 1);
+    if (step + 2 < nsteps) gload(step + 2, ycur, xcur);
     if (F32) {
       const float* Ys = sm32 + buf * Cfg::BUF_ELEMS;
       const float* Xs = Ys + Cfg::Y_ELEMS;
@@ -210,8 +213,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
           for (int j = 0; j < TN; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
       }
     }
-    if (step + 1 < nsteps) sstore(buf ^ 1);
+    if (step + 1 < nsteps) sstore(buf ^ 1, ynxt, xnxt);
     __syncthreads();
+  };
+  for (int step = 0; step < nsteps; step += 2) {
+    body(step, yregA, xregA, yregB, xregB);
+    if (step + 1 < nsteps) body(step + 1, yregB, xregB, yregA, xregA);
   }
 
   // partial tile -> slab [split][nws][kws]
@@ -243,28 +250,51 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   }
 }
 
-__global__ void gemm_tn_reduce_kernel(const hftt_gemm_tn_desc g, const int splits, const long nws, const long kws) {
+// Slab reduce: one thread per output element, splits summed in a FIXED order (bitwise reproducible) with 8 loads in flight.
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const hftt_gemm_tn_desc g, const int splits, const long nws, const long kws,
+                                                             const int nb_main) {
   const long total = (long)g.N * g.K_out;
   const float* ws = reinterpret_cast<const float*>(g.ws);
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  const long sstride = nws * kws;
+  if ((int)blockIdx.x >= nb_main) {
+    // bias rows: one wave per output row n, lanes stride over the splits, fixed-order tree reduce
+    const int n = ((int)blockIdx.x - nb_main) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= g.N) return;
+    int sg = -1;
+    for (int s = 0; s < g.n_seg; s++)
+      if (n >= g.seg_row0[s] && n < g.seg_row0[s] + g.seg_rows[s]) sg = s;
+    if (sg < 0 || g.seg_db[sg] == nullptr) return;
+    const float* bs = ws + (long)splits * sstride;
+    float b = 0.f;
+    for (int q = lane; q < splits; q += 64) b += bs[(long)q * nws + n];
+    b = wave_sum(b);
+    if (lane == 0) {
+      float* db = g.seg_db[sg] + (n - g.seg_row0[sg]);
+      const float bv = b * g.out_scale;
+      *db = (g.beta != 0.f) ? (*db * g.beta + bv) : bv;
+    }
+    return;
+  }
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)nb_main * blockDim.x) {
     const int n = (int)(idx / g.K_out), k = (int)(idx % g.K_out);
     int sg = -1;
     for (int s = 0; s < g.n_seg; s++)
       if (n >= g.seg_row0[s] && n < g.seg_row0[s] + g.seg_rows[s]) sg = s;
     if (sg < 0) continue;
-    float acc = 0.f;
-    for (int s = 0; s < splits; s++) acc += ws[((long)s * nws + n) * kws + k];
+    const float* p = ws + (long)n * kws + k;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    int s = 0;
+    for (; s + 8 <= splits; s += 8) {
+      const float v0 = p[(long)(s + 0) * sstride], v1 = p[(long)(s + 1) * sstride], v2 = p[(long)(s + 2) * sstride], v3 = p[(long)(s + 3) * sstride];
+      const float v4 = p[(long)(s + 4) * sstride], v5 = p[(long)(s + 5) * sstride], v6 = p[(long)(s + 6) * sstride], v7 = p[(long)(s + 7) * sstride];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3; a4 += v4; a5 += v5; a6 += v6; a7 += v7;
+    }
+    for (; s < splits; s++) a0 += p[(long)s * sstride];
+    const float acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     float* dst = g.seg_dw[sg] + (long)(n - g.seg_row0[sg]) * g.K_out + k;
     const float v = acc * g.out_scale;
     *dst = (g.beta != 0.f) ? (*dst * g.beta + v) : v;
-    if (k == 0 && g.seg_db[sg] != nullptr) {
-      const float* bs = ws + (long)splits * nws * kws;
-      float b = 0.f;
-      for (int s = 0; s < splits; s++) b += bs[(long)s * nws + n];
-      float* db = g.seg_db[sg] + (n - g.seg_row0[sg]);
-      const float bv = b * g.out_scale;
-      *db = (g.beta != 0.f) ? (*db * g.beta + bv) : bv;
-    }
   }
 }
 
@@ -322,7 +352,8 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   const long total = (long)d->N * d->K_out;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, st, *d, p.splits, p.nws, p.kws);
+  const int bias_blocks = (d->N + 3) / 4;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks + bias_blocks), dim3(256), 0, st, *d, p.splits, p.nws, p.kws, blocks);
   HFTT_CHECK_LAUNCH("gemm_tn_reduce");
   return 0;
 }
