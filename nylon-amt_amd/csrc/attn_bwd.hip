@@ -72,14 +72,28 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
 
   const float* kb = g.k + (long)seq * g.k_seq_stride + head * DH;
   const float* vb = g.v + (long)seq * g.v_seq_stride + head * DH;
-  // ---- stage all of K (row-major) for the dQ product ----
-  for (int i = tid; i < LKP * F4R; i += NTHR) {
-    const int key = i / F4R, c4 = i % F4R;
-    const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
-    float4 kf = *reinterpret_cast<const float4*>(kb + (long)kc * g.ldk + c4 * 4);
-    if (key >= Lk) kf = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (F32) put_row4(Ks32 + key * RSK + c4 * 4, kf);
-    else *reinterpret_cast<uint2*>(Ks16 + key * RSK + c4 * 4) = pack4(kf);
+  // ---- stage all of K (row-major) for the dQ product: all of a thread's loads in flight, then convert + store ----
+  {
+    constexpr int KCNT = (LKP * F4R + NTHR - 1) / NTHR;
+    float4 kst[KCNT];
+#pragma unroll
+    for (int u = 0; u < KCNT; u++) {
+      const int i = tid + NTHR * u;
+      const int ic = i < LKP * F4R ? i : LKP * F4R - 1;
+      const int key = ic / F4R, c4 = ic % F4R;
+      const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
+      kst[u] = *reinterpret_cast<const float4*>(kb + (long)kc * g.ldk + c4 * 4);
+      if (key >= Lk) kst[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < KCNT; u++) {
+      const int i = tid + NTHR * u;
+      if (i < LKP * F4R) {
+        const int key = i / F4R, c4 = i % F4R;
+        if (F32) put_row4(Ks32 + key * RSK + c4 * 4, kst[u]);
+        else *reinterpret_cast<uint2*>(Ks16 + key * RSK + c4 * 4) = pack4(kst[u]);
+      }
+    }
   }
   // ---- this wave's K and V rows as B-operand fragments (B[k = dh][col = key]) ----
   const int mykey = wave * 32 + lr;
@@ -128,34 +142,56 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   const long sh = (long)seq * g.n_heads + head;
   const int nqb = (Lq + 31) / 32;
 
-  for (int qb = 0; qb < nqb; qb++) {
-    // ---- (a) stage the Q and dO blocks, delta = rowsum(dO*O), lse ----
-    for (int i = tid; i < 32 * F4R; i += NTHR) {
-      const int row = i / F4R, c4 = i % F4R;
-      const int q = qb * 32 + row;
-      const int qc = q < Lq ? q : Lq - 1;
-      float4 qf = *reinterpret_cast<const float4*>(qbase + (long)qc * g.ldq + c4 * 4);
-      float4 df = *reinterpret_cast<const float4*>(dobase + (long)qc * g.ldo + c4 * 4);
-      float4 of = *reinterpret_cast<const float4*>(obase + (long)qc * g.ldo + c4 * 4);
-      if (q >= Lq) { qf = make_float4(0.f, 0.f, 0.f, 0.f); df = qf; of = qf; }
-      if (F32) {
-        put_row4(Qs32 + row * RSQ + c4 * 4, qf);
-        put_row4(Os32 + row * RSQ + c4 * 4, df);
-      } else {
-        *reinterpret_cast<uint2*>(Qs16 + row * RSQ + c4 * 4) = pack4(qf);
-        *reinterpret_cast<uint2*>(Os16 + row * RSQ + c4 * 4) = pack4(df);
-      }
-      float dot = df.x * of.x + df.y * of.y + df.z * of.z + df.w * of.w;
+  // Q / dO / O rows (+ softmax row statistics) of the NEXT query block are fetched into registers while the current block is
+  // being processed, so their HBM latency is off the critical path
+  constexpr int QCNT = (32 * F4R + NTHR - 1) / NTHR;
+  float4 pq[QCNT], pdo[QCNT], po[QCNT];
+  float pl0[QCNT], pl1[QCNT];
+  auto qload = [&](int qb) {
 #pragma unroll
-      for (int o = F4R / 2; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
-      if (c4 == 0) {
-        delta_s[row] = dot;
-        const float l0 = g.lse[(sh * Lq + qc) * 2], l1 = g.lse[(sh * Lq + qc) * 2 + 1];
-        lse_s[row] = (q < Lq) ? l0 : 0.f;
-        inv_s[row] = (q < Lq) ? l1 : 0.f;
+    for (int u = 0; u < QCNT; u++) {
+      const int i = tid + NTHR * u;
+      const int ic = i < 32 * F4R ? i : 32 * F4R - 1;
+      const int row = ic / F4R, c4 = ic % F4R;
+      const int q = qb * 32 + row;
+      const int qc = q < Lq ? q : Lq - 1;          // clamped address + select: loads stay unconditional
+      pq[u] = *reinterpret_cast<const float4*>(qbase + (long)qc * g.ldq + c4 * 4);
+      pdo[u] = *reinterpret_cast<const float4*>(dobase + (long)qc * g.ldo + c4 * 4);
+      po[u] = *reinterpret_cast<const float4*>(obase + (long)qc * g.ldo + c4 * 4);
+      pl0[u] = g.lse[(sh * Lq + qc) * 2];
+      pl1[u] = g.lse[(sh * Lq + qc) * 2 + 1];
+      if (q >= Lq) { pq[u] = make_float4(0.f, 0.f, 0.f, 0.f); pdo[u] = pq[u]; po[u] = pq[u]; pl0[u] = 0.f; pl1[u] = 0.f; }
+    }
+  };
+  qload(0);
+
+  for (int qb = 0; qb < nqb; qb++) {
+    // ---- (a) registers -> LDS: the Q and dO blocks, delta = rowsum(dO*O), row statistics ----
+#pragma unroll
+    for (int u = 0; u < QCNT; u++) {
+      const int i = tid + NTHR * u;
+      if (i < 32 * F4R) {                           // wave-uniform (32*F4R and NTHR are multiples of 64)
+        const int row = i / F4R, c4 = i % F4R;
+        const float4 qf = pq[u], df = pdo[u], of = po[u];
+        if (F32) {
+          put_row4(Qs32 + row * RSQ + c4 * 4, qf);
+          put_row4(Os32 + row * RSQ + c4 * 4, df);
+        } else {
+          *reinterpret_cast<uint2*>(Qs16 + row * RSQ + c4 * 4) = pack4(qf);
+          *reinterpret_cast<uint2*>(Os16 + row * RSQ + c4 * 4) = pack4(df);
+        }
+        float dot = df.x * of.x + df.y * of.y + df.z * of.z + df.w * of.w;
+#pragma unroll
+        for (int o = F4R / 2; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        if (c4 == 0) {
+          delta_s[row] = dot;
+          lse_s[row] = pl0[u];
+          inv_s[row] = pl1[u];
+        }
       }
     }
     __syncthreads();   // (b)
+    if (qb + 1 < nqb) qload(qb + 1);
 
     // ---- (c) S tile and (d) dP tile: rows = queries (registers), column = this lane's key ----
     f32x16 sacc, pacc;
@@ -239,7 +275,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         for (int k4 = 0; k4 < LKP / 4; k4++)
           a4 = mfma16_f32(Ss32[(qh2 * 16 + (lane & 15)) * RSS + k4 * 4 + gi], Ks32[(k4 * 4 + gi) * RSK + ct * 16 + (lane & 15)], a4);
       } else {
-#pragma unroll
+#pragma unroll 2
         for (int ks = 0; ks < KT; ks++) {
           const bf16x8 ah = lds_read_b128(Ss16 + (qh2 * 16 + (lane & 15)) * RSS + ks * 32 + 8 * gi);
           const int krow = ks * 32 + 8 * gi + qq;

@@ -29,7 +29,7 @@ struct AfCfg {
 };
 
 template <int KT, int DH, int NPASS>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const hftt_attn_desc g) {
   using Cfg = AfCfg<KT, DH, NPASS>;
   constexpr bool F32 = Cfg::F32;
   constexpr int RSK = Cfg::RSK, RSV = Cfg::RSV, LKP = Cfg::LKP;
@@ -48,28 +48,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const hftt_attn_desc g) {
   const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
   const int Lq = g.Lq, Lk = g.Lk;
 
-  // ---- stage K and V of this (seq, head) into LDS ----
+  // ---- stage K and V of this (seq, head) into LDS: 8 + 8 x 16 B loads in flight per thread, then convert + store ----
   {
     const float* kb = g.k + (long)seq * g.k_seq_stride + head * DH;
     const float* vb = g.v + (long)seq * g.v_seq_stride + head * DH;
     constexpr int F4R = DH / 4;
-    for (int i = tid; i < LKP * F4R; i += 256) {
-      const int key = i / F4R, c4 = i % F4R;
-      // unconditional loads from a clamped key + select (no branch around the loads: they all stay in flight)
-      const int kc = key < Lk ? key : Lk - 1;
-      float4 kf = *reinterpret_cast<const float4*>(kb + (long)kc * g.ldk + c4 * 4);
-      float4 vf = *reinterpret_cast<const float4*>(vb + (long)kc * g.ldv + c4 * 4);
-      if (key >= Lk) { kf = make_float4(0.f, 0.f, 0.f, 0.f); vf = kf; }
-      if (F32) {
-        float* kd = Ks32 + key * RSK + c4 * 4;
-        kd[0] = kf.x; kd[1] = kf.y; kd[2] = kf.z; kd[3] = kf.w;
-        *reinterpret_cast<float4*>(Vs32 + key * RSV + c4 * 4) = vf;
-      } else {
-        uint2 w;
-        w.x = f2bf(kf.x) | ((unsigned)f2bf(kf.y) << 16); w.y = f2bf(kf.z) | ((unsigned)f2bf(kf.w) << 16);
-        *reinterpret_cast<uint2*>(Ks16 + key * RSK + c4 * 4) = w;
-        w.x = f2bf(vf.x) | ((unsigned)f2bf(vf.y) << 16); w.y = f2bf(vf.z) | ((unsigned)f2bf(vf.w) << 16);
-        *reinterpret_cast<uint2*>(Vs16 + key * RSV + c4 * 4) = w;
+    constexpr int TOTAL = LKP * F4R;
+    constexpr int UB = (TOTAL / 256) < 8 ? (TOTAL / 256) : 8;     // TOTAL is a multiple of 256 for every (KT, DH)
+    for (int base = 0; base < TOTAL; base += 256 * UB) {
+      float4 kf[UB], vf[UB];
+#pragma unroll
+      for (int u = 0; u < UB; u++) {
+        const int i = base + tid + 256 * u;
+        const int key = i / F4R, c4 = i % F4R;
+        const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
+        kf[u] = *reinterpret_cast<const float4*>(kb + (long)kc * g.ldk + c4 * 4);
+        vf[u] = *reinterpret_cast<const float4*>(vb + (long)kc * g.ldv + c4 * 4);
+        if (key >= Lk) { kf[u] = make_float4(0.f, 0.f, 0.f, 0.f); vf[u] = kf[u]; }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; u++) {
+        const int i = base + tid + 256 * u;
+        const int key = i / F4R, c4 = i % F4R;
+        if (F32) {
+          float* kd = Ks32 + key * RSK + c4 * 4;
+          kd[0] = kf[u].x; kd[1] = kf[u].y; kd[2] = kf[u].z; kd[3] = kf[u].w;
+          *reinterpret_cast<float4*>(Vs32 + key * RSV + c4 * 4) = vf[u];
+        } else {
+          uint2 w;
+          w.x = f2bf(kf[u].x) | ((unsigned)f2bf(kf[u].y) << 16); w.y = f2bf(kf[u].z) | ((unsigned)f2bf(kf[u].w) << 16);
+          *reinterpret_cast<uint2*>(Ks16 + key * RSK + c4 * 4) = w;
+          w.x = f2bf(vf[u].x) | ((unsigned)f2bf(vf[u].y) << 16); w.y = f2bf(vf[u].z) | ((unsigned)f2bf(vf[u].w) << 16);
+          *reinterpret_cast<uint2*>(Vs16 + key * RSV + c4 * 4) = w;
+        }
       }
     }
   }
