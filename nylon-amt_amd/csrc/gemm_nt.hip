@@ -6,6 +6,7 @@
 //                         plane; v_mfma_f32_32x32x16_bf16; LDS rows padded to 80 B (conflict-free ds_read_b128).
 //   npass == 3 ("parity"): operands stay fp32 in LDS (rows of 33 floats: conflict-free ds_read_b32), weights come as a
 //                         prepared fp32 matrix; v_mfma_f32_32x32x2_f32 = exact fp32 FMA chains (<= 1e-3 parity mode).
+#include <stdlib.h>
 #include "hftt_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 // A is read once per GEMM regardless of N.
 // ------------------------------------------------------------------------------------------------------------------
 template <int APF, bool DBUF>
-__global__ __launch_bounds__(512, 4) void gemm_nt_as_kernel(const hftt_gemm_nt_desc g) {
+__global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const hftt_gemm_nt_desc g) {
   constexpr int BM_ = 32;
   constexpr int BN = 256;
   constexpr int RSW = 40;                          // W tile row stride (bf16): 80 B
@@ -760,8 +761,11 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
       if (d.N == 256) return launch_nt_as1<64, 1>(d, st);
       return launch_nt_as1<32, 2>(d, st);
     }
-    if (d.K <= 512) return launch_nt_as<8, false>(d, st);     // persistent form: 33 KB + 40 KB, 2 workgroups / CU
-    return launch_nt_as<12, false>(d, st);
+    // measured at M = 262144 (us): K=512,N=256: persistent 450 | one-shot BM=64 486;  K=768,N=256: one-shot BM=64 504 |
+    // one-shot BM=32 713 | persistent double-buffered 744 | persistent 928
+    if (d.K > 512 && d.N == 256) return launch_nt_as1<64, 1>(d, st);
+    if (d.K <= 512) return launch_nt_as<8, false>(d, st);
+    return launch_nt_as<12, true>(d, st);
   }
   return dispatch_nt<false>(d, st);      // small / ragged shapes: the k-tiled streaming kernel
 }

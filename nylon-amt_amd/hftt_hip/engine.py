@@ -302,7 +302,7 @@ class HfttEngine:
             if K <= 256:
                 kname = 'gemm_nt_as1_kernel<%s>' % ('64, 0' if not rich else ('64, 1' if N == 256 else '32, 2'))
             else:
-                kname = 'gemm_nt_as_kernel<%s>' % ('8, false' if K <= 512 else '12, false')
+                kname = 'gemm_nt_as_kernel<8, false>' if K <= 512 else ('gemm_nt_as1_kernel<64, 1>' if N == 256 else 'gemm_nt_as_kernel<12, true>')
         else:
             kname = 'gemm_nt_kernel<%d, %s, %s>' % (bn, 'true' if self.npass == 3 else 'false', 'true' if ln is not None else 'false')
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}

@@ -50,6 +50,8 @@ for npass in (1,):
     timeit('nt o+res+LN      N=256 K=256', lambda: ops.gemm_nt(x, W256, b256, npass=npass, planes=P256, residual=y, ln=(gam, bet)), 4 * Se * 256 * 4, 2.0 * Se * 256 * 256)
     timeit('nt f1 relu drop  N=512 K=256', lambda: ops.gemm_nt(x, W512, b512, npass=npass, planes=P512, act=1, drop_p=0.1, drop_site=1, drop_seed=5), 4 * Se * (256 + 512), 2.0 * Se * 512 * 256)
     timeit('nt f2+res+LN     N=256 K=512', lambda: ops.gemm_nt(h, W2, b256, npass=npass, planes=P2, residual=y, ln=(gam, bet)), 4 * Se * (512 + 768), 2.0 * Se * 256 * 512)
+    W3 = torch.randn(256, 768, device=dev) / 27; P3 = ops.prepare_weight(W3, npass); g3 = torch.randn(Se, 768, device=dev)
+    timeit('nt dX qkv_t+res  N=256 K=768', lambda: ops.gemm_nt(g3, W3, None, npass=npass, planes=P3, residual=y), 4 * Se * (768 + 512), 2.0 * Se * 256 * 768)
     timeit('tn dW   M=262144 N=256 K=256', lambda: ops.gemm_tn(x, y, npass=npass), 4 * Se * 512, 2.0 * Se * 256 * 256)
     timeit('tn dW   M=262144 N=512 K=256', lambda: ops.gemm_tn(h, y, npass=npass), 4 * Se * 768, 2.0 * Se * 512 * 256)
     qkv = torch.randn(1024, 256, 768, device=dev)
