@@ -63,6 +63,20 @@ def cpu_baseline(cfg, threads):
                       '(%.1f s) with the pure-PyTorch CPU oracle' % times[-1]}
 
 
+def pmc_traffic_bytes(kernel_key):
+    """HBM bytes per launch of `kernel_key` from the newest committed PMC summary (profiles/*_bench_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, FETCH_SIZE doubled for gfx950), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench_pmc_traffic.json')))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))['kernels'].get(kernel_key)
+        return None if k is None else (k['fetch_MB_per_launch_x2_corrected'] + k['write_MB_per_launch']) * 1e6
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -154,7 +168,10 @@ def main():
         if prof is not None:
             summ = prof.summary()
             total_ms = sum(v['ms'] for v in summ.values())
-            key, dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
+            # dominant kernel among the calls that launch exactly one kernel (hftt_gemm_tn launches its split kernel plus a
+            # slab reduce, so its event interval is not one kernel's duration and would not match rocprofv3's per-kernel average)
+            single = {k: v for k, v in summ.items() if not k.startswith('gemm_tn') and v['flops'] > 0}
+            key, dom = max(single.items(), key=lambda kv: kv[1]['ms'])
             avg_ms = dom['ms'] / dom['launches']
             ai = dom['flops'] / max(dom['bytes'], 1.0)
             peak_tf = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
@@ -165,6 +182,7 @@ def main():
             else:
                 ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['bytes'] > 0 else 0.0
                 roof = {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None}
+            roof['traffic'] = pmc_traffic_bytes(key)
             roof.update({'kernel': key, 'launches_per_step': dom['launches'] / args.steps, 'avg_launch_ms': avg_ms,
                          'share_of_step_device_time': dom['ms'] / max(total_ms, 1e-9),
                          'algorithmic_flops_per_launch': dom['flops'] / dom['launches'], 'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
