@@ -9,7 +9,9 @@
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no allocation, no sync:
  *     the caller owns all buffers, including workspaces sized by the *_ws_bytes helpers;
  *   - return value 0 = ok, non-zero = error (message via hftt_last_error(), thread-local);
- *   - all activations / gradients are fp32 row-major in HBM; `npass` selects the MFMA arithmetic:
+ *   - activations / gradients are fp32 row-major in HBM; in the bf16 mode (npass 1) tensors that are consumed ONLY as MFMA
+ *     operands may be stored as bf16 (`io_flags` of each descriptor; leading dimensions and strides then count bf16
+ *     elements) -- numerically identical to rounding at load time, half the traffic.  `npass` selects the MFMA arithmetic:
  *       1 = operands rounded to bf16, fp32 accumulate (v_mfma_f32_32x32x16_bf16): the "bf16" throughput mode,
  *       3 = exact fp32 products and accumulation (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate): the <=1e-3
  *           parity mode.  (A 3-pass split-bf16 scheme was measured first: its ~1e-5 relative error is not enough
@@ -22,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HFTT_ABI_VERSION 1
+#define HFTT_ABI_VERSION 2
 
 int hftt_abi_version(void);
 const char* hftt_last_error(void);
@@ -65,11 +67,15 @@ int hftt_prep_weights(const float* params, uint16_t* wbf, float* wf32, float* fd
  * W is the prepared matrix [N_pad, K] (K % 32 == 0, N_pad % 64 == 0, rows >= N zero): bf16 when npass == 1,
  * fp32 when npass == 3 (passed through the same pointer).
  * --------------------------------------------------------------------------------------------- */
+#define HFTT_NT_A_BF16 1u
+#define HFTT_NT_C_BF16 2u      /* not with LayerNorm */
+#define HFTT_NT_GATE_BF16 4u
 typedef struct {
   int32_t M, N, K, npass;
   const float* A; int64_t lda;
   const void* W;                                  /* [N_pad, K] bf16 (npass 1) or fp32 (npass 3) */
-  const void* reserved0;
+  uint32_t io_flags;                              /* HFTT_NT_* (npass 1 only): A / C / gate stored as bf16 */
+  uint32_t debug;
   const float* bias;                              /* [N] or NULL */
   float* C; int64_t ldc;
   int32_t act; float out_scale;
@@ -87,6 +93,8 @@ int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream);
  * Two launches: partial products per M-split into `ws`, then a reduce that writes (beta=0) or
  * accumulates (beta=1) into up to 4 row segments of the destination (fused QKV / packed heads).
  * --------------------------------------------------------------------------------------------- */
+#define HFTT_TN_DY_BF16 1u
+#define HFTT_TN_X_BF16 2u
 typedef struct {
   int32_t M, N, K, npass;
   const float* dY; int64_t lddy;
@@ -97,7 +105,7 @@ typedef struct {
   float* seg_dw[4];          /* [seg_rows, K] row-major (ld = K_out) */
   float* seg_db[4];          /* [seg_rows] or NULL */
   int32_t K_out;             /* number of K columns to write (<= K), destination leading dim */
-  int32_t pad;
+  uint32_t io_flags;         /* HFTT_TN_* (npass 1 only) */
   void* ws; int64_t ws_bytes;
 } hftt_gemm_tn_desc;
 int64_t hftt_gemm_tn_ws_bytes(int32_t M, int32_t N, int32_t K);
@@ -110,6 +118,11 @@ int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream);
  * backward: recomputes P from (Q,K,lse); dQ,dK,dV      -- autograd of the same lines
  * Q/K/V/out element (seq, row, head, c) lives at  base + seq*seq_stride + row*ld + head*dh + c.
  * --------------------------------------------------------------------------------------------- */
+#define HFTT_ATTN_Q_BF16 1u       /* q */
+#define HFTT_ATTN_KV_BF16 2u      /* k, v */
+#define HFTT_ATTN_O_BF16 4u       /* out, dout */
+#define HFTT_ATTN_DQ_BF16 8u      /* dq */
+#define HFTT_ATTN_DKV_BF16 16u    /* dk, dv */
 typedef struct {
   int32_t n_seq, n_heads, Lq, Lk, dh, npass;
   const float* q; int64_t q_seq_stride; int64_t ldq;
@@ -124,6 +137,8 @@ typedef struct {
   float* dq; int64_t dq_seq_stride; int64_t lddq;
   float* dk; int64_t dk_seq_stride; int64_t lddk;
   float* dv; int64_t dv_seq_stride; int64_t lddv;
+  uint32_t io_flags;          /* HFTT_ATTN_* (npass 1 only) */
+  uint32_t pad;
 } hftt_attn_desc;
 int hftt_attn_fwd(const hftt_attn_desc* d, void* stream);
 int hftt_attn_bwd(const hftt_attn_desc* d, void* stream);
@@ -166,6 +181,8 @@ typedef struct {
   float* dr; float* dr_drop;
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   float* ws;            /* [n_wg, 2, N] partial sums; n_wg = hftt_ln_bwd_wgs(M) */
+  uint32_t drop_bf16;   /* dr_drop is stored as bf16 */
+  uint32_t pad;
 } hftt_ln_bwd_desc;
 int32_t hftt_ln_bwd_wgs(int32_t M);
 int hftt_ln_bwd(const hftt_ln_bwd_desc* d, void* stream);

@@ -70,8 +70,12 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   };
   auto put_row4 = [&](float* dst, const float4& f) { dst[0] = f.x; dst[1] = f.y; dst[2] = f.z; dst[3] = f.w; };
 
-  const float* kb = g.k + (long)seq * g.k_seq_stride + head * DH;
-  const float* vb = g.v + (long)seq * g.v_seq_stride + head * DH;
+  const bool q_bf = !F32 && (g.io_flags & HFTT_ATTN_Q_BF16), kv_bf = !F32 && (g.io_flags & HFTT_ATTN_KV_BF16), o_bf = !F32 && (g.io_flags & HFTT_ATTN_O_BF16);
+  const bool dq_bf = !F32 && (g.io_flags & HFTT_ATTN_DQ_BF16), dkv_bf = !F32 && (g.io_flags & HFTT_ATTN_DKV_BF16);
+  const long kofs = (long)seq * g.k_seq_stride + head * DH;      // element offsets (tensors may be fp32 or bf16)
+  const long vofs = (long)seq * g.v_seq_stride + head * DH;
+  const float* kb = g.k + kofs;                                  // pointer forms: fp32 (parity) path only
+  const float* vb = g.v + vofs;
   // ---- stage all of K (row-major) for the dQ product: all of a thread's loads in flight, then convert + store ----
   {
     constexpr int KCNT = (LKP * F4R + NTHR - 1) / NTHR;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       const int ic = i < LKP * F4R ? i : LKP * F4R - 1;
       const int key = ic / F4R, c4 = ic % F4R;
       const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
-      kst[u] = *reinterpret_cast<const float4*>(kb + (long)kc * g.ldk + c4 * 4);
+      kst[u] = hftt_load4(g.k, kv_bf, kofs + (long)kc * g.ldk + c4 * 4);
       if (key >= Lk) kst[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -114,10 +118,10 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
     for (int s = 0; s < KS; s++) {
       float kv[8], vv[8];
       {
-        const float4 a0 = *reinterpret_cast<const float4*>(kb + (long)mykey_c * g.ldk + 16 * s + 8 * lh);
-        const float4 a1 = *reinterpret_cast<const float4*>(kb + (long)mykey_c * g.ldk + 16 * s + 8 * lh + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(vb + (long)mykey_c * g.ldv + 16 * s + 8 * lh);
-        const float4 b1 = *reinterpret_cast<const float4*>(vb + (long)mykey_c * g.ldv + 16 * s + 8 * lh + 4);
+        const float4 a0 = hftt_load4(g.k, kv_bf, kofs + (long)mykey_c * g.ldk + 16 * s + 8 * lh);
+        const float4 a1 = hftt_load4(g.k, kv_bf, kofs + (long)mykey_c * g.ldk + 16 * s + 8 * lh + 4);
+        const float4 b0 = hftt_load4(g.v, kv_bf, vofs + (long)mykey_c * g.ldv + 16 * s + 8 * lh);
+        const float4 b1 = hftt_load4(g.v, kv_bf, vofs + (long)mykey_c * g.ldv + 16 * s + 8 * lh + 4);
         kv[0] = a0.x; kv[1] = a0.y; kv[2] = a0.z; kv[3] = a0.w; kv[4] = a1.x; kv[5] = a1.y; kv[6] = a1.z; kv[7] = a1.w;
         vv[0] = b0.x; vv[1] = b0.y; vv[2] = b0.z; vv[3] = b0.w; vv[4] = b1.x; vv[5] = b1.y; vv[6] = b1.z; vv[7] = b1.w;
       }
@@ -135,10 +139,9 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
 #pragma unroll
     for (int r = 0; r < 16; r++) { dKT[n][r] = 0.f; dVT[n][r] = 0.f; }
 
-  const float* qbase = g.q + (long)seq * g.q_seq_stride + head * DH;
-  const float* obase = g.out + (long)seq * g.o_seq_stride + head * DH;
-  const float* dobase = g.dout + (long)seq * g.o_seq_stride + head * DH;
-  float* dqbase = g.dq + (long)seq * g.dq_seq_stride + head * DH;
+  const long qofs = (long)seq * g.q_seq_stride + head * DH;
+  const long oofs = (long)seq * g.o_seq_stride + head * DH;
+  const long dqofs = (long)seq * g.dq_seq_stride + head * DH;
   const long sh = (long)seq * g.n_heads + head;
   const int nqb = (Lq + 31) / 32;
 
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       const int row = ic / F4R, c4 = ic % F4R;
       const int q = qb * 32 + row;
       const int qc = q < Lq ? q : Lq - 1;          // clamped address + select: loads stay unconditional
-      pq[u] = *reinterpret_cast<const float4*>(qbase + (long)qc * g.ldq + c4 * 4);
-      pdo[u] = *reinterpret_cast<const float4*>(dobase + (long)qc * g.ldo + c4 * 4);
-      po[u] = *reinterpret_cast<const float4*>(obase + (long)qc * g.ldo + c4 * 4);
+      pq[u] = hftt_load4(g.q, q_bf, qofs + (long)qc * g.ldq + c4 * 4);
+      pdo[u] = hftt_load4(g.dout, o_bf, oofs + (long)qc * g.ldo + c4 * 4);
+      po[u] = hftt_load4(g.out, o_bf, oofs + (long)qc * g.ldo + c4 * 4);
       pl0[u] = g.lse[(sh * Lq + qc) * 2];
       pl1[u] = g.lse[(sh * Lq + qc) * 2 + 1];
       if (q >= Lq) { pq[u] = make_float4(0.f, 0.f, 0.f, 0.f); pdo[u] = pq[u]; po[u] = pq[u]; pl0[u] = 0.f; pl1[u] = 0.f; }
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int q = qb * 32 + qh2 * 16 + gi * 4 + r;
-        if (q < Lq) dqbase[(long)q * g.lddq + ct * 16 + (lane & 15)] = a4[r];
+        if (q < Lq) hftt_store1(g.dq, dq_bf, dqofs + (long)q * g.lddq + ct * 16 + (lane & 15), a4[r]);
       }
     }
     // no barrier needed here: the next iteration's staging touches only Qs/Os/lse/delta, which no wave reads in (i);
@@ -296,15 +299,15 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
 
   // ---- epilogue: dK, dV (this wave's 32 keys) ----
   if (mykey < Lk) {
-    float* dkb = g.dk + (long)seq * g.dk_seq_stride + (long)mykey * g.lddk + head * DH;
-    float* dvb = g.dv + (long)seq * g.dv_seq_stride + (long)mykey * g.lddv + head * DH;
+    const long dkofs = (long)seq * g.dk_seq_stride + (long)mykey * g.lddk + head * DH;
+    const long dvofs = (long)seq * g.dv_seq_stride + (long)mykey * g.lddv + head * DH;
 #pragma unroll
     for (int n = 0; n < NT; n++)
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const int dh0 = n * 32 + 8 * c + 4 * lh;
-        *reinterpret_cast<float4*>(dkb + dh0) = make_float4(dKT[n][4 * c], dKT[n][4 * c + 1], dKT[n][4 * c + 2], dKT[n][4 * c + 3]);
-        *reinterpret_cast<float4*>(dvb + dh0) = make_float4(dVT[n][4 * c], dVT[n][4 * c + 1], dVT[n][4 * c + 2], dVT[n][4 * c + 3]);
+        hftt_store4(g.dk, dkv_bf, dkofs + dh0, dKT[n][4 * c], dKT[n][4 * c + 1], dKT[n][4 * c + 2], dKT[n][4 * c + 3]);
+        hftt_store4(g.dv, dkv_bf, dvofs + dh0, dVT[n][4 * c], dVT[n][4 * c + 1], dVT[n][4 * c + 2], dVT[n][4 * c + 3]);
       }
   }
 }

@@ -29,7 +29,7 @@ struct AfCfg {
 };
 
 template <int KT, int DH, int NPASS>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const hftt_attn_desc g) {
+__global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(const hftt_attn_desc g) {
   using Cfg = AfCfg<KT, DH, NPASS>;
   constexpr bool F32 = Cfg::F32;
   constexpr int RSK = Cfg::RSK, RSV = Cfg::RSV, LKP = Cfg::LKP;
@@ -47,11 +47,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const hftt_attn_desc g
   const int gi = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
   const int Lq = g.Lq, Lk = g.Lk;
+  const bool q_bf = !F32 && (g.io_flags & HFTT_ATTN_Q_BF16), kv_bf = !F32 && (g.io_flags & HFTT_ATTN_KV_BF16), o_bf = !F32 && (g.io_flags & HFTT_ATTN_O_BF16);
 
   // ---- stage K and V of this (seq, head) into LDS: 8 + 8 x 16 B loads in flight per thread, then convert + store ----
   {
-    const float* kb = g.k + (long)seq * g.k_seq_stride + head * DH;
-    const float* vb = g.v + (long)seq * g.v_seq_stride + head * DH;
+    const long kofs = (long)seq * g.k_seq_stride + head * DH;      // element offsets (the tensors may be fp32 or bf16)
+    const long vofs = (long)seq * g.v_seq_stride + head * DH;
     constexpr int F4R = DH / 4;
     constexpr int TOTAL = LKP * F4R;
     constexpr int UB = (TOTAL / 256) < 8 ? (TOTAL / 256) : 8;     // TOTAL is a multiple of 256 for every (KT, DH)
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const hftt_attn_desc g
         const int i = base + tid + 256 * u;
         const int key = i / F4R, c4 = i % F4R;
         const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
-        kf[u] = *reinterpret_cast<const float4*>(kb + (long)kc * g.ldk + c4 * 4);
-        vf[u] = *reinterpret_cast<const float4*>(vb + (long)kc * g.ldv + c4 * 4);
+        kf[u] = hftt_load4(g.k, kv_bf, kofs + (long)kc * g.ldk + c4 * 4);
+        vf[u] = hftt_load4(g.v, kv_bf, vofs + (long)kc * g.ldv + c4 * 4);
         if (key >= Lk) { kf[u] = make_float4(0.f, 0.f, 0.f, 0.f); vf[u] = kf[u]; }
       }
 #pragma unroll
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const hftt_attn_desc g
   for (int qb = wave; qb < nqb; qb += 4) {
     const int qrow = qb * 32 + lr;                     // this lane's query (as the B-operand column)
     const int qrow_c = qrow < Lq ? qrow : Lq - 1;
-    const float* qp = g.q + (long)seq * g.q_seq_stride + (long)qrow_c * g.ldq + head * DH;
+    const long qofs = (long)seq * g.q_seq_stride + (long)qrow_c * g.ldq + head * DH;
+    const float* qp = g.q + qofs;                      // valid as a pointer only when q is fp32
     // ---- S^T = K . Q^T  (rows = keys in registers, column = this lane's query) ----
     f32x16 sacc[KT];
 #pragma unroll
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const hftt_attn_desc g
       bf16x8 qh[KS];
 #pragma unroll
       for (int s = 0; s < KS; s++) {
-        const float4 f0 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * lh);
-        const float4 f1 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * lh + 4);
+        const float4 f0 = hftt_load4(g.q, q_bf, qofs + 16 * s + 8 * lh);
+        const float4 f1 = hftt_load4(g.q, q_bf, qofs + 16 * s + 8 * lh + 4);
         const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
         for (int e = 0; e < 8; e++) qh[s][e] = (short)f2bf(v[e] * scale);
@@ -218,13 +220,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const hftt_attn_desc g
         }
       }
     }
-    float* ob = g.out + (long)seq * g.o_seq_stride + head * DH;
+    const long oofs = (long)seq * g.o_seq_stride + head * DH;
 #pragma unroll
     for (int n = 0; n < NT; n++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int q = qb * 32 + acc_row32(r, lh);
-        if (q < Lq) ob[(long)q * g.ldo + n * 32 + lr] = oacc[n][r];
+        if (q < Lq) hftt_store1(g.out, o_bf, oofs + (long)q * g.ldo + n * 32 + lr, oacc[n][r]);
       }
   }
 }

@@ -165,12 +165,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
     }
     if (VPL == 4) {
       *reinterpret_cast<float4*>(g.dr + base) = make_float4(o[0], o[1 % VPL], o[2 % VPL], o[3 % VPL]);
-      if (g.dr_drop != nullptr) *reinterpret_cast<float4*>(g.dr_drop + base) = make_float4(od[0], od[1 % VPL], od[2 % VPL], od[3 % VPL]);
+      if (g.dr_drop != nullptr) {
+        if (g.drop_bf16) {
+          uint2 u;
+          u.x = f2bf(od[0]) | ((unsigned)f2bf(od[1 % VPL]) << 16); u.y = f2bf(od[2 % VPL]) | ((unsigned)f2bf(od[3 % VPL]) << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.dr_drop) + base) = u;
+        } else {
+          *reinterpret_cast<float4*>(g.dr_drop + base) = make_float4(od[0], od[1 % VPL], od[2 % VPL], od[3 % VPL]);
+        }
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < VPL; e++) {
         g.dr[base + e] = o[e];
-        if (g.dr_drop != nullptr) g.dr_drop[base + e] = od[e];
+        if (g.dr_drop != nullptr) {
+          if (g.drop_bf16) reinterpret_cast<unsigned short*>(g.dr_drop)[base + e] = f2bf(od[e]);
+          else g.dr_drop[base + e] = od[e];
+        }
       }
     }
   }

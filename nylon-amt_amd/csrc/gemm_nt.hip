@@ -13,6 +13,25 @@
 
 namespace {
 
+// gate value > 0 for an fp32 or a bf16 gate tensor (4 consecutive elements at element offset `off`)
+__device__ __forceinline__ float4 load_gate4(const float* gate, bool bf, long off) {
+  if (bf) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(gate) + off);
+    return make_float4(bf2f(u.x & 0xFFFFu), bf2f(u.x >> 16), bf2f(u.y & 0xFFFFu), bf2f(u.y >> 16));
+  }
+  return *reinterpret_cast<const float4*>(gate + off);
+}
+// store 4 consecutive outputs as fp32 (16 B) or bf16 (8 B)
+__device__ __forceinline__ void store_c4(float* C, bool bf, long off, float a, float b, float c, float d) {
+  if (bf) {
+    uint2 u;
+    u.x = f2bf(a) | ((unsigned)f2bf(b) << 16); u.y = f2bf(c) | ((unsigned)f2bf(d) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(C) + off) = u;
+  } else {
+    *reinterpret_cast<float4*>(C + off) = make_float4(a, b, c, d);
+  }
+}
+
 constexpr int BM = 128;
 constexpr int BK = 32;
 
@@ -57,6 +76,10 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   float4 areg[2];
+  uint4 abreg = make_uint4(0u, 0u, 0u, 0u);        // A tile chunk when A is stored as bf16 (16 B = 8 elements per thread)
+  const bool a_bf = !F32 && (g.io_flags & HFTT_NT_A_BF16);
+  const bool c_bf = !F32 && (g.io_flags & HFTT_NT_C_BF16);
+  const bool gate_bf = !F32 && (g.io_flags & HFTT_NT_GATE_BF16);
   uint4 wreg[Cfg::WCH];
 #pragma unroll
   for (int j = 0; j < Cfg::WCH; j++) wreg[j] = make_uint4(0u, 0u, 0u, 0u);
@@ -65,6 +88,13 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
+    if (a_bf) {
+      const int row = tid >> 2, ch = tid & 3;
+      const long grow = m0 + row;
+      const long gr = grow < g.M ? grow : (long)g.M - 1;
+      const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.A) + gr * g.lda + k0 + ch * 8);
+      abreg = grow < g.M ? t : make_uint4(0u, 0u, 0u, 0u);
+    } else
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int i = tid + 512 * j;
@@ -115,6 +145,9 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
     } else {
       unsigned short* As = sm16 + buf * Cfg::BUF_ELEMS;
       unsigned short* Ws = As + Cfg::A_ELEMS;
+      if (a_bf) {
+        *reinterpret_cast<uint4*>(As + (tid >> 2) * RS + (tid & 3) * 8) = abreg;
+      } else
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int i = tid + 512 * j;
@@ -200,14 +233,18 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
         v *= g.out_scale;
         if (ok) {
           if (g.add_table != nullptr) v += g.add_table[(long)(row % g.add_mod) * g.N + col];
-          if (g.gate != nullptr) v = (g.gate[row * g.ldg + col] > 0.f) ? v * g.gate_scale : 0.f;
+          if (g.gate != nullptr) {
+            const float gv = gate_bf ? bf2f(reinterpret_cast<const unsigned short*>(g.gate)[row * g.ldg + col]) : g.gate[row * g.ldg + col];
+            v = (gv > 0.f) ? v * g.gate_scale : 0.f;
+          }
           if (g.drop_p > 0.f) v = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)row * g.N + col, thr) ? v * inv_keep : 0.f;
           if (g.residual != nullptr) v += g.residual[(long)(row % g.res_mod) * g.ldr + col];
         }
         if (LN) {
           stage[row_l * Cfg::STAGE_LD + col_l] = v;
         } else if (ok) {
-          g.C[row * g.ldc + col] = v;
+          if (c_bf) reinterpret_cast<unsigned short*>(g.C)[row * g.ldc + col] = f2bf(v);
+          else g.C[row * g.ldc + col] = v;
         }
       }
     }
@@ -259,7 +296,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 //     layout were measured at 2.8 TB/s; the staged float4 form reaches > 4 TB/s.)
 // A is read once per GEMM regardless of N.
 // ------------------------------------------------------------------------------------------------------------------
-template <int APF, bool DBUF>
+template <int APF, bool DBUF, bool ABF>
 __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const hftt_gemm_nt_desc g) {
   constexpr int BM_ = 32;
   constexpr int BN = 256;
@@ -306,8 +343,25 @@ __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const h
       *reinterpret_cast<uint4*>(Ws + buf * W_ELEMS + row * RSW + ch * 8) = wreg[j];
     }
   };
+  constexpr bool a_bf = ABF;                       // A stored as bf16: APF counts 16-byte chunks either way
+  const bool c_bf = g.io_flags & HFTT_NT_C_BF16, gate_bf = g.io_flags & HFTT_NT_GATE_BF16;
+  const int c8r = K >> 3;                          // 16-byte chunks per row when A is stored as bf16
+  const int a_total8 = BM_ * c8r;
   float4 apf[APF];
   auto aload = [&](long blk) {                     // HBM -> registers (APF x 16 B in flight per thread)
+    if (a_bf) {
+#pragma unroll
+      for (int u = 0; u < APF; u++) {
+        const int i = tid + 512 * u;
+        const int ic = i < a_total8 ? i : a_total8 - 1;
+        const int row = ic / c8r, c8 = ic - row * c8r;
+        const long grow = blk * BM_ + row;
+        const long gr = grow < g.M ? grow : (long)g.M - 1;
+        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(g.A) + gr * g.lda + c8 * 8);
+        apf[u] = (i < a_total8 && grow < g.M) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < APF; u++) {
       const int i = tid + 512 * u;
@@ -320,6 +374,17 @@ __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const h
     }
   };
   auto astore = [&](unsigned short* As) {          // registers -> bf16 -> LDS
+    if (a_bf) {
+#pragma unroll
+      for (int u = 0; u < APF; u++) {
+        const int i = tid + 512 * u;
+        if (i < a_total8) {
+          const int row = i / c8r, c8 = i - row * c8r;
+          *reinterpret_cast<float4*>(As + row * RSA + c8 * 8) = apf[u];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < APF; u++) {
       const int i = tid + 512 * u;
@@ -402,7 +467,7 @@ __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const h
             tab[rr] = make_float4(0.f, 0.f, 0.f, 0.f); gat[rr] = tab[rr]; res[rr] = tab[rr];
             const long rc = row < g.M ? row : (long)g.M - 1;      // clamped row: the (wave-uniform) pointer tests are the only branches
             if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(rc % g.add_mod) * g.N + c4);
-            if (g.gate != nullptr) gat[rr] = *reinterpret_cast<const float4*>(g.gate + rc * g.ldg + c4);
+            if (g.gate != nullptr) gat[rr] = load_gate4(g.gate, gate_bf, rc * g.ldg + c4);
             if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(rc % g.res_mod) * g.ldr + c4);
           }
 #pragma unroll
@@ -436,7 +501,7 @@ __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const h
                   if (g.ln_rstd != nullptr) g.ln_rstd[row] = rstd;
                 }
               }
-              *reinterpret_cast<float4*>(g.C + row * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+              store_c4(g.C, c_bf, row * g.ldc + c4, v[0], v[1], v[2], v[3]);
             }
           }
           }
@@ -462,13 +527,13 @@ __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const h
   }
 }
 
-template <int APF, bool DBUF>
+template <int APF, bool DBUF, bool ABF>
 int launch_nt_as(const hftt_gemm_nt_desc& d, hipStream_t st) {
   const int lds = ((DBUF ? 2 : 1) * 32 * (d.K + 8) + 2 * 256 * 40) * 2;
   if (lds > 160 * 1024) { hftt_set_error("gemm_nt: K=%d too large for the A-stationary tile (%d B LDS)", d.K, lds); return 1; }
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_as_kernel<APF, DBUF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_as_kernel<APF, DBUF, ABF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { hftt_set_error("gemm_nt: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e)); return 2; }
     attr_lds = lds;
@@ -484,7 +549,7 @@ int launch_nt_as(const hftt_gemm_nt_desc& d, hipStream_t st) {
   const int per_cu = (lds <= 80 * 1024) ? 2 : 1;
   long grid = (long)n_cu * per_cu;
   if (grid > nblk) grid = nblk;
-  hipLaunchKernelGGL((gemm_nt_as_kernel<APF, DBUF>), dim3((unsigned)grid), dim3(512), lds, st, d);
+  hipLaunchKernelGGL((gemm_nt_as_kernel<APF, DBUF, ABF>), dim3((unsigned)grid), dim3(512), lds, st, d);
   HFTT_CHECK_LAUNCH("gemm_nt");
   return 0;
 }
@@ -544,7 +609,32 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
     }
   };
   wload(0);
-  {
+  const bool a_bf = g.io_flags & HFTT_NT_A_BF16, c_bf = g.io_flags & HFTT_NT_C_BF16, gate_bf = g.io_flags & HFTT_NT_GATE_BF16;
+  if (a_bf) {                                      // A stored as bf16: 16-byte chunks straight into LDS
+    const int c8r = K >> 3;
+    const int total = BM_ * c8r;
+    for (int base = 0; base < total; base += 512 * 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = base + tid + 512 * u;
+        const int ic = i < total ? i : total - 1;
+        const int row = ic / c8r, c8 = ic - row * c8r;
+        const long grow = m0 + row;
+        const long gr = grow < g.M ? grow : (long)g.M - 1;
+        const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.A) + gr * g.lda + c8 * 8);
+        v[u] = (i < total && grow < g.M) ? t : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = base + tid + 512 * u;
+        if (i < total) {
+          const int row = i / c8r, c8 = i - row * c8r;
+          *reinterpret_cast<uint4*>(As + row * RSA + c8 * 8) = v[u];
+        }
+      }
+    }
+  } else {
     const int f4r = K >> 2;
     const int total = BM_ * f4r;
     for (int base = 0; base < total; base += 512 * 8) {
@@ -642,7 +732,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
             tab[rr] = make_float4(0.f, 0.f, 0.f, 0.f); gat[rr] = tab[rr]; res[rr] = tab[rr];
             const long rc = row < g.M ? row : (long)g.M - 1;      // clamped row: the (wave-uniform) pointer tests are the only branches
             if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(rc % g.add_mod) * g.N + c4);
-            if (g.gate != nullptr) gat[rr] = *reinterpret_cast<const float4*>(g.gate + rc * g.ldg + c4);
+            if (g.gate != nullptr) gat[rr] = load_gate4(g.gate, gate_bf, rc * g.ldg + c4);
             if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(rc % g.res_mod) * g.ldr + c4);
           }
 #pragma unroll
@@ -676,7 +766,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
                   if (g.ln_rstd != nullptr) g.ln_rstd[row] = rstd;
                 }
               }
-              *reinterpret_cast<float4*>(g.C + row * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+              store_c4(g.C, c_bf, row * g.ldc + c4, v[0], v[1], v[2], v[3]);
             }
           }
         }
@@ -756,7 +846,7 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
                       (!d.ln_gamma || d.N == 256);
   if (d.N % 256 == 0 && d.K <= 768 && d.M >= 256 && vec_ok) {
     if (d.K <= 256) {       // one-shot form (measured: qkv 391 vs 518 us, o+LN 256 vs 300 us against the persistent form)
-      const bool rich = d.add_table || d.gate || d.drop_p > 0.f || d.residual || d.ln_gamma;
+      const bool rich = d.add_table || d.gate || d.drop_p > 0.f || d.residual || d.ln_gamma || (d.io_flags & HFTT_NT_C_BF16);
       if (!rich) return launch_nt_as1<64, 0>(d, st);
       if (d.N == 256) return launch_nt_as1<64, 1>(d, st);
       return launch_nt_as1<32, 2>(d, st);
@@ -764,8 +854,9 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
     // measured at M = 262144 (us): K=512,N=256: persistent 450 | one-shot BM=64 486;  K=768,N=256: one-shot BM=64 504 |
     // one-shot BM=32 713 | persistent double-buffered 744 | persistent 928
     if (d.K > 512 && d.N == 256) return launch_nt_as1<64, 1>(d, st);
-    if (d.K <= 512) return launch_nt_as<8, false>(d, st);
-    return launch_nt_as<12, true>(d, st);
+    const bool abf = d.io_flags & HFTT_NT_A_BF16;
+    if (d.K <= 512) return abf ? launch_nt_as<4, false, true>(d, st) : launch_nt_as<8, false, false>(d, st);
+    return abf ? launch_nt_as<6, true, true>(d, st) : launch_nt_as<12, true, false>(d, st);
   }
   return dispatch_nt<false>(d, st);      // small / ragged shapes: the k-tiled streaming kernel
 }
@@ -776,7 +867,9 @@ extern "C" int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream) {
   HFTT_REQUIRE(d != nullptr, "gemm_nt: null descriptor");
   HFTT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
   HFTT_REQUIRE(d->K % 32 == 0, "gemm_nt: K=%d must be a multiple of 32", d->K);
-  HFTT_REQUIRE(d->lda % 4 == 0, "gemm_nt: lda=%ld must be a multiple of 4", (long)d->lda);
+  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1, "gemm_nt: bf16-stored operands need npass == 1");
+  HFTT_REQUIRE(!(d->io_flags & HFTT_NT_C_BF16) || d->ln_gamma == nullptr, "gemm_nt: a bf16 C cannot be combined with LayerNorm");
+  HFTT_REQUIRE(d->lda % ((d->io_flags & HFTT_NT_A_BF16) ? 8 : 4) == 0, "gemm_nt: lda=%ld breaks 16-byte row alignment", (long)d->lda);
   HFTT_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->W & 15) == 0, "gemm_nt: A/W must be 16-byte aligned");
   HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "gemm_nt: npass must be 1 (bf16) or 3 (fp32 parity)");
   HFTT_REQUIRE(d->A != nullptr && d->W != nullptr && d->C != nullptr, "gemm_nt: null operand");

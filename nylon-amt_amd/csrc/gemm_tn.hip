@@ -99,6 +99,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
 
   float4 yregA[Cfg::YL], xregA[Cfg::XL], yregB[Cfg::YL], xregB[Cfg::XL];   // two staging sets: loads run two steps ahead
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool dy_bf = !F32 && (g.io_flags & HFTT_TN_DY_BF16), x_bf = !F32 && (g.io_flags & HFTT_TN_X_BF16);
   constexpr int YF4R = TILE_N / 4;   // float4 per row
   constexpr int XF4R = TILE_K / 4;
   const int yc4 = tid % YF4R;
@@ -115,7 +116,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       const long m = mb + row;
       // unconditional load from a clamped address + select: a branch around the load would make hipcc wait vmcnt(0) per load
       const long mc = m < mend ? m : mend - 1;
-      const float4 t = *reinterpret_cast<const float4*>(g.dY + mc * g.lddy + ycol_c);
+      float4 t;
+      if (dy_bf) {      // 4 bf16 = 8 bytes (exact widening; the tile is re-rounded to the same bf16 values on the way into LDS)
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.dY) + mc * g.lddy + ycol_c);
+        t = make_float4(bf2f(u.x & 0xFFFFu), bf2f(u.x >> 16), bf2f(u.y & 0xFFFFu), bf2f(u.y >> 16));
+      } else {
+        t = *reinterpret_cast<const float4*>(g.dY + mc * g.lddy + ycol_c);
+      }
       yreg[j] = (ycol_ok && m < mend) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -126,7 +133,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       const int col = k0 + c4 * 4;
       const long mc = m < mend ? m : mend - 1;
       const int cc = col < g.K ? col : g.K - 4;
-      const float4 t = *reinterpret_cast<const float4*>(g.X + mc * g.ldx + cc);
+      float4 t;
+      if (x_bf) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.X) + mc * g.ldx + cc);
+        t = make_float4(bf2f(u.x & 0xFFFFu), bf2f(u.x >> 16), bf2f(u.y & 0xFFFFu), bf2f(u.y >> 16));
+      } else {
+        t = *reinterpret_cast<const float4*>(g.X + mc * g.ldx + cc);
+      }
       xreg[j] = (row < BMT && col < g.K && m < mend) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -329,6 +342,7 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   HFTT_REQUIRE(d->lddy % 4 == 0 && d->ldx % 4 == 0, "gemm_tn: leading dims must be multiples of 4");
   HFTT_REQUIRE(((uintptr_t)d->dY & 15) == 0 && ((uintptr_t)d->X & 15) == 0, "gemm_tn: dY/X must be 16-byte aligned");
   HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "gemm_tn: npass must be 1 or 3");
+  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1, "gemm_tn: bf16-stored operands need npass == 1");
   HFTT_REQUIRE(d->n_seg >= 1 && d->n_seg <= 4, "gemm_tn: n_seg must be 1..4");
   HFTT_REQUIRE(d->K_out > 0 && d->K_out <= d->K, "gemm_tn: K_out out of range");
   for (int s = 0; s < d->n_seg; s++) {

@@ -77,6 +77,28 @@ __device__ __forceinline__ bf16x8 join4(bf16x4 a, bf16x4 b) {
   return r;
 }
 
+// ---- tensors stored as fp32 or as bf16 (io_flags): 4 consecutive elements at ELEMENT offset `off` ----
+__device__ __forceinline__ float4 hftt_load4(const float* base, bool bf, long off) {
+  if (bf) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+    return make_float4(bf2f(u.x & 0xFFFFu), bf2f(u.x >> 16), bf2f(u.y & 0xFFFFu), bf2f(u.y >> 16));
+  }
+  return *reinterpret_cast<const float4*>(base + off);
+}
+__device__ __forceinline__ void hftt_store4(float* base, bool bf, long off, float a, float b, float c, float d) {
+  if (bf) {
+    uint2 u;
+    u.x = f2bf(a) | ((unsigned)f2bf(b) << 16); u.y = f2bf(c) | ((unsigned)f2bf(d) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = u;
+  } else {
+    *reinterpret_cast<float4*>(base + off) = make_float4(a, b, c, d);
+  }
+}
+__device__ __forceinline__ void hftt_store1(float* base, bool bf, long off, float a) {
+  if (bf) reinterpret_cast<unsigned short*>(base)[off] = f2bf(a);
+  else base[off] = a;
+}
+
 // ---- counter-based dropout RNG: keep(seed, site, element index) -- identical in forward and backward ----
 __device__ __forceinline__ uint32_t hftt_hash(uint64_t seed, uint32_t site, uint64_t idx) {
   uint64_t x = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1u) + seed;

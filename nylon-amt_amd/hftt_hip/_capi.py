@@ -24,7 +24,7 @@ class PrepEntry(C.Structure):
 class GemmNtDesc(C.Structure):
     _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('npass', C.c_int32),
                 ('A', c_f32p), ('lda', C.c_int64),
-                ('W', C.c_void_p), ('reserved0', C.c_void_p),
+                ('W', C.c_void_p), ('io_flags', C.c_uint32), ('debug', C.c_uint32),
                 ('bias', c_f32p),
                 ('C', c_f32p), ('ldc', C.c_int64),
                 ('act', C.c_int32), ('out_scale', C.c_float),
@@ -43,7 +43,7 @@ class GemmTnDesc(C.Structure):
                 ('n_seg', C.c_int32),
                 ('seg_row0', C.c_int32 * 4), ('seg_rows', C.c_int32 * 4),
                 ('seg_dw', c_f32p * 4), ('seg_db', c_f32p * 4),
-                ('K_out', C.c_int32), ('pad', C.c_int32),
+                ('K_out', C.c_int32), ('io_flags', C.c_uint32),
                 ('ws', C.c_void_p), ('ws_bytes', C.c_int64)]
 
 
@@ -58,7 +58,8 @@ class AttnDesc(C.Structure):
                 ('dout', c_f32p),
                 ('dq', c_f32p), ('dq_seq_stride', C.c_int64), ('lddq', C.c_int64),
                 ('dk', c_f32p), ('dk_seq_stride', C.c_int64), ('lddk', C.c_int64),
-                ('dv', c_f32p), ('dv_seq_stride', C.c_int64), ('lddv', C.c_int64)]
+                ('dv', c_f32p), ('dv_seq_stride', C.c_int64), ('lddv', C.c_int64),
+                ('io_flags', C.c_uint32), ('pad', C.c_uint32)]
 
 
 class FoldDesc(C.Structure):
@@ -74,7 +75,7 @@ class LnBwdDesc(C.Structure):
                 ('dy', c_f32p), ('r', c_f32p), ('mean', c_f32p), ('rstd', c_f32p), ('gamma', c_f32p),
                 ('dr', c_f32p), ('dr_drop', c_f32p),
                 ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
-                ('ws', c_f32p)]
+                ('ws', c_f32p), ('drop_bf16', C.c_uint32), ('pad', C.c_uint32)]
 
 
 class LossDesc(C.Structure):
@@ -150,7 +151,7 @@ def lib():
             fn = getattr(handle, name)   # AttributeError if the symbol is missing: also loud
             fn.restype = res
             fn.argtypes = args
-        if handle.hftt_abi_version() != 1:
+        if handle.hftt_abi_version() != 2:
             raise HfttError('libhftt_hip.so ABI version mismatch')
         _lib = handle
     return _lib

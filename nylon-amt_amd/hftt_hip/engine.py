@@ -73,6 +73,8 @@ class HfttEngine:
             raise _capi.HfttError('n_velocity must be a multiple of 4')
         self.NH = self.V + 3                       # packed head rows: velocity[0:V], onset, offset, mpe
         self.NHp = _align(self.NH + 1, 64)
+        import os as _os0
+        self.store_bf16_opt = _os0.environ.get('HFTT_BF16_STORE', '1') != '0'
         self.set_precision(precision)
         self.dropout = float(dropout)
         self.base_seed = int(seed)
@@ -82,6 +84,8 @@ class HfttEngine:
         self._ws = {}
         self._site = 0
         self.profiler = None                        # optional per-launch HIP-event timer (bench.py)
+        import os as _os
+        self.store_bf16_opt = _os.environ.get('HFTT_BF16_STORE', '1') != '0'
 
     # ------------------------------------------------------------------ precision / parameters
     def set_precision(self, precision):
@@ -90,6 +94,9 @@ class HfttEngine:
         self.precision = precision
         self.npass = PRECISION_NPASS[precision]
         self._ws = {}
+        # bf16 mode: tensors consumed only as MFMA operands (projections, attention context, FFN hidden and their gradients)
+        # are STORED as bf16 -- identical numerics (they were rounded at load time anyway), half the traffic
+        self.sb = (self.npass == 1) and getattr(self, 'store_bf16_opt', True)
         if getattr(self, '_bound', None) is not None:
             self._build_prep()
 
@@ -267,14 +274,19 @@ class HfttEngine:
         self._site += 1
         return self._site
 
-    def _buf(self, ws, name, *shape, dtype=torch.float32):
+    def _buf(self, ws, name, *shape, dtype=torch.float32, half=False):
+        """half=True: a GEMM-only tensor -> bf16 when the engine stores such tensors as bf16."""
+        if half and self.sb:
+            dtype = torch.bfloat16
         t = torch.empty(*shape, dtype=dtype, device=self.device)
         ws['bufs'][name] = t
         return t
 
     def _nt(self, plan, ws, M, N, K, A, lda, W, bias, Cp, ldc, act=0, out_scale=1.0, add_table=0, add_mod=0,
-            gate=0, ldg=0, gate_scale=1.0, drop_site=0, residual=0, ldr=0, res_mod=0, ln=None):
+            gate=0, ldg=0, gate_scale=1.0, drop_site=0, residual=0, ldr=0, res_mod=0, ln=None, a_bf=False, c_bf=False, gate_bf=False):
+        a_bf, c_bf, gate_bf = (a_bf and self.sb), (c_bf and self.sb), (gate_bf and self.sb)
         dsc = GemmNtDesc()
+        dsc.io_flags = (1 if a_bf else 0) | (2 if c_bf else 0) | (4 if gate_bf else 0)
         dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, self.npass
         dsc.A, dsc.lda = A, lda
         dsc.W = W
@@ -296,25 +308,31 @@ class HfttEngine:
         n_pad = _align(N, 64)
         bn = N if ln is not None else (256 if n_pad % 256 == 0 else (128 if n_pad % 128 == 0 else 64))
         esz = 2 if self.npass == 1 else 4
-        nbytes = 4 * M * K + 4 * M * N + esz * N * K + (4 * M * N if residual else 0) + (4 * M * N if ln is not None else 0) + (4 * M * N if gate else 0)
-        rich = bool(add_table or gate or drop_site or residual or ln is not None)
+        nbytes = (2 if a_bf else 4) * M * K + (2 if c_bf else 4) * M * N + esz * N * K + (4 * M * N if residual else 0) + (4 * M * N if ln is not None else 0) \
+            + ((2 if gate_bf else 4) * M * N if gate else 0)
+        rich = bool(add_table or gate or drop_site or residual or ln is not None or c_bf)
         if self.npass == 1 and N % 256 == 0 and K <= 768 and M >= 256:      # mirrors dispatch_nt_bf16 in csrc/gemm_nt.hip
             if K <= 256:
                 kname = 'gemm_nt_as1_kernel<%s>' % ('64, 0' if not rich else ('64, 1' if N == 256 else '32, 2'))
             else:
-                kname = 'gemm_nt_as_kernel<8, false>' if K <= 512 else ('gemm_nt_as1_kernel<64, 1>' if N == 256 else 'gemm_nt_as_kernel<12, true>')
+                if K <= 512:
+                    kname = 'gemm_nt_as_kernel<4, false, true>' if a_bf else 'gemm_nt_as_kernel<8, false, false>'
+                else:
+                    kname = 'gemm_nt_as1_kernel<64, 1>' if N == 256 else ('gemm_nt_as_kernel<6, true, true>' if a_bf else 'gemm_nt_as_kernel<12, true, false>')
         else:
             kname = 'gemm_nt_kernel<%d, %s, %s>' % (bn, 'true' if self.npass == 3 else 'false', 'true' if ln is not None else 'false')
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_gemm_nt, (C.byref(dsc),), 'gemm_nt', meta))
         return dsc
 
-    def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0):
+    def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0, dy_bf=False, x_bf=False):
         """segs: list of (row0, rows, dw_addr, db_addr or 0)"""
         need = self.lib.hftt_gemm_tn_ws_bytes(M, N, K)
         ws['tn_need'] = max(ws.get('tn_need', 0), need)
         dsc = GemmTnDesc()
         dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, self.npass
+        dy_bf, x_bf = (dy_bf and self.sb), (x_bf and self.sb)
+        dsc.io_flags = (1 if dy_bf else 0) | (2 if x_bf else 0)
         dsc.dY, dsc.lddy, dsc.X, dsc.ldx = dY, lddy, X, ldx
         dsc.out_scale, dsc.beta = out_scale, beta
         dsc.n_seg = len(segs)
@@ -324,14 +342,16 @@ class HfttEngine:
         ws['tn'].append(dsc)
         ws['keep'].append(dsc)
         tile = '2, 4' if (N >= 256 and K >= 256) else ('1, 2' if (N >= 128 and K >= 128) else '1, 1')
-        meta = {'kernel': 'gemm_tn_kernel<%s, %d>' % (tile, self.npass), 'flops': 2.0 * M * N * K, 'bytes': 4.0 * M * (N + K) + 4.0 * N * K,
-                'shape': (M, N, K)}
+        meta = {'kernel': 'gemm_tn_kernel<%s, %d>' % (tile, self.npass), 'flops': 2.0 * M * N * K,
+                'bytes': (2.0 if dy_bf else 4.0) * M * N + (2.0 if x_bf else 4.0) * M * K + 4.0 * N * K, 'shape': (M, N, K)}
         plan.append((self.lib.hftt_gemm_tn, (C.byref(dsc),), 'gemm_tn', meta))
         return dsc
 
     def _attn(self, plan, ws, bwd, n_seq, H, Lq, Lk, q, qss, ldq, k, kss, ldk, v, vss, ldv, out, oss, ldo, lse, probs=0,
-              drop_site=0, dout=0, dq=0, dqss=0, lddq=0, dk=0, dkss=0, lddk=0, dv=0, dvss=0, lddv=0):
+              drop_site=0, dout=0, dq=0, dqss=0, lddq=0, dk=0, dkss=0, lddk=0, dv=0, dvss=0, lddv=0, flags=0):
+        flags = flags if self.sb else 0
         dsc = AttnDesc()
+        dsc.io_flags = flags
         dsc.n_seq, dsc.n_heads, dsc.Lq, dsc.Lk, dsc.dh, dsc.npass = n_seq, H, Lq, Lk, self.d // H, self.npass
         dsc.q, dsc.q_seq_stride, dsc.ldq = q, qss, ldq
         dsc.k, dsc.k_seq_stride, dsc.ldk = k, kss, ldk
@@ -349,23 +369,27 @@ class HfttEngine:
         dh = self.d // H
         kt = (Lk + 31) // 32
         kt = kt if kt <= 4 else 8
-        qkv_bytes = 4.0 * n_seq * (Lq + 2 * Lk) * self.d
+        eq = 2.0 if flags & 1 else 4.0
+        ekv = 2.0 if flags & 2 else 4.0
+        eo = 2.0 if flags & 4 else 4.0
+        qkv_bytes = n_seq * (eq * Lq + 2 * ekv * Lk) * self.d
         if bwd:
             meta = {'kernel': 'attn_bwd_kernel<%d, %d, %d>' % (kt, dh, self.npass), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
-                    'bytes': 2 * qkv_bytes + 2 * 4.0 * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
+                    'bytes': qkv_bytes + n_seq * ((2.0 if flags & 8 else 4.0) * Lq + 2 * (2.0 if flags & 16 else 4.0) * Lk) * self.d + 2 * eo * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
         else:
             meta = {'kernel': 'attn_fwd_kernel<%d, %d, %d>' % (kt, dh, self.npass), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
-                    'bytes': qkv_bytes + 4.0 * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
+                    'bytes': qkv_bytes + eo * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
         plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd', meta))
         return dsc
 
-    def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta):
+    def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta, drop_bf=True):
         n_wg = self.lib.hftt_ln_bwd_wgs(M)
         ws['ln_need'] = max(ws.get('ln_need', 0), n_wg * 2 * self.d * 4)
         dsc = LnBwdDesc()
         dsc.M, dsc.N = M, self.d
         dsc.dy, dsc.r, dsc.mean, dsc.rstd, dsc.gamma = dy, r, mean, rstd, gamma
         dsc.dr, dsc.dr_drop = dr, dr_drop
+        dsc.drop_bf16 = 1 if (drop_bf and self.sb and dr_drop) else 0
         dsc.drop_p, dsc.drop_site, dsc.drop_seed = 0.0, drop_site, 0
         ws['ln'].append(dsc)
         if drop_site:
@@ -399,42 +423,43 @@ class HfttEngine:
         """EncoderLayer (model_spec2midi.py:230-245).  Returns address of the layer output [S, d]."""
         d, p = self.d, self.p
         b = ws['bufs']
-        qkv = self._buf(ws, tag + '.qkv', S, 3 * d)
-        ctx = self._buf(ws, tag + '.ctx', S, d)
+        hz = 2 if self.sb else 4                    # element size of the GEMM-only ("half") tensors
+        qkv = self._buf(ws, tag + '.qkv', S, 3 * d, half=True)
+        ctx = self._buf(ws, tag + '.ctx', S, d, half=True)
         lse = self._buf(ws, tag + '.lse', n_seq * H * L * 2)
         r1 = self._buf(ws, tag + '.r1', S, d); x1 = self._buf(ws, tag + '.x1', S, d)
         m1 = self._buf(ws, tag + '.m1', S); s1 = self._buf(ws, tag + '.s1', S)
-        h = self._buf(ws, tag + '.h', S, p)
+        h = self._buf(ws, tag + '.h', S, p, half=True)
         r2 = self._buf(ws, tag + '.r2', S, d); x2 = self._buf(ws, tag + '.x2', S, d)
         m2 = self._buf(ws, tag + '.m2', S); s2 = self._buf(ws, tag + '.s2', S)
         sites = ws.setdefault('sites', {})
         sa, so, sh, sf = (self._new_site() for _ in range(4))
         sites[tag] = (sa, so, sh, sf)
         gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
-        self._nt(plan, ws, S, 3 * d, d, x_in, d, self.Wp(key + '.sa.qkv'), self.Fp(key + '.sa.qkv_b'), qkv.data_ptr(), 3 * d)
+        self._nt(plan, ws, S, 3 * d, d, x_in, d, self.Wp(key + '.sa.qkv'), self.Fp(key + '.sa.qkv_b'), qkv.data_ptr(), 3 * d, c_bf=True)
         q = qkv.data_ptr()
-        self._attn(plan, ws, False, n_seq, H, L, L, q, L * 3 * d, 3 * d, q + 4 * d, L * 3 * d, 3 * d, q + 8 * d, L * 3 * d, 3 * d,
-                   ctx.data_ptr(), L * d, d, lse.data_ptr(), drop_site=sa)
+        self._attn(plan, ws, False, n_seq, H, L, L, q, L * 3 * d, 3 * d, q + hz * d, L * 3 * d, 3 * d, q + 2 * hz * d, L * 3 * d, 3 * d,
+                   ctx.data_ptr(), L * d, d, lse.data_ptr(), drop_site=sa, flags=1 | 2 | 4)
         self._nt(plan, ws, S, d, d, ctx.data_ptr(), d, self.Wp(key + '.sa.o'), self.P(pre + 'self_attention.fc_o.bias'), x1.data_ptr(), d,
-                 drop_site=so, residual=x_in, ldr=d, ln=(gam, bet, r1.data_ptr(), m1.data_ptr(), s1.data_ptr()))
+                 drop_site=so, residual=x_in, ldr=d, ln=(gam, bet, r1.data_ptr(), m1.data_ptr(), s1.data_ptr()), a_bf=True)
         self._nt(plan, ws, S, p, d, x1.data_ptr(), d, self.Wp(key + '.f1'), self.P(pre + 'positionwise_feedforward.fc_1.bias'), h.data_ptr(), p,
-                 act=1, drop_site=sh)
+                 act=1, drop_site=sh, c_bf=True)
         self._nt(plan, ws, S, d, p, h.data_ptr(), p, self.Wp(key + '.f2'), self.P(pre + 'positionwise_feedforward.fc_2.bias'), x2.data_ptr(), d,
-                 drop_site=sf, residual=x1.data_ptr(), ldr=d, ln=(gam, bet, r2.data_ptr(), m2.data_ptr(), s2.data_ptr()))
+                 drop_site=sf, residual=x1.data_ptr(), ldr=d, ln=(gam, bet, r2.data_ptr(), m2.data_ptr(), s2.data_ptr()), a_bf=True)
         return x2.data_ptr()
 
     def _ffn_fwd(self, plan, ws, tag, key, pre, S, x_in, sites):
         d, p = self.d, self.p
-        h = self._buf(ws, tag + '.h', S, p)
+        h = self._buf(ws, tag + '.h', S, p, half=True)
         r = self._buf(ws, tag + '.fr', S, d); x = self._buf(ws, tag + '.fx', S, d)
         m = self._buf(ws, tag + '.fm', S); s = self._buf(ws, tag + '.fs', S)
         sh, sf = self._new_site(), self._new_site()
         sites['ffn'] = (sh, sf)
         gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
         self._nt(plan, ws, S, p, d, x_in, d, self.Wp(key + '.f1'), self.P(pre + 'positionwise_feedforward.fc_1.bias'), h.data_ptr(), p,
-                 act=1, drop_site=sh)
+                 act=1, drop_site=sh, c_bf=True)
         self._nt(plan, ws, S, d, p, h.data_ptr(), p, self.Wp(key + '.f2'), self.P(pre + 'positionwise_feedforward.fc_2.bias'), x.data_ptr(), d,
-                 drop_site=sf, residual=x_in, ldr=d, ln=(gam, bet, r.data_ptr(), m.data_ptr(), s.data_ptr()))
+                 drop_site=sf, residual=x_in, ldr=d, ln=(gam, bet, r.data_ptr(), m.data_ptr(), s.data_ptr()), a_bf=True)
         return x.data_ptr()
 
     def _build_forward(self, ws):
@@ -461,7 +486,8 @@ class HfttEngine:
         dd = 'decoder_spec2midi.'
         H = self.Hd
         pos_dec = self.P(dd + 'pos_embedding_freq.weight')
-        q0 = self._buf(ws, 'dec0.q0', N, d)
+        hz = 2 if self.sb else 4
+        q0 = self._buf(ws, 'dec0.q0', N, d, half=True)
         trg = None
         ws['dec_out'] = []
         for j in range(self.Ld):
@@ -471,43 +497,43 @@ class HfttEngine:
             pre = dd + ('layer_zero_freq.' if j == 0 else f'layers_freq.{j - 1}.')
             gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
             if j > 0:
-                sqkv = self._buf(ws, tag + '.sqkv', Sn, 3 * d)
-                sctx = self._buf(ws, tag + '.sctx', Sn, d)
+                sqkv = self._buf(ws, tag + '.sqkv', Sn, 3 * d, half=True)
+                sctx = self._buf(ws, tag + '.sctx', Sn, d, half=True)
                 slse = self._buf(ws, tag + '.slse', BT * H * N * 2)
                 sr = self._buf(ws, tag + '.sr', Sn, d); sx = self._buf(ws, tag + '.sx', Sn, d)
                 sm = self._buf(ws, tag + '.sm', Sn); ss = self._buf(ws, tag + '.ss', Sn)
                 s_a, s_o = self._new_site(), self._new_site()
                 sites['self'] = (s_a, s_o)
-                self._nt(plan, ws, Sn, 3 * d, d, trg, d, self.Wp(tag + '.sa.qkv'), self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d)
+                self._nt(plan, ws, Sn, 3 * d, d, trg, d, self.Wp(tag + '.sa.qkv'), self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d, c_bf=True)
                 q = sqkv.data_ptr()
-                self._attn(plan, ws, False, BT, H, N, N, q, N * 3 * d, 3 * d, q + 4 * d, N * 3 * d, 3 * d, q + 8 * d, N * 3 * d, 3 * d,
-                           sctx.data_ptr(), N * d, d, slse.data_ptr(), drop_site=s_a)
+                self._attn(plan, ws, False, BT, H, N, N, q, N * 3 * d, 3 * d, q + hz * d, N * 3 * d, 3 * d, q + 2 * hz * d, N * 3 * d, 3 * d,
+                           sctx.data_ptr(), N * d, d, slse.data_ptr(), drop_site=s_a, flags=1 | 2 | 4)
                 self._nt(plan, ws, Sn, d, d, sctx.data_ptr(), d, self.Wp(tag + '.sa.o'), self.P(pre + 'self_attention.fc_o.bias'), sx.data_ptr(), d,
-                         drop_site=s_o, residual=trg, ldr=d, ln=(gam, bet, sr.data_ptr(), sm.data_ptr(), ss.data_ptr()))
+                         drop_site=s_o, residual=trg, ldr=d, ln=(gam, bet, sr.data_ptr(), sm.data_ptr(), ss.data_ptr()), a_bf=True)
                 cross_in = sx.data_ptr()
-                cq = self._buf(ws, tag + '.cq', Sn, d)
-                self._nt(plan, ws, Sn, d, d, cross_in, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), cq.data_ptr(), d)
+                cq = self._buf(ws, tag + '.cq', Sn, d, half=True)
+                self._nt(plan, ws, Sn, d, d, cross_in, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), cq.data_ptr(), d, c_bf=True)
                 qaddr, qss = cq.data_ptr(), N * d
                 res, res_mod = cross_in, 0
             else:
-                self._nt(plan, ws, N, d, d, pos_dec, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), q0.data_ptr(), d)
+                self._nt(plan, ws, N, d, d, pos_dec, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), q0.data_ptr(), d, c_bf=True)
                 qaddr, qss = q0.data_ptr(), 0
                 res, res_mod = pos_dec, N
-            ckv = self._buf(ws, tag + '.ckv', Se, 2 * d)
-            cctx = self._buf(ws, tag + '.cctx', Sn, d)
+            ckv = self._buf(ws, tag + '.ckv', Se, 2 * d, half=True)
+            cctx = self._buf(ws, tag + '.cctx', Sn, d, half=True)
             clse = self._buf(ws, tag + '.clse', BT * H * N * 2)
             cr = self._buf(ws, tag + '.cr', Sn, d); cx = self._buf(ws, tag + '.cx', Sn, d)
             cm = self._buf(ws, tag + '.cm', Sn); cs = self._buf(ws, tag + '.cs', Sn)
             c_a, c_o = self._new_site(), self._new_site()
             sites['cross'] = (c_a, c_o)
-            self._nt(plan, ws, Se, 2 * d, d, enc, d, self.Wp(tag + '.ca.kv'), self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d)
+            self._nt(plan, ws, Se, 2 * d, d, enc, d, self.Wp(tag + '.ca.kv'), self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d, c_bf=True)
             kk = ckv.data_ptr()
-            ad = self._attn(plan, ws, False, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + 4 * d, F * 2 * d, 2 * d,
-                            cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a)
+            ad = self._attn(plan, ws, False, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
+                            cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a, flags=1 | 2 | 4)
             if j == self.Ld - 1:
                 ws['attn_out_desc'] = ad
             self._nt(plan, ws, Sn, d, d, cctx.data_ptr(), d, self.Wp(tag + '.ca.o'), self.P(pre + 'encoder_attention.fc_o.bias'), cx.data_ptr(), d,
-                     drop_site=c_o, residual=res, ldr=d, res_mod=res_mod, ln=(gam, bet, cr.data_ptr(), cm.data_ptr(), cs.data_ptr()))
+                     drop_site=c_o, residual=res, ldr=d, res_mod=res_mod, ln=(gam, bet, cr.data_ptr(), cm.data_ptr(), cs.data_ptr()), a_bf=True)
             trg = self._ffn_fwd(plan, ws, tag, tag, pre, Sn, cx.data_ptr(), sites)
             ws['dec_out'].append(trg)
         # ---------------- heads A ----------------
@@ -535,7 +561,8 @@ class HfttEngine:
         d, p = self.d, self.p
         b = ws['bufs']
         sa, so, sh, sf = ws['sites'][tag]
-        GA, GB, GC, Gh, Gq = G
+        GA, GB, GC, Gh, Gq, Gx = G              # fp32: GA (stream), GB (dr);  "half": GC (dropped dr), Gh (dh), Gq (dqkv), Gx (dctx)
+        hz = 2 if self.sb else 4
         gam = self.P(pre + 'layer_norm.weight')
         dgam, dbet = self.G(pre + 'layer_norm.weight'), self.G(pre + 'layer_norm.bias')
         pf = pre + 'positionwise_feedforward.'
@@ -544,48 +571,53 @@ class HfttEngine:
         # LN2 backward
         self._lnb(plan, ws, S, GA, b[tag + '.r2'].data_ptr(), b[tag + '.m2'].data_ptr(), b[tag + '.s2'].data_ptr(), gam,
                   GB, GC if use_drop else 0, sf, dgam, dbet, 0.0)
-        dbr = GC if use_drop else GB
+        dbr, dbr_bf = (GC, True) if use_drop else (GB, False)
         # fc_2
-        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))])
+        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))],
+                 dy_bf=dbr_bf, x_bf=True)
         self._nt(plan, ws, S, p, d, dbr, d, self.Wp(key + '.f2_t'), 0, Gh, p, gate=b[tag + '.h'].data_ptr(), ldg=p,
-                 gate_scale=('inv_keep',))
+                 gate_scale=('inv_keep',), a_bf=dbr_bf, c_bf=True, gate_bf=True)
         # fc_1
-        self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))])
-        self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d)
+        self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True)
+        self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True)
         # LN1 backward
         self._lnb(plan, ws, S, GA, b[tag + '.r1'].data_ptr(), b[tag + '.m1'].data_ptr(), b[tag + '.s1'].data_ptr(), gam,
                   GB, GC if use_drop else 0, so, dgam, dbet, 1.0)
         # fc_o
-        self._tn(plan, ws, S, d, d, dbr, d, b[tag + '.ctx'].data_ptr(), d, [(0, d, self.G(pa + 'fc_o.weight'), self.G(pa + 'fc_o.bias'))])
-        self._nt(plan, ws, S, d, d, dbr, d, self.Wp(key + '.sa.o_t'), 0, GA, d)
+        self._tn(plan, ws, S, d, d, dbr, d, b[tag + '.ctx'].data_ptr(), d, [(0, d, self.G(pa + 'fc_o.weight'), self.G(pa + 'fc_o.bias'))],
+                 dy_bf=dbr_bf, x_bf=True)
+        self._nt(plan, ws, S, d, d, dbr, d, self.Wp(key + '.sa.o_t'), 0, Gx, d, a_bf=dbr_bf, c_bf=True)
         # attention
         qkv = b[tag + '.qkv'].data_ptr()
-        self._attn(plan, ws, True, n_seq, H, L, L, qkv, L * 3 * d, 3 * d, qkv + 4 * d, L * 3 * d, 3 * d, qkv + 8 * d, L * 3 * d, 3 * d,
-                   b[tag + '.ctx'].data_ptr(), L * d, d, b[tag + '.lse'].data_ptr(), drop_site=sa, dout=GA,
-                   dq=Gq, dqss=L * 3 * d, lddq=3 * d, dk=Gq + 4 * d, dkss=L * 3 * d, lddk=3 * d, dv=Gq + 8 * d, dvss=L * 3 * d, lddv=3 * d)
+        self._attn(plan, ws, True, n_seq, H, L, L, qkv, L * 3 * d, 3 * d, qkv + hz * d, L * 3 * d, 3 * d, qkv + 2 * hz * d, L * 3 * d, 3 * d,
+                   b[tag + '.ctx'].data_ptr(), L * d, d, b[tag + '.lse'].data_ptr(), drop_site=sa, dout=Gx,
+                   dq=Gq, dqss=L * 3 * d, lddq=3 * d, dk=Gq + hz * d, dkss=L * 3 * d, lddk=3 * d, dv=Gq + 2 * hz * d, dvss=L * 3 * d, lddv=3 * d,
+                   flags=1 | 2 | 4 | 8 | 16)
         # qkv projection
         self._tn(plan, ws, S, 3 * d, d, Gq, 3 * d, x_in, d,
                  [(0, d, self.G(pa + 'fc_q.weight'), self.G(pa + 'fc_q.bias')), (d, d, self.G(pa + 'fc_k.weight'), self.G(pa + 'fc_k.bias')),
-                  (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))])
-        self._nt(plan, ws, S, d, 3 * d, Gq, 3 * d, self.Wp(key + '.sa.qkv_t'), 0, GA, d, residual=GB, ldr=d)
+                  (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))], dy_bf=True)
+        self._nt(plan, ws, S, d, 3 * d, Gq, 3 * d, self.Wp(key + '.sa.qkv_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True)
 
     def _ffn_bwd(self, plan, ws, tag, key, pre, S, x_in, G, ln_beta):
         """FFN + LN block of the decoder layers: grad of output in GA -> grad of x_in in GA."""
         d, p = self.d, self.p
         b = ws['bufs']
         sh, sf = ws['sites'][tag]['ffn']
-        GA, GB, GC, Gh, Gq = G
+        GA, GB, GC, Gh, Gq, Gx = G
         gam = self.P(pre + 'layer_norm.weight')
         dgam, dbet = self.G(pre + 'layer_norm.weight'), self.G(pre + 'layer_norm.bias')
         pf = pre + 'positionwise_feedforward.'
         use_drop = self.dropout > 0.0
         self._lnb(plan, ws, S, GA, b[tag + '.fr'].data_ptr(), b[tag + '.fm'].data_ptr(), b[tag + '.fs'].data_ptr(), gam,
                   GB, GC if use_drop else 0, sf, dgam, dbet, ln_beta)
-        dbr = GC if use_drop else GB
-        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))])
-        self._nt(plan, ws, S, p, d, dbr, d, self.Wp(key + '.f2_t'), 0, Gh, p, gate=b[tag + '.h'].data_ptr(), ldg=p, gate_scale=('inv_keep',))
-        self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))])
-        self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d)
+        dbr, dbr_bf = (GC, True) if use_drop else (GB, False)
+        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))],
+                 dy_bf=dbr_bf, x_bf=True)
+        self._nt(plan, ws, S, p, d, dbr, d, self.Wp(key + '.f2_t'), 0, Gh, p, gate=b[tag + '.h'].data_ptr(), ldg=p, gate_scale=('inv_keep',),
+                 a_bf=dbr_bf, c_bf=True, gate_bf=True)
+        self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True)
+        self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True)
 
     def _build_backward(self, ws):
         B, T, F, N, V, d, p = ws['B'], self.T, self.F, self.N, self.V, self.d, self.p
@@ -598,11 +630,14 @@ class HfttEngine:
         use_drop = self.dropout > 0.0
         # gradient scratch: note-token sized and bin-token sized sets
         nGA = self._buf(ws, 'g.nA', Sn, d).data_ptr(); nGB = self._buf(ws, 'g.nB', Sn, d).data_ptr()
-        nGC = self._buf(ws, 'g.nC', Sn, d).data_ptr(); nGD = self._buf(ws, 'g.nD', Sn, d).data_ptr()
-        nGh = self._buf(ws, 'g.nh', Sn, p).data_ptr(); nGq = self._buf(ws, 'g.nq', Sn, 3 * d).data_ptr()
+        hz = 2 if self.sb else 4
+        nGC = self._buf(ws, 'g.nC', Sn, d, half=True).data_ptr(); nGD = self._buf(ws, 'g.nD', Sn, d).data_ptr()
+        nGh = self._buf(ws, 'g.nh', Sn, p, half=True).data_ptr(); nGq = self._buf(ws, 'g.nq', Sn, 3 * d, half=True).data_ptr()
+        nGx = self._buf(ws, 'g.nx', Sn, d, half=True).data_ptr()
         eGA = self._buf(ws, 'g.eA', Se, d).data_ptr(); eGB = self._buf(ws, 'g.eB', Se, d).data_ptr()
-        eGC = self._buf(ws, 'g.eC', Se, d).data_ptr()
-        eGh = self._buf(ws, 'g.eh', Se, p).data_ptr(); eGq = self._buf(ws, 'g.eq', Se, 3 * d).data_ptr()
+        eGC = self._buf(ws, 'g.eC', Se, d, half=True).data_ptr()
+        eGh = self._buf(ws, 'g.eh', Se, p, half=True).data_ptr(); eGq = self._buf(ws, 'g.eq', Se, 3 * d, half=True).data_ptr()
+        eGx = self._buf(ws, 'g.ex', Se, d, half=True).data_ptr()
         dlog = self._buf(ws, 'g.dlog', Sn, self.NHp).data_ptr()
         cs_n = max(F * d, N * d, T * d)
         cs_ws = self._buf(ws, 'g.cs', self.lib.hftt_colsum_ws_bytes(1, cs_n) // 4 + 16).data_ptr()
@@ -623,7 +658,7 @@ class HfttEngine:
         y_last = ws['time_in'][-1]
         self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, y_last, d, head_segs('time'))
         self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_t_t'), 0, nGA, d)
-        Gn = (nGA, nGB, nGC, nGh, nGq)
+        Gn = (nGA, nGB, nGC, nGh, nGq, nGx)
         for i in reversed(range(self.Ld)):
             self._enc_layer_bwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, ws['time_in'][i], Gn)
         # ---- heads A, then the time-embedding transpose back onto the note-major gradient ----
@@ -636,8 +671,8 @@ class HfttEngine:
         # ---- frequency decoder layers, last to first.  Gradient stream lives in A (= nGD), per-sequence dq in Q1 (= nGA);
         #      the encoder-output gradient accumulates in eGA ----
         A, Bf, Cf, Q1 = nGD, nGB, nGC, nGA
-        Gd = (A, Bf, Cf, nGh, nGq)
-        dbr = Cf if use_drop else Bf
+        Gd = (A, Bf, Cf, nGh, nGq, nGx)
+        dbr, dbr_bf = (Cf, True) if use_drop else (Bf, False)
         first_enc_grad = True
         enc = ws['enc']
         for j in reversed(range(self.Ld)):
@@ -651,24 +686,27 @@ class HfttEngine:
             c_a, c_o = sites['cross']
             self._lnb(plan, ws, Sn, A, b[tag + '.cr'].data_ptr(), b[tag + '.cm'].data_ptr(), b[tag + '.cs'].data_ptr(), gam,
                       Bf, Cf if use_drop else 0, c_o, dgam, dbet, 1.0)
-            self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.cctx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_o.weight'), self.G(pc + 'fc_o.bias'))])
-            self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.ca.o_t'), 0, A, d)
+            self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.cctx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_o.weight'), self.G(pc + 'fc_o.bias'))],
+                     dy_bf=dbr_bf, x_bf=True)
+            self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.ca.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
             kk = b[tag + '.ckv'].data_ptr()
             if j > 0:
                 qaddr, qss = b[tag + '.cq'].data_ptr(), N * d
             else:
                 qaddr, qss = b['dec0.q0'].data_ptr(), 0
             # dq (per sequence) -> Q1 ; dk,dv -> eGq viewed as [Se, 2d]
-            self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + 4 * d, F * 2 * d, 2 * d,
-                       b[tag + '.cctx'].data_ptr(), N * d, d, b[tag + '.clse'].data_ptr(), drop_site=c_a, dout=A,
-                       dq=Q1, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + 4 * d, dvss=F * 2 * d, lddv=2 * d)
+            # per-sequence dq stays fp32 (layer zero sums it over sequences with the fp32 colsum); dk, dv are "half" tensors
+            self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
+                       b[tag + '.cctx'].data_ptr(), N * d, d, b[tag + '.clse'].data_ptr(), drop_site=c_a, dout=nGx,
+                       dq=Q1, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + hz * d, dvss=F * 2 * d, lddv=2 * d,
+                       flags=1 | 2 | 4 | 16)
             self._tn(plan, ws, Se, 2 * d, d, eGq, 2 * d, enc, d,
-                     [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))])
+                     [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))], dy_bf=True)
             if first_enc_grad:
-                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d)
+                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, a_bf=True)
                 first_enc_grad = False
             else:
-                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, residual=eGA, ldr=d)
+                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, residual=eGA, ldr=d, a_bf=True)
             if j > 0:
                 # q projection of the cross attention (input sx, which is also the residual of this block)
                 self._tn(plan, ws, Sn, d, d, Q1, d, b[tag + '.sx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
@@ -679,16 +717,18 @@ class HfttEngine:
                 trg = ws['dec_out'][j - 1]
                 self._lnb(plan, ws, Sn, A, b[tag + '.sr'].data_ptr(), b[tag + '.sm'].data_ptr(), b[tag + '.ss'].data_ptr(), gam,
                           Bf, Cf if use_drop else 0, s_o, dgam, dbet, 1.0)
-                self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.sctx'].data_ptr(), d, [(0, d, self.G(ps + 'fc_o.weight'), self.G(ps + 'fc_o.bias'))])
-                self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.sa.o_t'), 0, A, d)
+                self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.sctx'].data_ptr(), d, [(0, d, self.G(ps + 'fc_o.weight'), self.G(ps + 'fc_o.bias'))],
+                         dy_bf=dbr_bf, x_bf=True)
+                self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.sa.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
                 q = b[tag + '.sqkv'].data_ptr()
-                self._attn(plan, ws, True, BT, H, N, N, q, N * 3 * d, 3 * d, q + 4 * d, N * 3 * d, 3 * d, q + 8 * d, N * 3 * d, 3 * d,
-                           b[tag + '.sctx'].data_ptr(), N * d, d, b[tag + '.slse'].data_ptr(), drop_site=s_a, dout=A,
-                           dq=nGq, dqss=N * 3 * d, lddq=3 * d, dk=nGq + 4 * d, dkss=N * 3 * d, lddk=3 * d, dv=nGq + 8 * d, dvss=N * 3 * d, lddv=3 * d)
+                self._attn(plan, ws, True, BT, H, N, N, q, N * 3 * d, 3 * d, q + hz * d, N * 3 * d, 3 * d, q + 2 * hz * d, N * 3 * d, 3 * d,
+                           b[tag + '.sctx'].data_ptr(), N * d, d, b[tag + '.slse'].data_ptr(), drop_site=s_a, dout=nGx,
+                           dq=nGq, dqss=N * 3 * d, lddq=3 * d, dk=nGq + hz * d, dkss=N * 3 * d, lddk=3 * d, dv=nGq + 2 * hz * d, dvss=N * 3 * d, lddv=3 * d,
+                           flags=1 | 2 | 4 | 8 | 16)
                 self._tn(plan, ws, Sn, 3 * d, d, nGq, 3 * d, trg, d,
                          [(0, d, self.G(ps + 'fc_q.weight'), self.G(ps + 'fc_q.bias')), (d, d, self.G(ps + 'fc_k.weight'), self.G(ps + 'fc_k.bias')),
-                          (2 * d, d, self.G(ps + 'fc_v.weight'), self.G(ps + 'fc_v.bias'))])
-                self._nt(plan, ws, Sn, d, 3 * d, nGq, 3 * d, self.Wp(tag + '.sa.qkv_t'), 0, A, d, residual=Bf, ldr=d)
+                          (2 * d, d, self.G(ps + 'fc_v.weight'), self.G(ps + 'fc_v.bias'))], dy_bf=True)
+                self._nt(plan, ws, Sn, d, 3 * d, nGq, 3 * d, self.Wp(tag + '.sa.qkv_t'), 0, A, d, residual=Bf, ldr=d, a_bf=True)
             else:
                 # layer zero: query = fc_q(pos_embedding_freq) shared by all sequences, residual = pos_embedding_freq
                 gpos = self.G(dd + 'pos_embedding_freq.weight')
@@ -698,7 +738,7 @@ class HfttEngine:
                          [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
                 self._nt(plan, ws, N, d, d, dq0s, d, self.Wp(tag + '.ca.q_t'), 0, gpos, d, residual=gpos, ldr=d)
         # ---- encoder layers ----
-        Ge = (eGA, eGB, eGC, eGh, eGq)
+        Ge = (eGA, eGB, eGC, eGh, eGq, eGx)
         for i in reversed(range(self.Le)):
             self._enc_layer_bwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, ws['enc_in'][i], Ge)
         # ---- embedding ----

@@ -23,6 +23,12 @@ def _need_cuda(*ts):
             raise HfttError('hftt ops need ROCm device tensors (got %s); there is no CPU fallback' % t.device)
 
 
+BF16 = torch.bfloat16
+NT_A_BF16, NT_C_BF16, NT_GATE_BF16 = 1, 2, 4
+TN_DY_BF16, TN_X_BF16 = 1, 2
+ATTN_Q_BF16, ATTN_KV_BF16, ATTN_O_BF16, ATTN_DQ_BF16, ATTN_DKV_BF16 = 1, 2, 4, 8, 16
+
+
 def _align(x, a):
     return (x + a - 1) // a * a
 
@@ -46,18 +52,19 @@ def prepare_weight(w: torch.Tensor, npass=3, transposed=False, n_pad=64):
 
 
 def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_mod=0, gate=None, gate_scale=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, residual=None, res_mod=0, ln=None, planes=None, debug=0):
+            drop_p=0.0, drop_site=0, drop_seed=0, residual=None, res_mod=0, ln=None, planes=None, debug=0, out_dtype=torch.float32):
     """C = epi(A @ W.T + bias); W fp32 [N, K].  ln = (gamma, beta) -> returns (C, pre_ln, mean, rstd)."""
     _need_cuda(A, W)
     M, K = A.shape
     N = W.shape[0]
     Wprep = planes if planes is not None else prepare_weight(W, npass)
-    Cout = torch.empty(M, N, device=A.device)
+    Cout = torch.empty(M, N, device=A.device, dtype=out_dtype)
     d = GemmNtDesc()
     d.M, d.N, d.K, d.npass = M, N, K, npass
     d.A, d.lda = A.data_ptr(), A.stride(0)
     d.W = Wprep.data_ptr()
-    d.reserved0 = debug
+    d.debug = debug
+    d.io_flags = (NT_A_BF16 if A.dtype == BF16 else 0) | (NT_C_BF16 if out_dtype == BF16 else 0) | (NT_GATE_BF16 if (gate is not None and gate.dtype == BF16) else 0)
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc = Cout.data_ptr(), N
     d.act, d.out_scale = act, out_scale
@@ -94,6 +101,7 @@ def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True):
     d.M, d.N, d.K, d.npass = M, N, K, npass
     d.dY, d.lddy, d.X, d.ldx = dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0)
     d.out_scale, d.beta, d.n_seg = out_scale, 0.0, 1
+    d.io_flags = (TN_DY_BF16 if dY.dtype == BF16 else 0) | (TN_X_BF16 if X.dtype == BF16 else 0)
     d.seg_row0[0], d.seg_rows[0], d.seg_dw[0], d.seg_db[0] = 0, N, dW.data_ptr(), (db.data_ptr() if with_bias else 0)
     d.K_out = K
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
@@ -110,35 +118,39 @@ def _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed):
     d.k, d.k_seq_stride, d.ldk = k.data_ptr(), k.stride(0), k.stride(1)
     d.v, d.v_seq_stride, d.ldv = v.data_ptr(), v.stride(0), v.stride(1)
     d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
+    d.io_flags = (ATTN_Q_BF16 if q.dtype == BF16 else 0) | (ATTN_KV_BF16 if k.dtype == BF16 else 0)
+    assert k.dtype == v.dtype
     return d
 
 
-def attn_fwd(q, k, v, n_heads, npass=3, want_probs=False, drop_p=0.0, drop_site=0, drop_seed=0):
+def attn_fwd(q, k, v, n_heads, npass=3, want_probs=False, drop_p=0.0, drop_site=0, drop_seed=0, out_dtype=torch.float32):
     """q [n_seq, Lq, d], k/v [n_seq, Lk, d] (any row/seq strides) -> out [n_seq, Lq, d], row stats [n_seq, H, Lq, 2](, probs)."""
     _need_cuda(q, k, v)
     n_seq, Lq, dm = q.shape
     Lk = k.shape[1]
-    out = torch.empty(n_seq, Lq, dm, device=q.device)
+    out = torch.empty(n_seq, Lq, dm, device=q.device, dtype=out_dtype)
     lse = torch.empty(n_seq, n_heads, Lq, 2, device=q.device)     # (row max, 1/row sum)
     probs = torch.empty(n_seq, n_heads, Lq, Lk, device=q.device) if want_probs else None
     d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed)
     d.out, d.o_seq_stride, d.ldo = out.data_ptr(), out.stride(0), out.stride(1)
     d.lse = lse.data_ptr()
     d.probs = probs.data_ptr() if want_probs else 0
+    d.io_flags |= ATTN_O_BF16 if out_dtype == BF16 else 0
     check(lib().hftt_attn_fwd(C.byref(d), _stream(q.device)), 'attn_fwd')
     return (out, lse, probs) if want_probs else (out, lse)
 
 
-def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0, drop_seed=0):
+def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0, drop_seed=0, dq_dtype=torch.float32, dkv_dtype=torch.float32):
     _need_cuda(q, k, v, out, dout)
-    dq = torch.empty(q.shape, device=q.device)
-    dk = torch.empty(k.shape, device=q.device)
-    dv = torch.empty(v.shape, device=q.device)
+    dq = torch.empty(q.shape, device=q.device, dtype=dq_dtype)
+    dk = torch.empty(k.shape, device=q.device, dtype=dkv_dtype)
+    dv = torch.empty(v.shape, device=q.device, dtype=dkv_dtype)
     d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed)
     d.out, d.o_seq_stride, d.ldo = out.data_ptr(), out.stride(0), out.stride(1)
     d.lse = lse.data_ptr()
-    assert dout.stride() == out.stride()
+    assert dout.stride() == out.stride() and dout.dtype == out.dtype
     d.dout = dout.data_ptr()
+    d.io_flags |= (ATTN_O_BF16 if out.dtype == BF16 else 0) | (ATTN_DQ_BF16 if dq_dtype == BF16 else 0) | (ATTN_DKV_BF16 if dkv_dtype == BF16 else 0)
     d.dq, d.dq_seq_stride, d.lddq = dq.data_ptr(), dq.stride(0), dq.stride(1)
     d.dk, d.dk_seq_stride, d.lddk = dk.data_ptr(), dk.stride(0), dk.stride(1)
     d.dv, d.dv_seq_stride, d.lddv = dv.data_ptr(), dv.stride(0), dv.stride(1)
@@ -146,20 +158,21 @@ def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0,
     return dq, dk, dv
 
 
-def ln_bwd(dy, r, mean, rstd, gamma, drop_p=0.0, drop_site=0, drop_seed=0):
+def ln_bwd(dy, r, mean, rstd, gamma, drop_p=0.0, drop_site=0, drop_seed=0, drop_dtype=torch.float32):
     _need_cuda(dy, r)
     M, N = dy.shape
     L = lib()
     n_wg = L.hftt_ln_bwd_wgs(M)
     ws = torch.empty(n_wg * 2 * N, device=dy.device)
     dr = torch.empty_like(dy)
-    drd = torch.empty_like(dy) if drop_p > 0 else None
+    drd = torch.empty(dy.shape, device=dy.device, dtype=drop_dtype) if drop_p > 0 else None
     d = LnBwdDesc()
     d.M, d.N = M, N
     d.dy, d.r, d.mean, d.rstd, d.gamma = dy.data_ptr(), r.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr()
     d.dr, d.dr_drop = dr.data_ptr(), (drd.data_ptr() if drd is not None else 0)
     d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
     d.ws = ws.data_ptr()
+    d.drop_bf16 = 1 if drop_dtype == BF16 else 0
     st = _stream(dy.device)
     check(L.hftt_ln_bwd(C.byref(d), st), 'ln_bwd')
     dg = torch.empty(N, device=dy.device)

@@ -202,3 +202,79 @@ def test_logmel(dev):
     assert max_err(feat, ref) < 2e-3
     ref32 = util.O.logmel(wave)
     assert max_err(feat, ref32) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16-STORED operands (io_flags): numerically the same kernels, inputs are exactly representable in bf16 here so the
+# only extra error is the final rounding of a bf16 output (2^-9 relative)
+# ------------------------------------------------------------------------------------------------------------------
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 256, 256), (700, 768, 256), (515, 256, 512), (300, 256, 768), (257, 192, 96), (4096, 512, 256)])
+def test_gemm_nt_bf16_storage(dev, M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g)); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    gate = _bf(torch.randn(M, N, generator=g)); res = torch.randn(M, N, generator=g)
+    lin = A.double() @ _bf(W).double().T + b.double()
+    out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=1)                                    # bf16 A, fp32 C
+    assert out.dtype == torch.float32 and rel_err(out, lin) < 1e-5
+    out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=1, act=1, out_dtype=torch.bfloat16)    # bf16 A, bf16 C
+    assert out.dtype == torch.bfloat16 and rel_err(out.float(), torch.relu(lin)) < 5e-3
+    out = ops.gemm_nt(A.float().to(dev), W.to(dev), None, npass=1, gate=gate.to(dev), gate_scale=2.0, residual=res.to(dev), out_dtype=torch.bfloat16)
+    ref = torch.where(gate.double() > 0, (lin - b.double()) * 2.0, torch.zeros((), dtype=torch.float64)) + res.double()
+    assert rel_err(out.float(), ref) < 5e-3
+    if N == 256:
+        gam = torch.randn(N, generator=g); bet = torch.randn(N, generator=g)
+        o, pre, mean, rstd = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=1, residual=res.to(dev), ln=(gam.to(dev), bet.to(dev)))
+        assert rel_err(pre, lin + res.double()) < 1e-5
+        assert rel_err(o, F.layer_norm(lin + res.double(), (N,), gam.double(), bet.double(), 1e-5)) < 1e-4
+
+
+@pytest.mark.parametrize('M,N,K', [(5000, 256, 256), (3000, 512, 256), (1000, 192, 256), (2000, 768, 256)])
+def test_gemm_tn_bf16_storage(dev, M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    dY = _bf(torch.randn(M, N, generator=g)); X = _bf(torch.randn(M, K, generator=g))
+    ref = dY.double().T @ X.double()
+    for a, b in ((dY, X), (dY.float(), X), (dY, X.float())):
+        dW, db = ops.gemm_tn(a.to(dev), b.to(dev), npass=1)
+        assert max_err(dW, ref) / math.sqrt(M) < 1e-4
+        assert max_err(db, dY.double().sum(0)) / math.sqrt(M) < 1e-5
+
+
+@pytest.mark.parametrize('n,H,Lq,Lk,dh', [(5, 4, 256, 256, 64), (5, 4, 88, 256, 64), (4, 4, 88, 88, 64), (4, 4, 128, 128, 64), (3, 2, 48, 48, 32)])
+def test_attention_bf16_storage(dev, n, H, Lq, Lk, dh):
+    ops = _ops()
+    d = H * dh
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = _bf(torch.randn(n, Lq, d, generator=g)); k = _bf(torch.randn(n, Lk, d, generator=g)); v = _bf(torch.randn(n, Lk, d, generator=g))
+    do = _bf(torch.randn(n, Lq, d, generator=g))
+    q64, k64, v64 = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    o_ref, p_ref, _ = _attn_ref(q64, k64, v64, H)
+    out, lse, probs = ops.attn_fwd(q.to(dev), k.to(dev), v.to(dev), H, npass=1, want_probs=True, out_dtype=torch.bfloat16)
+    assert out.dtype == torch.bfloat16
+    assert max_err(probs, p_ref) < 2e-2 and rel_err(out.float(), o_ref) < 3e-2
+    # backward against autograd THROUGH the bf16-rounded output the kernel itself stored
+    (o_ref * do.double()).sum().backward()
+    dq, dk, dv = ops.attn_bwd(q.to(dev), k.to(dev), v.to(dev), out, lse, do.to(dev), H, npass=1, dq_dtype=torch.bfloat16, dkv_dtype=torch.bfloat16)
+    assert dq.dtype == dk.dtype == torch.bfloat16
+    assert rel_err(dq.float(), q64.grad) < 6e-2 and rel_err(dk.float(), k64.grad) < 6e-2 and rel_err(dv.float(), v64.grad) < 6e-2
+    # same kernels with fp32 storage agree with the bf16-storage run up to the output roundings
+    out32, lse32 = ops.attn_fwd(q.float().to(dev), k.float().to(dev), v.float().to(dev), H, npass=1)
+    assert rel_err(out.float(), out32) < 1e-2
+
+
+def test_ln_bwd_bf16_dropped_output(dev):
+    ops = _ops()
+    M, N = 777, 256
+    g = torch.Generator().manual_seed(4)
+    r = torch.randn(M, N, generator=g); dy = torch.randn(M, N, generator=g); gam = torch.randn(N, generator=g)
+    mean = r.mean(1); rstd = 1.0 / torch.sqrt(r.var(1, unbiased=False) + 1e-5)
+    a = ops.ln_bwd(dy.to(dev), r.to(dev), mean.to(dev), rstd.to(dev), gam.to(dev), drop_p=0.2, drop_site=3, drop_seed=9)
+    b = ops.ln_bwd(dy.to(dev), r.to(dev), mean.to(dev), rstd.to(dev), gam.to(dev), drop_p=0.2, drop_site=3, drop_seed=9, drop_dtype=torch.bfloat16)
+    assert b[1].dtype == torch.bfloat16
+    assert max_err(a[0], b[0]) == 0.0
+    assert rel_err(b[1].float(), a[1]) < 5e-3
