@@ -35,10 +35,12 @@ struct AbCfg {
   static constexpr int NTHR = KT * 64;
 };
 
-template <int KT, int DH, int NPASS>
+// HB: q, k, v, out, dout all stored as bf16 -> 16-byte loads straight into LDS / fragments (dq, dk, dv dtype by io_flags)
+template <int KT, int DH, int NPASS, bool HB>
 __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc g) {
   using Cfg = AbCfg<KT, DH, NPASS>;
   constexpr bool F32 = Cfg::F32;
+  static_assert(!(F32 && HB), "bf16-stored tensors are a bf16-mode feature");
   constexpr int RSK = Cfg::RSK, RSQ = Cfg::RSQ, RSS = Cfg::RSS, LKP = Cfg::LKP, NTHR = Cfg::NTHR;
   constexpr int KS = DH / 16, NT = DH / 32, F4R = DH / 4, HD = DH / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -77,7 +79,26 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   const float* kb = g.k + kofs;                                  // pointer forms: fp32 (parity) path only
   const float* vb = g.v + vofs;
   // ---- stage all of K (row-major) for the dQ product: all of a thread's loads in flight, then convert + store ----
-  {
+  if (HB) {
+    constexpr int S8R = DH / 8;
+    constexpr int KCNT8 = (LKP * S8R + NTHR - 1) / NTHR;
+    const unsigned short* kp = reinterpret_cast<const unsigned short*>(g.k) + kofs;
+    uint4 kst[KCNT8];
+#pragma unroll
+    for (int u = 0; u < KCNT8; u++) {
+      const int i = tid + NTHR * u;
+      const int ic = i < LKP * S8R ? i : LKP * S8R - 1;
+      const int key = ic / S8R, c8 = ic % S8R;
+      const int kc = key < Lk ? key : Lk - 1;
+      kst[u] = *reinterpret_cast<const uint4*>(kp + (long)kc * g.ldk + c8 * 8);
+      if (key >= Lk) kst[u] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < KCNT8; u++) {
+      const int i = tid + NTHR * u;
+      if (i < LKP * S8R) *reinterpret_cast<uint4*>(Ks16 + (i / S8R) * RSK + (i % S8R) * 8) = kst[u];
+    }
+  } else {
     constexpr int KCNT = (LKP * F4R + NTHR - 1) / NTHR;
     float4 kst[KCNT];
 #pragma unroll
@@ -113,6 +134,18 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       kf32[4 * t4] = a.x; kf32[4 * t4 + 1] = a.y; kf32[4 * t4 + 2] = a.z; kf32[4 * t4 + 3] = a.w;
       vf32[4 * t4] = b.x; vf32[4 * t4 + 1] = b.y; vf32[4 * t4 + 2] = b.z; vf32[4 * t4 + 3] = b.w;
     }
+  } else if (HB) {
+    const unsigned short* kp = reinterpret_cast<const unsigned short*>(g.k) + kofs + (long)mykey_c * g.ldk;
+    const unsigned short* vp = reinterpret_cast<const unsigned short*>(g.v) + vofs + (long)mykey_c * g.ldv;
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      kfh[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s + 8 * lh);
+      vfh[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s + 8 * lh);
+      if (mykey >= Lk) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { kfh[s][e] = 0; vfh[s][e] = 0; }
+      }
+    }
   } else {
 #pragma unroll
     for (int s = 0; s < KS; s++) {
@@ -147,23 +180,33 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
 
   // Q / dO / O rows (+ softmax row statistics) of the NEXT query block are fetched into registers while the current block is
   // being processed, so their HBM latency is off the critical path
-  constexpr int QCNT = (32 * F4R + NTHR - 1) / NTHR;
-  float4 pq[QCNT], pdo[QCNT], po[QCNT];
+  constexpr int QSLOT = HB ? DH / 8 : F4R;          // 16-byte slots per row (8 bf16 or 4 fp32)
+  constexpr int QCNT = (32 * QSLOT + NTHR - 1) / NTHR;
+  uint4 pq[QCNT], pdo[QCNT], po[QCNT];             // raw 16-byte slots
   float pl0[QCNT], pl1[QCNT];
   auto qload = [&](int qb) {
 #pragma unroll
     for (int u = 0; u < QCNT; u++) {
       const int i = tid + NTHR * u;
-      const int ic = i < 32 * F4R ? i : 32 * F4R - 1;
-      const int row = ic / F4R, c4 = ic % F4R;
+      const int ic = i < 32 * QSLOT ? i : 32 * QSLOT - 1;
+      const int row = ic / QSLOT, cs = ic % QSLOT;
       const int q = qb * 32 + row;
       const int qc = q < Lq ? q : Lq - 1;          // clamped address + select: loads stay unconditional
-      pq[u] = hftt_load4(g.q, q_bf, qofs + (long)qc * g.ldq + c4 * 4);
-      pdo[u] = hftt_load4(g.dout, o_bf, oofs + (long)qc * g.ldo + c4 * 4);
-      po[u] = hftt_load4(g.out, o_bf, oofs + (long)qc * g.ldo + c4 * 4);
+      if (HB) {
+        pq[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.q) + qofs + (long)qc * g.ldq + cs * 8);
+        pdo[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.dout) + oofs + (long)qc * g.ldo + cs * 8);
+        po[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.out) + oofs + (long)qc * g.ldo + cs * 8);
+      } else {
+        const float4 a = hftt_load4(g.q, q_bf, qofs + (long)qc * g.ldq + cs * 4);
+        const float4 b2 = hftt_load4(g.dout, o_bf, oofs + (long)qc * g.ldo + cs * 4);
+        const float4 c = hftt_load4(g.out, o_bf, oofs + (long)qc * g.ldo + cs * 4);
+        pq[u] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w));
+        pdo[u] = make_uint4(__float_as_uint(b2.x), __float_as_uint(b2.y), __float_as_uint(b2.z), __float_as_uint(b2.w));
+        po[u] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w));
+      }
       pl0[u] = g.lse[(sh * Lq + qc) * 2];
       pl1[u] = g.lse[(sh * Lq + qc) * 2 + 1];
-      if (q >= Lq) { pq[u] = make_float4(0.f, 0.f, 0.f, 0.f); pdo[u] = pq[u]; po[u] = pq[u]; pl0[u] = 0.f; pl1[u] = 0.f; }
+      if (q >= Lq) { pq[u] = make_uint4(0u, 0u, 0u, 0u); pdo[u] = pq[u]; po[u] = pq[u]; pl0[u] = 0.f; pl1[u] = 0.f; }
     }
   };
   qload(0);
@@ -173,20 +216,33 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
 #pragma unroll
     for (int u = 0; u < QCNT; u++) {
       const int i = tid + NTHR * u;
-      if (i < 32 * F4R) {                           // wave-uniform (32*F4R and NTHR are multiples of 64)
-        const int row = i / F4R, c4 = i % F4R;
-        const float4 qf = pq[u], df = pdo[u], of = po[u];
-        if (F32) {
-          put_row4(Qs32 + row * RSQ + c4 * 4, qf);
-          put_row4(Os32 + row * RSQ + c4 * 4, df);
-        } else {
-          *reinterpret_cast<uint2*>(Qs16 + row * RSQ + c4 * 4) = pack4(qf);
-          *reinterpret_cast<uint2*>(Os16 + row * RSQ + c4 * 4) = pack4(df);
-        }
-        float dot = df.x * of.x + df.y * of.y + df.z * of.z + df.w * of.w;
+      if (i < 32 * QSLOT) {                         // wave-uniform (32*QSLOT and NTHR are multiples of 64)
+        const int row = i / QSLOT, cs = i % QSLOT;
+        float dot;
+        if (HB) {
+          *reinterpret_cast<uint4*>(Qs16 + row * RSQ + cs * 8) = pq[u];
+          *reinterpret_cast<uint4*>(Os16 + row * RSQ + cs * 8) = pdo[u];
+          const unsigned dw[4] = {pdo[u].x, pdo[u].y, pdo[u].z, pdo[u].w};
+          const unsigned ow[4] = {po[u].x, po[u].y, po[u].z, po[u].w};
+          dot = 0.f;
 #pragma unroll
-        for (int o = F4R / 2; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
-        if (c4 == 0) {
+          for (int e = 0; e < 4; e++) dot += bf2f(dw[e] & 0xFFFFu) * bf2f(ow[e] & 0xFFFFu) + bf2f(dw[e] >> 16) * bf2f(ow[e] >> 16);
+        } else {
+          const float4 qf = make_float4(__uint_as_float(pq[u].x), __uint_as_float(pq[u].y), __uint_as_float(pq[u].z), __uint_as_float(pq[u].w));
+          const float4 df = make_float4(__uint_as_float(pdo[u].x), __uint_as_float(pdo[u].y), __uint_as_float(pdo[u].z), __uint_as_float(pdo[u].w));
+          const float4 of = make_float4(__uint_as_float(po[u].x), __uint_as_float(po[u].y), __uint_as_float(po[u].z), __uint_as_float(po[u].w));
+          if (F32) {
+            put_row4(Qs32 + row * RSQ + cs * 4, qf);
+            put_row4(Os32 + row * RSQ + cs * 4, df);
+          } else {
+            *reinterpret_cast<uint2*>(Qs16 + row * RSQ + cs * 4) = pack4(qf);
+            *reinterpret_cast<uint2*>(Os16 + row * RSQ + cs * 4) = pack4(df);
+          }
+          dot = df.x * of.x + df.y * of.y + df.z * of.z + df.w * of.w;
+        }
+#pragma unroll
+        for (int o = QSLOT / 2; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        if (cs == 0) {
           delta_s[row] = dot;
           lse_s[row] = pl0[u];
           inv_s[row] = pl1[u];
@@ -287,10 +343,24 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
           a4 = mfma16(ah, bh, a4);
         }
       }
+      if (dq_bf) {
+        // lanes 2i / 2i+1 hold adjacent columns: one packed 4-byte store per register pair
+        unsigned short* dqp = reinterpret_cast<unsigned short*>(g.dq) + dqofs;
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int rp = 0; rp < 2; rp++) {
+          const float own0 = a4[2 * rp], own1 = a4[2 * rp + 1];
+          const float y = __shfl_xor(odd ? own0 : own1, 1, 64);
+          const float lo = odd ? y : own0, hi = odd ? own1 : y;
+          const int q = qb * 32 + qh2 * 16 + gi * 4 + 2 * rp + (odd ? 1 : 0);
+          if (q < Lq) *reinterpret_cast<unsigned*>(dqp + (long)q * g.lddq + ct * 16 + ((lane & 15) & ~1)) = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+        }
+      } else {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int q = qb * 32 + qh2 * 16 + gi * 4 + r;
-        if (q < Lq) hftt_store1(g.dq, dq_bf, dqofs + (long)q * g.lddq + ct * 16 + (lane & 15), a4[r]);
+        if (q < Lq) g.dq[dqofs + (long)q * g.lddq + ct * 16 + (lane & 15)] = a4[r];
+      }
       }
     }
     // no barrier needed here: the next iteration's staging touches only Qs/Os/lse/delta, which no wave reads in (i);
@@ -312,29 +382,29 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   }
 }
 
-template <int KT, int DH, int NPASS>
+template <int KT, int DH, int NPASS, bool HB>
 int launch_ab(const hftt_attn_desc& d, hipStream_t st) {
   using Cfg = AbCfg<KT, DH, NPASS>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT, DH, NPASS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT, DH, NPASS, HB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) { hftt_set_error("attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<KT, DH, NPASS>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, d);
+  hipLaunchKernelGGL((attn_bwd_kernel<KT, DH, NPASS, HB>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, d);
   HFTT_CHECK_LAUNCH("attn_bwd");
   return 0;
 }
 
-template <int DH, int NPASS>
+template <int DH, int NPASS, bool HB>
 int dispatch_ab(const hftt_attn_desc& d, hipStream_t st) {
   const int kt = (d.Lk + 31) / 32;
-  if (kt <= 1) return launch_ab<1, DH, NPASS>(d, st);
-  if (kt <= 2) return launch_ab<2, DH, NPASS>(d, st);
-  if (kt <= 3) return launch_ab<3, DH, NPASS>(d, st);
-  if (kt <= 4) return launch_ab<4, DH, NPASS>(d, st);
-  return launch_ab<8, DH, NPASS>(d, st);
+  if (kt <= 1) return launch_ab<1, DH, NPASS, HB>(d, st);
+  if (kt <= 2) return launch_ab<2, DH, NPASS, HB>(d, st);
+  if (kt <= 3) return launch_ab<3, DH, NPASS, HB>(d, st);
+  if (kt <= 4) return launch_ab<4, DH, NPASS, HB>(d, st);
+  return launch_ab<8, DH, NPASS, HB>(d, st);
 }
 
 }  // namespace
@@ -343,6 +413,11 @@ extern "C" int hftt_attn_bwd(const hftt_attn_desc* d, void* stream) {
   int rc = hftt_attn_check(d, true);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->dh == 64) return d->npass == 3 ? dispatch_ab<64, 3>(*d, st) : dispatch_ab<64, 1>(*d, st);
-  return d->npass == 3 ? dispatch_ab<32, 3>(*d, st) : dispatch_ab<32, 1>(*d, st);
+  const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
+  const bool hb = (d->io_flags & all_half) == all_half && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 8 == 0 &&
+                  d->q_seq_stride % 8 == 0 && d->k_seq_stride % 8 == 0 && d->v_seq_stride % 8 == 0 && d->o_seq_stride % 8 == 0;
+  HFTT_REQUIRE(!(d->io_flags & HFTT_ATTN_DQ_BF16) || (d->lddq % 2 == 0 && d->dq_seq_stride % 2 == 0), "attn_bwd: bf16 dq needs even strides");
+  if (d->npass == 3) return d->dh == 64 ? dispatch_ab<64, 3, false>(*d, st) : dispatch_ab<32, 3, false>(*d, st);
+  if (d->dh == 64) return hb ? dispatch_ab<64, 1, true>(*d, st) : dispatch_ab<64, 1, false>(*d, st);
+  return hb ? dispatch_ab<32, 1, true>(*d, st) : dispatch_ab<32, 1, false>(*d, st);
 }

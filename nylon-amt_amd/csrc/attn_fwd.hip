@@ -28,10 +28,12 @@ struct AfCfg {
   static constexpr int LDS_BYTES = (K_ELEMS + V_ELEMS) * (F32 ? 4 : 2);
 };
 
-template <int KT, int DH, int NPASS>
+// HB: q, k, v and out are all stored as bf16 -> 16-byte loads straight into LDS / fragments, packed 4-byte output stores
+template <int KT, int DH, int NPASS, bool HB>
 __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(const hftt_attn_desc g) {
   using Cfg = AfCfg<KT, DH, NPASS>;
   constexpr bool F32 = Cfg::F32;
+  static_assert(!(F32 && HB), "bf16-stored tensors are a bf16-mode feature");
   constexpr int RSK = Cfg::RSK, RSV = Cfg::RSV, LKP = Cfg::LKP;
   constexpr int KS = DH / 16;   // bf16 k-steps of the QK^T product
   constexpr int NT = DH / 32;   // output column tiles
@@ -53,6 +55,35 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
   {
     const long kofs = (long)seq * g.k_seq_stride + head * DH;      // element offsets (the tensors may be fp32 or bf16)
     const long vofs = (long)seq * g.v_seq_stride + head * DH;
+    if (HB) {
+      constexpr int S8R = DH / 8;                    // 16-byte slots (8 bf16) per key row
+      constexpr int TOTAL8 = LKP * S8R;
+      constexpr int UB8 = (TOTAL8 / 256) < 8 ? ((TOTAL8 / 256) < 1 ? 1 : (TOTAL8 / 256)) : 8;
+      const unsigned short* kp = reinterpret_cast<const unsigned short*>(g.k) + kofs;
+      const unsigned short* vp = reinterpret_cast<const unsigned short*>(g.v) + vofs;
+      for (int base = 0; base < TOTAL8; base += 256 * UB8) {
+        uint4 kf[UB8], vf[UB8];
+#pragma unroll
+        for (int u = 0; u < UB8; u++) {
+          const int i = base + tid + 256 * u;
+          const int ic = i < TOTAL8 ? i : TOTAL8 - 1;
+          const int key = ic / S8R, c8 = ic % S8R;
+          const int kc = key < Lk ? key : Lk - 1;
+          kf[u] = *reinterpret_cast<const uint4*>(kp + (long)kc * g.ldk + c8 * 8);
+          vf[u] = *reinterpret_cast<const uint4*>(vp + (long)kc * g.ldv + c8 * 8);
+          if (key >= Lk) { kf[u] = make_uint4(0u, 0u, 0u, 0u); vf[u] = kf[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UB8; u++) {
+          const int i = base + tid + 256 * u;
+          if (i < TOTAL8) {
+            const int key = i / S8R, c8 = i % S8R;
+            *reinterpret_cast<uint4*>(Ks16 + key * RSK + c8 * 8) = kf[u];
+            *reinterpret_cast<uint4*>(Vs16 + key * RSV + c8 * 8) = vf[u];
+          }
+        }
+      }
+    } else {
     constexpr int F4R = DH / 4;
     constexpr int TOTAL = LKP * F4R;
     constexpr int UB = (TOTAL / 256) < 8 ? (TOTAL / 256) : 8;     // TOTAL is a multiple of 256 for every (KT, DH)
@@ -83,6 +114,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
           *reinterpret_cast<uint2*>(Vs16 + key * RSV + c4 * 4) = w;
         }
       }
+    }
     }
   }
   __syncthreads();
@@ -118,6 +150,11 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
           sacc[kt] = mfma32_f32(Ks32[(kt * 32 + lr) * RSK + HD * lh + t], qf[t], sacc[kt]);
     } else {
       bf16x8 qh[KS];
+      if (HB) {
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+          qh[s] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(g.q) + qofs + 16 * s + 8 * lh);   // unscaled: scores are scaled below
+      } else
 #pragma unroll
       for (int s = 0; s < KS; s++) {
         const float4 f0 = hftt_load4(g.q, q_bf, qofs + 16 * s + 8 * lh);
@@ -139,6 +176,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int key = kt * 32 + acc_row32(r, lh);
+        if (HB) sacc[kt][r] *= scale;
         if (key >= Lk) sacc[kt][r] = -INFINITY;
         mx = fmaxf(mx, sacc[kt][r]);
       }
@@ -221,6 +259,21 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
       }
     }
     const long oofs = (long)seq * g.o_seq_stride + head * DH;
+    if (HB) {
+      // lanes 2i / 2i+1 hold adjacent columns: exchange so that each lane stores one packed pair (4 bytes) per register pair
+      unsigned short* op = reinterpret_cast<unsigned short*>(g.out) + oofs;
+      const bool odd = lane & 1;
+#pragma unroll
+      for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int rp = 0; rp < 8; rp++) {
+          const float own0 = oacc[n][2 * rp], own1 = oacc[n][2 * rp + 1];
+          const float y = __shfl_xor(odd ? own0 : own1, 1, 64);
+          const float lo = odd ? y : own0, hi = odd ? own1 : y;
+          const int q = qb * 32 + acc_row32(2 * rp + (odd ? 1 : 0), lh);
+          if (q < Lq) *reinterpret_cast<unsigned*>(op + (long)q * g.ldo + n * 32 + (lr & ~1)) = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+        }
+    } else {
 #pragma unroll
     for (int n = 0; n < NT; n++)
 #pragma unroll
@@ -228,32 +281,33 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
         const int q = qb * 32 + acc_row32(r, lh);
         if (q < Lq) hftt_store1(g.out, o_bf, oofs + (long)q * g.ldo + n * 32 + lr, oacc[n][r]);
       }
+    }
   }
 }
 
-template <int KT, int DH, int NPASS>
+template <int KT, int DH, int NPASS, bool HB>
 int launch_af(const hftt_attn_desc& d, hipStream_t st) {
   using Cfg = AfCfg<KT, DH, NPASS>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT, DH, NPASS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT, DH, NPASS, HB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) { hftt_set_error("attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<KT, DH, NPASS>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(256), Cfg::LDS_BYTES, st, d);
+  hipLaunchKernelGGL((attn_fwd_kernel<KT, DH, NPASS, HB>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(256), Cfg::LDS_BYTES, st, d);
   HFTT_CHECK_LAUNCH("attn_fwd");
   return 0;
 }
 
-template <int DH, int NPASS>
+template <int DH, int NPASS, bool HB>
 int dispatch_af(const hftt_attn_desc& d, hipStream_t st) {
   const int kt = (d.Lk + 31) / 32;
-  if (kt <= 1) return launch_af<1, DH, NPASS>(d, st);
-  if (kt <= 2) return launch_af<2, DH, NPASS>(d, st);
-  if (kt <= 3) return launch_af<3, DH, NPASS>(d, st);
-  if (kt <= 4) return launch_af<4, DH, NPASS>(d, st);
-  return launch_af<8, DH, NPASS>(d, st);
+  if (kt <= 1) return launch_af<1, DH, NPASS, HB>(d, st);
+  if (kt <= 2) return launch_af<2, DH, NPASS, HB>(d, st);
+  if (kt <= 3) return launch_af<3, DH, NPASS, HB>(d, st);
+  if (kt <= 4) return launch_af<4, DH, NPASS, HB>(d, st);
+  return launch_af<8, DH, NPASS, HB>(d, st);
 }
 
 }  // namespace
@@ -269,6 +323,7 @@ int hftt_attn_check(const hftt_attn_desc* d, bool bwd) {
   HFTT_REQUIRE(d->q_seq_stride % 4 == 0 && d->k_seq_stride % 4 == 0 && d->v_seq_stride % 4 == 0, "attn: seq strides must be multiples of 4");
   HFTT_REQUIRE((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 15) == 0, "attn: operands must be 16-byte aligned");
   HFTT_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "attn: drop_p out of range");
+  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1, "attn: bf16-stored tensors need npass == 1");
   if (bwd) {
     HFTT_REQUIRE(d->dout && d->dq && d->dk && d->dv, "attn_bwd: null gradient operand");
     HFTT_REQUIRE(d->lddq % 4 == 0 && d->lddk % 4 == 0 && d->lddv % 4 == 0, "attn_bwd: row strides must be multiples of 4");
@@ -281,6 +336,10 @@ extern "C" int hftt_attn_fwd(const hftt_attn_desc* d, void* stream) {
   int rc = hftt_attn_check(d, false);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->dh == 64) return d->npass == 3 ? dispatch_af<64, 3>(*d, st) : dispatch_af<64, 1>(*d, st);
-  return d->npass == 3 ? dispatch_af<32, 3>(*d, st) : dispatch_af<32, 1>(*d, st);
+  const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
+  const bool hb = (d->io_flags & all_half) == all_half && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 2 == 0 &&
+                  d->q_seq_stride % 8 == 0 && d->k_seq_stride % 8 == 0 && d->v_seq_stride % 8 == 0 && d->o_seq_stride % 2 == 0;
+  if (d->npass == 3) return d->dh == 64 ? dispatch_af<64, 3, false>(*d, st) : dispatch_af<32, 3, false>(*d, st);
+  if (d->dh == 64) return hb ? dispatch_af<64, 1, true>(*d, st) : dispatch_af<64, 1, false>(*d, st);
+  return hb ? dispatch_af<32, 1, true>(*d, st) : dispatch_af<32, 1, false>(*d, st);
 }

@@ -693,6 +693,29 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
     if (tile_end) {
       const int n0 = nt * BN;
       if (MODE != 0) __syncthreads();
+      if (MODE == 0 && c_bf) {
+        // bf16 C straight from the accumulators: lanes 2i / 2i+1 hold adjacent columns, so they swap one register each and
+        // every lane stores one packed pair (4 bytes) per register pair
+        const bool odd = lane & 1;
+        unsigned short* Cb = reinterpret_cast<unsigned short*>(g.C);
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const int col = n0 + wn * TN * 32 + j * 32 + lr;
+          const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+          for (int rp = 0; rp < 8; rp++) {
+            float own0 = acc[j][2 * rp] + bv, own1 = acc[j][2 * rp + 1] + bv;
+            acc[j][2 * rp] = 0.f; acc[j][2 * rp + 1] = 0.f;
+            if (g.act == 1) { own0 = fmaxf(own0, 0.f); own1 = fmaxf(own1, 0.f); }
+            own0 *= g.out_scale; own1 *= g.out_scale;
+            const float y = __shfl_xor(odd ? own0 : own1, 1, 64);
+            const float lo = odd ? y : own0, hi = odd ? own1 : y;
+            const long row = m0 + wm * 32 + acc_row32(2 * rp + (odd ? 1 : 0), lh);
+            const int ce = col & ~1;
+            if (row < g.M && ce < g.N) *reinterpret_cast<unsigned*>(Cb + row * g.ldc + ce) = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+          }
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         const int col_l = wn * TN * 32 + j * 32 + lr;
@@ -846,7 +869,7 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
                       (!d.ln_gamma || d.N == 256);
   if (d.N % 256 == 0 && d.K <= 768 && d.M >= 256 && vec_ok) {
     if (d.K <= 256) {       // one-shot form (measured: qkv 391 vs 518 us, o+LN 256 vs 300 us against the persistent form)
-      const bool rich = d.add_table || d.gate || d.drop_p > 0.f || d.residual || d.ln_gamma || (d.io_flags & HFTT_NT_C_BF16);
+      const bool rich = d.add_table || d.gate || d.drop_p > 0.f || d.residual || d.ln_gamma;
       if (!rich) return launch_nt_as1<64, 0>(d, st);
       if (d.N == 256) return launch_nt_as1<64, 1>(d, st);
       return launch_nt_as1<32, 2>(d, st);

@@ -50,9 +50,11 @@ TnPlan tn_plan(int M, int N, int K) {
   return p;
 }
 
-template <int TM, int TN, int NPASS>
+template <int TM, int TN, int NPASS, bool DYB = false, bool XB = false>
 struct TnCfg {
   static constexpr bool F32 = (NPASS == 3);
+  static constexpr int YE = DYB ? 8 : 4;           // elements per 16-byte global slot (bf16- or fp32-stored operand)
+  static constexpr int XE = XB ? 8 : 4;
   static constexpr int TILE_N = 128 * TM;
   static constexpr int TILE_K = 64 * TN;
   // bf16: row stride in shorts, bytes = 2*TILE + 64 == 64 (mod 128): conflict-free tr reads.  fp32: floats, 16-byte aligned rows.
@@ -63,15 +65,18 @@ struct TnCfg {
   static constexpr int X_ELEMS = BMT * RSX;
   static constexpr int BUF_ELEMS = Y_ELEMS + X_ELEMS;
   static constexpr int LDS_BYTES = 2 * BUF_ELEMS * ESZ;
-  static constexpr int YL = TILE_N / 64;    // float4 loads per thread (dY)
-  static constexpr int XL = (TILE_K + 63) / 64;   // float4 loads per thread (X)
+  static constexpr int YSPR = TILE_N / YE;         // slots per tile row
+  static constexpr int XSPR = TILE_K / XE;
+  static constexpr int YL = (BMT * YSPR + 511) / 512;   // 16-byte loads per thread
+  static constexpr int XL = (BMT * XSPR + 511) / 512;
 };
 
-template <int TM, int TN, int NPASS>
+template <int TM, int TN, int NPASS, bool DYB, bool XB>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g, const int k_tiles, const int rows_per_split,
                                                      const long nws, const long kws) {
-  using Cfg = TnCfg<TM, TN, NPASS>;
+  using Cfg = TnCfg<TM, TN, NPASS, DYB, XB>;
   constexpr bool F32 = Cfg::F32;
+  static_assert(!F32 || (!DYB && !XB), "bf16-stored operands are a bf16-mode feature");
   constexpr int RSY = Cfg::RSY, RSX = Cfg::RSX, TILE_N = Cfg::TILE_N, TILE_K = Cfg::TILE_K;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
@@ -97,53 +102,43 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  float4 yregA[Cfg::YL], xregA[Cfg::XL], yregB[Cfg::YL], xregB[Cfg::XL];   // two staging sets: loads run two steps ahead
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool dy_bf = !F32 && (g.io_flags & HFTT_TN_DY_BF16), x_bf = !F32 && (g.io_flags & HFTT_TN_X_BF16);
-  constexpr int YF4R = TILE_N / 4;   // float4 per row
-  constexpr int XF4R = TILE_K / 4;
-  const int yc4 = tid % YF4R;
-  const int ycol = n0 + yc4 * 4;
-  const bool ycol_ok = ycol < g.N;    // N % 4 == 0
-  const int ycol_c = ycol_ok ? ycol : g.N - 4;
+  uint4 yregA[Cfg::YL], xregA[Cfg::XL], yregB[Cfg::YL], xregB[Cfg::XL];   // two staging sets of raw 16-byte slots: loads run two steps ahead
+  constexpr int YE = Cfg::YE, XE = Cfg::XE, YSPR = Cfg::YSPR, XSPR = Cfg::XSPR;
+  float csum[YE];
+#pragma unroll
+  for (int e = 0; e < YE; e++) csum[e] = 0.f;
+  const int ycs = tid % YSPR;                       // this thread's slot column (fixed: 512 % YSPR == 0)
+  const int ycol = n0 + ycs * YE;
+  const bool ycol_ok = ycol < g.N;                  // N % 8 == 0 when dY is bf16-stored, % 4 otherwise
+  const int ycol_c = ycol_ok ? ycol : g.N - YE;
 
-  auto gload = [&](int step, float4 (&yreg)[Cfg::YL], float4 (&xreg)[Cfg::XL]) {
+  auto gload = [&](int step, uint4 (&yreg)[Cfg::YL], uint4 (&xreg)[Cfg::XL]) {
     const long mb = mbeg + (long)step * BMT;
 #pragma unroll
     for (int j = 0; j < Cfg::YL; j++) {
       const int i = tid + 512 * j;
-      const int row = i / YF4R;
+      const int row = i / YSPR;
       const long m = mb + row;
       // unconditional load from a clamped address + select: a branch around the load would make hipcc wait vmcnt(0) per load
       const long mc = m < mend ? m : mend - 1;
-      float4 t;
-      if (dy_bf) {      // 4 bf16 = 8 bytes (exact widening; the tile is re-rounded to the same bf16 values on the way into LDS)
-        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.dY) + mc * g.lddy + ycol_c);
-        t = make_float4(bf2f(u.x & 0xFFFFu), bf2f(u.x >> 16), bf2f(u.y & 0xFFFFu), bf2f(u.y >> 16));
-      } else {
-        t = *reinterpret_cast<const float4*>(g.dY + mc * g.lddy + ycol_c);
-      }
-      yreg[j] = (ycol_ok && m < mend) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g.dY) + (mc * g.lddy + ycol_c) * (DYB ? 2 : 4));
+      yreg[j] = (ycol_ok && m < mend && row < BMT) ? t : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
     for (int j = 0; j < Cfg::XL; j++) {
       const int i = tid + 512 * j;
-      const int row = i / XF4R, c4 = i % XF4R;
+      const int row = i / XSPR, cs = i % XSPR;
       const long m = mb + row;
-      const int col = k0 + c4 * 4;
+      const int col = k0 + cs * XE;
       const long mc = m < mend ? m : mend - 1;
-      const int cc = col < g.K ? col : g.K - 4;
-      float4 t;
-      if (x_bf) {
-        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.X) + mc * g.ldx + cc);
-        t = make_float4(bf2f(u.x & 0xFFFFu), bf2f(u.x >> 16), bf2f(u.y & 0xFFFFu), bf2f(u.y >> 16));
-      } else {
-        t = *reinterpret_cast<const float4*>(g.X + mc * g.ldx + cc);
-      }
-      xreg[j] = (row < BMT && col < g.K && m < mend) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int cc = col < g.K ? col : g.K - XE;
+      const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g.X) + (mc * g.ldx + cc) * (XB ? 2 : 4));
+      xreg[j] = (row < BMT && col < g.K && m < mend) ? t : make_uint4(0u, 0u, 0u, 0u);
     }
   };
-  auto put4 = [&](int buf, int which, int off, const float4& f) {      // which: 0 = dY tile, 1 = X tile
+  // one 16-byte slot -> LDS tile (which: 0 = dY tile, 1 = X tile) at element offset off
+  auto put_f32 = [&](int buf, int which, int off, const uint4& u) {      // fp32-stored slot: 4 elements
+    const float4 f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
     if (F32) {
       float* base = sm32 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
       *reinterpret_cast<float4*>(base + off) = f;
@@ -154,19 +149,36 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       *reinterpret_cast<uint2*>(base + off) = ph;
     }
   };
-  auto sstore = [&](int buf, const float4 (&yreg)[Cfg::YL], const float4 (&xreg)[Cfg::XL]) {
+  auto put_bf16 = [&](int buf, int which, int off, const uint4& u) {     // bf16-stored slot: 8 elements, no conversion
+    unsigned short* base = sm16 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
+    *reinterpret_cast<uint4*>(base + off) = u;
+  };
+  auto sstore = [&](int buf, const uint4 (&yreg)[Cfg::YL], const uint4 (&xreg)[Cfg::XL]) {
 #pragma unroll
     for (int j = 0; j < Cfg::YL; j++) {
       const int i = tid + 512 * j;
-      const int row = i / YF4R;
-      csum[0] += yreg[j].x; csum[1] += yreg[j].y; csum[2] += yreg[j].z; csum[3] += yreg[j].w;
-      put4(buf, 0, row * RSY + yc4 * 4, yreg[j]);
+      const int row = i / YSPR;
+      if (row < BMT) {
+        if (DYB) {
+          const unsigned w[4] = {yreg[j].x, yreg[j].y, yreg[j].z, yreg[j].w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) { csum[2 * e] += bf2f(w[e] & 0xFFFFu); csum[2 * e + 1] += bf2f(w[e] >> 16); }
+          put_bf16(buf, 0, row * RSY + ycs * 8, yreg[j]);
+        } else {
+          csum[0] += __uint_as_float(yreg[j].x); csum[1] += __uint_as_float(yreg[j].y);
+          csum[2] += __uint_as_float(yreg[j].z); csum[3] += __uint_as_float(yreg[j].w);
+          put_f32(buf, 0, row * RSY + ycs * 4, yreg[j]);
+        }
+      }
     }
 #pragma unroll
     for (int j = 0; j < Cfg::XL; j++) {
       const int i = tid + 512 * j;
-      const int row = i / XF4R, c4 = i % XF4R;
-      if (row < BMT) put4(buf, 1, row * RSX + c4 * 4, xreg[j]);
+      const int row = i / XSPR, cs = i % XSPR;
+      if (row < BMT) {
+        if (XB) put_bf16(buf, 1, row * RSX + cs * 8, xreg[j]);
+        else put_f32(buf, 1, row * RSX + cs * 4, xreg[j]);
+      }
     }
   };
 
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   __syncthreads();
   // step s computes from LDS buffer (s&1); set `cur` (stored to LDS one step ago) is refilled with step s+2, set `nxt`
   // (holding step s+1, issued one step ago) is converted into the other LDS buffer after the MFMAs
-  auto body = [&](int step, float4 (&ycur)[Cfg::YL], float4 (&xcur)[Cfg::XL], const float4 (&ynxt)[Cfg::YL], const float4 (&xnxt)[Cfg::XL]) {
+  auto body = [&](int step, uint4 (&ycur)[Cfg::YL], uint4 (&xcur)[Cfg::XL], const uint4 (&ynxt)[Cfg::YL], const uint4 (&xnxt)[Cfg::XL]) {
     const int buf = step & 1;
     if (step + 2 < nsteps) gload(step + 2, ycur, xcur);
     if (F32) {
@@ -248,16 +260,16 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       }
   // column sums of dY (bias gradient): only the k-tile-0 workgroups publish them
   if (ktile == 0) {
-    float* red = reinterpret_cast<float*>(smem);   // [512/YF4R][TILE_N]
+    float* red = reinterpret_cast<float*>(smem);   // [512/YSPR][TILE_N]
     __syncthreads();
-    const int grp = tid / YF4R;
+    const int grp = tid / YSPR;
 #pragma unroll
-    for (int e = 0; e < 4; e++) red[grp * TILE_N + yc4 * 4 + e] = csum[e];
+    for (int e = 0; e < YE; e++) red[grp * TILE_N + ycs * YE + e] = csum[e];
     __syncthreads();
     float* bslab = reinterpret_cast<float*>(g.ws) + (long)gridDim.y * nws * kws + (long)split * nws;
     for (int c = tid; c < TILE_N; c += 512) {
       float s = 0.f;
-      for (int q = 0; q < 512 / YF4R; q++) s += red[q * TILE_N + c];
+      for (int q = 0; q < 512 / YSPR; q++) s += red[q * TILE_N + c];
       bslab[n0 + c] = s;
     }
   }
@@ -311,18 +323,18 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const hftt_gemm_tn_
   }
 }
 
-template <int TM, int TN, int NPASS>
+template <int TM, int TN, int NPASS, bool DYB, bool XB>
 int launch_tn(const hftt_gemm_tn_desc& d, const TnPlan& p, hipStream_t st) {
-  using Cfg = TnCfg<TM, TN, NPASS>;
+  using Cfg = TnCfg<TM, TN, NPASS, DYB, XB>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<TM, TN, NPASS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<TM, TN, NPASS, DYB, XB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) { hftt_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
   dim3 grid((unsigned)(p.n_tiles * p.k_tiles), (unsigned)p.splits, 1);
-  hipLaunchKernelGGL((gemm_tn_kernel<TM, TN, NPASS>), grid, dim3(512), Cfg::LDS_BYTES, st, d, p.k_tiles, p.rows_per_split, p.nws, p.kws);
+  hipLaunchKernelGGL((gemm_tn_kernel<TM, TN, NPASS, DYB, XB>), grid, dim3(512), Cfg::LDS_BYTES, st, d, p.k_tiles, p.rows_per_split, p.nws, p.kws);
   HFTT_CHECK_LAUNCH("gemm_tn");
   return 0;
 }
@@ -338,8 +350,11 @@ extern "C" int64_t hftt_gemm_tn_ws_bytes(int32_t M, int32_t N, int32_t K) {
 extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   HFTT_REQUIRE(d != nullptr, "gemm_tn: null descriptor");
   HFTT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_tn: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
-  HFTT_REQUIRE(d->N % 4 == 0 && d->K % 4 == 0, "gemm_tn: N=%d and K=%d must be multiples of 4", d->N, d->K);
-  HFTT_REQUIRE(d->lddy % 4 == 0 && d->ldx % 4 == 0, "gemm_tn: leading dims must be multiples of 4");
+  {
+    const int ye = (d->io_flags & HFTT_TN_DY_BF16) ? 8 : 4, xe = (d->io_flags & HFTT_TN_X_BF16) ? 8 : 4;
+    HFTT_REQUIRE(d->N % ye == 0 && d->K % xe == 0, "gemm_tn: N=%d / K=%d must be multiples of %d / %d", d->N, d->K, ye, xe);
+    HFTT_REQUIRE(d->lddy % ye == 0 && d->ldx % xe == 0, "gemm_tn: leading dims must keep rows 16-byte aligned");
+  }
   HFTT_REQUIRE(((uintptr_t)d->dY & 15) == 0 && ((uintptr_t)d->X & 15) == 0, "gemm_tn: dY/X must be 16-byte aligned");
   HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "gemm_tn: npass must be 1 or 3");
   HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1, "gemm_tn: bf16-stored operands need npass == 1");
@@ -353,14 +368,19 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const TnPlan p = tn_plan(d->M, d->N, d->K);
   int rc;
+  const bool dyb = d->io_flags & HFTT_TN_DY_BF16, xb = d->io_flags & HFTT_TN_X_BF16;
   if (d->npass == 3) {
-    if (p.tm == 2) rc = launch_tn<2, 4, 3>(*d, p, st);
-    else if (p.tn == 2) rc = launch_tn<1, 2, 3>(*d, p, st);
-    else rc = launch_tn<1, 1, 3>(*d, p, st);
+    if (p.tm == 2) rc = launch_tn<2, 4, 3, false, false>(*d, p, st);
+    else if (p.tn == 2) rc = launch_tn<1, 2, 3, false, false>(*d, p, st);
+    else rc = launch_tn<1, 1, 3, false, false>(*d, p, st);
   } else {
-    if (p.tm == 2) rc = launch_tn<2, 4, 1>(*d, p, st);
-    else if (p.tn == 2) rc = launch_tn<1, 2, 1>(*d, p, st);
-    else rc = launch_tn<1, 1, 1>(*d, p, st);
+#define HFTT_TN_GO(TM_, TN_)                                                     \
+    (dyb ? (xb ? launch_tn<TM_, TN_, 1, true, true>(*d, p, st) : launch_tn<TM_, TN_, 1, true, false>(*d, p, st)) \
+         : (xb ? launch_tn<TM_, TN_, 1, false, true>(*d, p, st) : launch_tn<TM_, TN_, 1, false, false>(*d, p, st)))
+    if (p.tm == 2) rc = HFTT_TN_GO(2, 4);
+    else if (p.tn == 2) rc = HFTT_TN_GO(1, 2);
+    else rc = HFTT_TN_GO(1, 1);
+#undef HFTT_TN_GO
   }
   if (rc != 0) return rc;
   const long total = (long)d->N * d->K_out;

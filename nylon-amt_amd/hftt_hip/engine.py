@@ -310,7 +310,7 @@ class HfttEngine:
         esz = 2 if self.npass == 1 else 4
         nbytes = (2 if a_bf else 4) * M * K + (2 if c_bf else 4) * M * N + esz * N * K + (4 * M * N if residual else 0) + (4 * M * N if ln is not None else 0) \
             + ((2 if gate_bf else 4) * M * N if gate else 0)
-        rich = bool(add_table or gate or drop_site or residual or ln is not None or c_bf)
+        rich = bool(add_table or gate or drop_site or residual or ln is not None)
         if self.npass == 1 and N % 256 == 0 and K <= 768 and M >= 256:      # mirrors dispatch_nt_bf16 in csrc/gemm_nt.hip
             if K <= 256:
                 kname = 'gemm_nt_as1_kernel<%s>' % ('64, 0' if not rich else ('64, 1' if N == 256 else '32, 2'))
@@ -342,7 +342,7 @@ class HfttEngine:
         ws['tn'].append(dsc)
         ws['keep'].append(dsc)
         tile = '2, 4' if (N >= 256 and K >= 256) else ('1, 2' if (N >= 128 and K >= 128) else '1, 1')
-        meta = {'kernel': 'gemm_tn_kernel<%s, %d>' % (tile, self.npass), 'flops': 2.0 * M * N * K,
+        meta = {'kernel': 'gemm_tn_kernel<%s, %d, %s, %s>' % (tile, self.npass, 'true' if dy_bf else 'false', 'true' if x_bf else 'false'), 'flops': 2.0 * M * N * K,
                 'bytes': (2.0 if dy_bf else 4.0) * M * N + (2.0 if x_bf else 4.0) * M * K + 4.0 * N * K, 'shape': (M, N, K)}
         plan.append((self.lib.hftt_gemm_tn, (C.byref(dsc),), 'gemm_tn', meta))
         return dsc
@@ -374,10 +374,12 @@ class HfttEngine:
         eo = 2.0 if flags & 4 else 4.0
         qkv_bytes = n_seq * (eq * Lq + 2 * ekv * Lk) * self.d
         if bwd:
-            meta = {'kernel': 'attn_bwd_kernel<%d, %d, %d>' % (kt, dh, self.npass), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
+            hb = 'true' if (flags & 7) == 7 else 'false'
+            meta = {'kernel': 'attn_bwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
                     'bytes': qkv_bytes + n_seq * ((2.0 if flags & 8 else 4.0) * Lq + 2 * (2.0 if flags & 16 else 4.0) * Lk) * self.d + 2 * eo * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
         else:
-            meta = {'kernel': 'attn_fwd_kernel<%d, %d, %d>' % (kt, dh, self.npass), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
+            hb = 'true' if (flags & 7) == 7 else 'false'
+            meta = {'kernel': 'attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
                     'bytes': qkv_bytes + eo * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
         plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd', meta))
         return dsc
