@@ -670,6 +670,10 @@ class HfttEngine:
         self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_f_t'), 0, nGD, d)
         plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed']), 'time_embed_bwd', None))
         plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws), 'colsum', None))
+        # gradient buckets in the order they become final (flat ranges are contiguous: state_dict order is encoder,
+        # frequency decoder + heads A, time decoder + heads B): (plan length when final, flat lo, flat hi)
+        o_dec, o_time, o_end = self.poff[dd + 'pos_embedding_freq.weight'], self.poff[dd + 'pos_embedding_time.weight'], self.flat_grads.numel()
+        marks = [(len(plan), o_time, o_end)]
         # ---- frequency decoder layers, last to first.  Gradient stream lives in A (= nGD), per-sequence dq in Q1 (= nGA);
         #      the encoder-output gradient accumulates in eGA ----
         A, Bf, Cf, Q1 = nGD, nGB, nGC, nGA
@@ -739,6 +743,7 @@ class HfttEngine:
                 self._tn(plan, ws, N, d, d, dq0s, d, self.P(dd + 'pos_embedding_freq.weight'), d,
                          [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
                 self._nt(plan, ws, N, d, d, dq0s, d, self.Wp(tag + '.ca.q_t'), 0, gpos, d, residual=gpos, ldr=d)
+        marks.append((len(plan), o_dec, o_time))
         # ---- encoder layers ----
         Ge = (eGA, eGB, eGC, eGh, eGq, eGx)
         for i in reversed(range(self.Le)):
@@ -749,7 +754,9 @@ class HfttEngine:
         self._tn(plan, ws, Se, d, self.Kp, eGA, d, b['win'].data_ptr(), self.Kp, [(0, d, self.dweff.data_ptr(), self.dbeff.data_ptr())],
                  out_scale=math.sqrt(d))
         plan.append((self.lib.hftt_embed_fold_bwd, (C.byref(self.fold),), 'embed_fold_bwd', None))
+        marks.append((len(plan), 0, o_dec))
         ws['bwd'] = plan
+        ws['bwd_marks'] = marks
 
     # ------------------------------------------------------------------ running plans
     def _run(self, ws, plan, stream, outs=None, seed=0, p=0.0):
@@ -834,9 +841,12 @@ class HfttEngine:
         ws['generation'] = self.generation
         return tuple(outs)
 
-    def backward(self, B, generation=None):
+    def backward(self, B, generation=None, on_ready=None):
         """Backward through the most recent forward of batch size B; the gradients of the 8 outputs must be in
-        the 'd.*' workspace buffers.  Fills flat_grads (every parameter written exactly once)."""
+        the 'd.*' workspace buffers.  Fills flat_grads (every parameter written exactly once).
+        on_ready(lo, hi), if given, is called three times, each as soon as every launch that writes flat_grads[lo:hi] has
+        been enqueued (time decoder, frequency decoder, encoder): the data-parallel all-reduce of that range can then
+        overlap the rest of the backward (hftt_hip/ddp.py)."""
         ws = self._ws.get(B)
         if ws is None or 'outs' not in ws:
             raise _capi.HfttError('backward called without a forward')
@@ -845,7 +855,14 @@ class HfttEngine:
         self._cur_ws = ws
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._patch(ws, ws['p'], ws['seed'])
-        self._run(ws, ws['bwd'], stream, outs=ws['outs'], seed=ws['seed'], p=ws['p'])
+        if on_ready is None:
+            self._run(ws, ws['bwd'], stream, outs=ws['outs'], seed=ws['seed'], p=ws['p'])
+            return
+        start = 0
+        for end, lo, hi in ws['bwd_marks']:
+            self._run(ws, ws['bwd'][start:end], stream, outs=ws['outs'], seed=ws['seed'], p=ws['p'])
+            on_ready(lo, hi)
+            start = end
 
     # ------------------------------------------------------------------ fused loss (training/train.py:141-153)
     def loss(self, B, labels, weight_A=1.0, weight_B=1.0, with_grad=True):

@@ -58,7 +58,7 @@ class TrainStep:
         B = spec.shape[0]
         eng.forward(spec, training=self.model.training)
         loss = eng.loss(B, (label_onset, label_offset, label_mpe, label_velocity), self.weight_A, self.weight_B, with_grad=True)
-        eng.backward(B)
+        eng.backward(B, on_ready=getattr(self.grad_sync, 'bucket_ready', None))
         return loss
 
     def __call__(self, spec, label_onset, label_offset, label_mpe, label_velocity):

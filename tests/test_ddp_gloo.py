@@ -48,6 +48,20 @@ def _worker(rank, world, port, tmp):
     sync = FlatGradSync(eng, world, buckets=3)
     scale = sync(eng.flat_grads)
     avg = eng.flat_grads * scale
+    # overlapped mode: the engine hands over three ranges as they become final (here: after the fact, any order)
+    eng2 = _FakeEngine(flat.numel())
+    eng2.flat_grads.copy_(torch.cat([sd[n_].grad.reshape(-1) for n_ in names]))
+    sync2 = FlatGradSync(eng2, world)
+    n_all = flat.numel()
+    for lo, hi in ((n_all // 2, n_all), (n_all // 5, n_all // 2), (0, n_all // 5)):
+        sync2.bucket_ready(lo, hi)
+    assert sync2(eng2.flat_grads) == scale and torch.equal(eng2.flat_grads * scale, avg)
+    sync2.bucket_ready(0, 10)                            # a step that forgot a range must not pass silently
+    try:
+        sync2(eng2.flat_grads)
+        raise AssertionError('missing range not detected')
+    except RuntimeError:
+        pass
     if rank == 0:
         sd_full = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
         O.spec2midi_loss(O.model_forward(sd_full, x, cfg), *labels).backward()

@@ -209,6 +209,39 @@ def test_dropout_training_mode(dev):
     assert all(max_err(p, q) == 0.0 for p, q in zip(a, b))
 
 
+def test_backward_reports_gradient_buckets_when_final(dev):
+    """HfttEngine.backward(on_ready=...) (the hook hftt_hip/ddp.py overlaps its all-reduce on): the three flat ranges tile
+    the gradient buffer, and each range already holds its final value at the moment it is reported (stream-ordered
+    snapshot), with dropout on so every backward launch is in the plan."""
+    from hftt_hip.trainer import TrainStep
+    cfg, B = MINI, 2
+    model = util.build_model(cfg, 5, dropout=0.1).to(dev)
+    model.train()
+    ts = TrainStep(model, lr=1e-3)
+    eng = ts.engine
+    x = (O.synth_spec(B, cfg, salt=3) * 0.5).to(dev)
+    ld = _to_dev(O.synth_labels(B, cfg, salt=4), dev)
+    ts.forward_backward(x, *ld)                      # builds the plans
+    eng.forward(x, training=True)
+    eng.loss(B, ld, 1.0, 1.0, with_grad=True)
+    eng.flat_grads.fill_(float('nan'))
+    snaps = []
+    eng.backward(B, on_ready=lambda lo, hi: snaps.append((lo, hi, eng.flat_grads[lo:hi].clone())))
+    torch.cuda.synchronize()
+    assert [s[0] for s in snaps] == sorted((s[0] for s in snaps), reverse=True)        # time, freq decoder, encoder
+    pos = 0
+    final = eng.flat_grads.clone()
+    for lo, hi, snap in sorted(snaps, key=lambda s: s[0]):
+        assert lo == pos
+        pos = hi
+        for (name, _, o, n) in eng._bound:           # alignment padding between parameters is never written
+            if lo <= o < hi:
+                assert o + n <= hi
+                assert torch.isfinite(snap[o - lo:o - lo + n]).all(), name
+                assert torch.equal(snap[o - lo:o - lo + n], final[o:o + n]), name
+    assert pos == eng.flat_grads.numel() and len(snaps) == 3
+
+
 def test_pickle_roundtrip_and_amt_transcript(dev, tmp_path):
     """m_training.py:372-392 (pickle.dump(model), torch.save) and amt.py:21-27,66-118 (pickle.load -> .to -> .eval -> transcript)."""
     from model.amt import AMT
