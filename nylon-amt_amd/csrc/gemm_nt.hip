@@ -562,7 +562,7 @@ int launch_nt_as(const hftt_gemm_nt_desc& d, hipStream_t st) {
 //           residual, LayerNorm with float4 traffic);
 //   MODE 2  staged, several N tiles (BM = 32): same row pass per N tile, staged in the weight ring.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM_, int MODE>
+template <int BM_, int MODE, bool EW = false>
 __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_desc g) {
   constexpr int BN = 256;
   constexpr int WM = (BM_ == 32) ? 1 : 2;
@@ -702,17 +702,35 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
         for (int j = 0; j < TN; j++) {
           const int col = n0 + wn * TN * 32 + j * 32 + lr;
           const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+          unsigned rbase = (unsigned)(wm * 32 + 4 * lh);
+          if (EW) asm volatile("" : "+v"(rbase));       // opaque: keeps the per-row 64-bit index terms from being hoisted out of the k loop
+          const uint64_t ebase = (uint64_t)(m0 + rbase) * (unsigned)g.N + (unsigned)col;
 #pragma unroll
           for (int rp = 0; rp < 8; rp++) {
             float own0 = acc[j][2 * rp] + bv, own1 = acc[j][2 * rp + 1] + bv;
             acc[j][2 * rp] = 0.f; acc[j][2 * rp + 1] = 0.f;
             if (g.act == 1) { own0 = fmaxf(own0, 0.f); own1 = fmaxf(own1, 0.f); }
             own0 *= g.out_scale; own1 *= g.out_scale;
+            if (EW && g.drop_p > 0.f) {    // elementwise extras stay in registers (no staging pass): dropout on the own elements ...
+              // element index = row * N + col; acc_row32(r, lh) = (r & 3) + 8 * (r >> 2) + 4 * lh, so only a scalar multiple of N varies
+              const uint64_t i0 = ebase + (uint64_t)((unsigned)(((2 * rp) & 3) + 8 * ((2 * rp) >> 2)) * (unsigned)g.N);
+              own0 = hftt_keep(g.drop_seed, g.drop_site, i0, thr) ? own0 * inv_keep : 0.f;
+              own1 = hftt_keep(g.drop_seed, g.drop_site, i0 + (unsigned)g.N, thr) ? own1 * inv_keep : 0.f;
+            }
             const float y = __shfl_xor(odd ? own0 : own1, 1, 64);
-            const float lo = odd ? y : own0, hi = odd ? own1 : y;
-            const long row = m0 + wm * 32 + acc_row32(2 * rp + (odd ? 1 : 0), lh);
+            float lo = odd ? y : own0, hi = odd ? own1 : y;
+            const long row = m0 + rbase + (((2 * rp) & 3) + 8 * ((2 * rp) >> 2)) + (odd ? 1 : 0);     // = acc_row32(2 * rp + odd, lh)
             const int ce = col & ~1;
-            if (row < g.M && ce < g.N) *reinterpret_cast<unsigned*>(Cb + row * g.ldc + ce) = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+            const bool ok = row < g.M && ce < g.N;
+            if (EW && g.gate != nullptr) { // ... and the bf16 ReLU gate as one packed pair per lane, same footprint as the store
+              const long rc = row < g.M ? row : (long)g.M - 1;
+              const int cc = ce < g.N ? ce : 0;
+              const unsigned gp = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(g.gate) + rc * g.ldg + cc);
+              lo = bf2f((unsigned short)(gp & 0xffffu)) > 0.f ? lo * g.gate_scale : 0.f;
+              hi = bf2f((unsigned short)(gp >> 16)) > 0.f ? hi * g.gate_scale : 0.f;
+            }
+            if (ok) *reinterpret_cast<unsigned*>(Cb + row * g.ldc + ce) = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+            if (EW) __builtin_amdgcn_sched_barrier(0);      // keep the 64-bit hash chains of different pairs from overlapping (registers)
           }
         }
       } else
@@ -807,20 +825,20 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
   }
 }
 
-template <int BM_, int MODE>
+template <int BM_, int MODE, bool EW = false>
 int launch_nt_as1(const hftt_gemm_nt_desc& d, hipStream_t st) {
   int lds = (BM_ * (d.K + 8) + 2 * 256 * 40) * 2;
   const int stage = BM_ * 260 * 4;
   if (MODE == 1 && stage > lds) lds = stage;
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_as1_kernel<BM_, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_as1_kernel<BM_, MODE, EW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { hftt_set_error("gemm_nt: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e)); return 2; }
     attr_lds = lds;
   }
   dim3 grid((unsigned)((d.M + BM_ - 1) / BM_), 1, 1);
-  hipLaunchKernelGGL((gemm_nt_as1_kernel<BM_, MODE>), grid, dim3(512), lds, st, d);
+  hipLaunchKernelGGL((gemm_nt_as1_kernel<BM_, MODE, EW>), grid, dim3(512), lds, st, d);
   HFTT_CHECK_LAUNCH("gemm_nt");
   return 0;
 }
@@ -871,6 +889,10 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
     if (d.K <= 256) {       // one-shot form (measured: qkv 391 vs 518 us, o+LN 256 vs 300 us against the persistent form)
       const bool rich = d.add_table || d.gate || d.drop_p > 0.f || d.residual || d.ln_gamma;
       if (!rich) return launch_nt_as1<64, 0>(d, st);
+      // dropout / bf16 ReLU gate on a bf16 C are elementwise: they ride in the direct packed-store epilogue (no staging pass)
+      const bool elementwise = !d.add_table && !d.residual && !d.ln_gamma && (d.io_flags & HFTT_NT_C_BF16) && d.ldc % 2 == 0 &&
+                               (!d.gate || ((d.io_flags & HFTT_NT_GATE_BF16) && d.ldg % 2 == 0));
+      if (elementwise) return launch_nt_as1<64, 0, true>(d, st);
       if (d.N == 256) return launch_nt_as1<64, 1>(d, st);
       return launch_nt_as1<32, 2>(d, st);
     }

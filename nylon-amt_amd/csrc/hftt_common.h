@@ -101,11 +101,19 @@ __device__ __forceinline__ void hftt_store1(float* base, bool bf, long off, floa
 
 // ---- counter-based dropout RNG: keep(seed, site, element index) -- identical in forward and backward ----
 __device__ __forceinline__ uint32_t hftt_hash(uint64_t seed, uint32_t site, uint64_t idx) {
-  uint64_t x = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1u) + seed;
-  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-  x ^= x >> 27; x *= 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return (uint32_t)(x >> 32);
+  // key: one splitmix64 round over (seed, site) -- wave-uniform, so it runs on the scalar ALU once per kernel
+  uint64_t k = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1u);
+  k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull;
+  k ^= k >> 27; k *= 0x94D049BB133111EBull;
+  k ^= k >> 31;
+  // per element: a 32-bit two-multiply mixer (64-bit multiplies cost ~4x on the vector ALU and the dropout sites hash
+  // ~2e9 elements per paper-size step); the high index word only matters beyond 2^32 elements per site
+  const uint32_t hi = (uint32_t)(idx >> 32);
+  uint32_t x = ((uint32_t)idx + (uint32_t)k) ^ (hi ^ (hi << 16));
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x ^= (uint32_t)(k >> 32); x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
 }
 // keep threshold: keep iff hash < thr, thr = (1-p)*2^32 (clamped)
 __host__ __device__ inline uint32_t hftt_keep_thr(float p) {

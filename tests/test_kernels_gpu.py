@@ -226,6 +226,14 @@ def test_gemm_nt_bf16_storage(dev, M, N, K):
     out = ops.gemm_nt(A.float().to(dev), W.to(dev), None, npass=1, gate=gate.to(dev), gate_scale=2.0, residual=res.to(dev), out_dtype=torch.bfloat16)
     ref = torch.where(gate.double() > 0, (lin - b.double()) * 2.0, torch.zeros((), dtype=torch.float64)) + res.double()
     assert rel_err(out.float(), ref) < 5e-3
+    # elementwise extras on a bf16 C (ReLU + dropout; bf16 ReLU gate): the direct packed-store epilogue when N % 256 == 0 and K <= 256
+    out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=1, act=1, drop_p=0.25, drop_site=7, drop_seed=99, out_dtype=torch.bfloat16)
+    keep = util.keep_mask_t(99, 7, (M, N), 0.25)
+    ref = torch.where(keep, torch.relu(lin) / 0.75, torch.zeros((), dtype=torch.float64))
+    assert rel_err(out.float(), ref) < 5e-3 and ((out.float().cpu() == 0) >= ~keep).all()
+    out = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=1, gate=gate.to(dev), gate_scale=1.5, out_dtype=torch.bfloat16)
+    ref = torch.where(gate.double() > 0, (lin - b.double()) * 1.5, torch.zeros((), dtype=torch.float64))
+    assert rel_err(out.float(), ref) < 5e-3 and ((out.float().cpu() == 0) >= (gate <= 0)).all()
     if N == 256:
         gam = torch.randn(N, generator=g); bet = torch.randn(N, generator=g)
         o, pre, mean, rstd = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=1, residual=res.to(dev), ln=(gam.to(dev), bet.to(dev)))
