@@ -240,8 +240,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
           }
           dot = df.x * of.x + df.y * of.y + df.z * of.z + df.w * of.w;
         }
-#pragma unroll
-        for (int o = QSLOT / 2; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        dot = group_sum<QSLOT>(dot);
         if (cs == 0) {
           delta_s[row] = dot;
           lse_s[row] = pl0[u];
@@ -349,11 +348,9 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         const bool odd = lane & 1;
 #pragma unroll
         for (int rp = 0; rp < 2; rp++) {
-          const float own0 = a4[2 * rp], own1 = a4[2 * rp + 1];
-          const float y = __shfl_xor(odd ? own0 : own1, 1, 64);
-          const float lo = odd ? y : own0, hi = odd ? own1 : y;
+          const unsigned pk = pair_rows_to_cols(a4[2 * rp], a4[2 * rp + 1], odd);
           const int q = qb * 32 + qh2 * 16 + gi * 4 + 2 * rp + (odd ? 1 : 0);
-          if (q < Lq) *reinterpret_cast<unsigned*>(dqp + (long)q * g.lddq + ct * 16 + ((lane & 15) & ~1)) = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+          if (q < Lq) *reinterpret_cast<unsigned*>(dqp + (long)q * g.lddq + ct * 16 + ((lane & 15) & ~1)) = pk;
         }
       } else {
 #pragma unroll

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
         if (key >= Lk) sacc[kt][r] = -INFINITY;
         mx = fmaxf(mx, sacc[kt][r]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor32_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
         sacc[kt][r] = p;
         sum += p;
       }
-    sum += __shfl_xor(sum, 32, 64);
+    sum = xor32_sum(sum);
     const float inv = 1.0f / sum;
     if (lh == 0 && qrow < Lq) {      // row statistics for the backward recompute: P = exp(s - max) * inv  (bitwise the forward P)
       float* st = g.lse + (((long)seq * g.n_heads + head) * Lq + qrow) * 2;
@@ -267,11 +267,9 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
       for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int rp = 0; rp < 8; rp++) {
-          const float own0 = oacc[n][2 * rp], own1 = oacc[n][2 * rp + 1];
-          const float y = __shfl_xor(odd ? own0 : own1, 1, 64);
-          const float lo = odd ? y : own0, hi = odd ? own1 : y;
+          const unsigned pk = pair_rows_to_cols(oacc[n][2 * rp], oacc[n][2 * rp + 1], odd);
           const int q = qb * 32 + acc_row32(2 * rp + (odd ? 1 : 0), lh);
-          if (q < Lq) *reinterpret_cast<unsigned*>(op + (long)q * g.ldo + n * 32 + (lr & ~1)) = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+          if (q < Lq) *reinterpret_cast<unsigned*>(op + (long)q * g.ldo + n * 32 + (lr & ~1)) = pk;
         }
     } else {
 #pragma unroll

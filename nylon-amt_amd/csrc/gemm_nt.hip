@@ -7,6 +7,7 @@
 //   npass == 3 ("parity"): operands stay fp32 in LDS (rows of 33 floats: conflict-free ds_read_b32), weights come as a
 //                         prepared fp32 matrix; v_mfma_f32_32x32x2_f32 = exact fp32 FMA chains (<= 1e-3 parity mode).
 #include <stdlib.h>
+#include <type_traits>
 #include "hftt_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
@@ -562,7 +563,7 @@ int launch_nt_as(const hftt_gemm_nt_desc& d, hipStream_t st) {
 //           residual, LayerNorm with float4 traffic);
 //   MODE 2  staged, several N tiles (BM = 32): same row pass per N tile, staged in the weight ring.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM_, int MODE, bool EW = false>
+template <int BM_, int MODE, bool EW = false, int PF = 1>
 __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_desc g) {
   constexpr int BN = 256;
   constexpr int WM = (BM_ == 32) ? 1 : 2;
@@ -590,79 +591,89 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
   const int steps = NT * KT;
   const unsigned short* Wb = reinterpret_cast<const unsigned short*>(g.W);
 
-  uint4 wreg[WCH] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
-  auto wload = [&](int s) {
+  // weight tiles travel global -> registers -> LDS ring; the global load of tile s + PF is issued at step s into one of PF
+  // register sets, so an L2 round trip (~700 ns) has PF steps of MFMA work to hide behind
+  uint4 wr[PF][WCH];
+#pragma unroll
+  for (int i = 0; i < PF; i++)
+#pragma unroll
+    for (int j = 0; j < WCH; j++) wr[i][j] = make_uint4(0u, 0u, 0u, 0u);
+  auto wload = [&](uint4 (&w)[WCH], int s) {
     const int nt = s / KT, kt = s - nt * KT;
 #pragma unroll
     for (int j = 0; j < WCH; j++) {
       const int i = tid + 512 * j;
       const int row = i >> 2, ch = i & 3;
-      wreg[j] = *reinterpret_cast<const uint4*>(Wb + (long)(nt * BN + row) * K + kt * 32 + ch * 8);
+      w[j] = *reinterpret_cast<const uint4*>(Wb + (long)(nt * BN + row) * K + kt * 32 + ch * 8);
     }
   };
-  auto wstore = [&](int buf) {
+  auto a_off = [&](int row, int c8) { return row * RSA + (c8 << 3); };
+  auto w_off = [&](int row, int ch) { return row * RSW + (ch << 3); };
+  auto wstore = [&](const uint4 (&w)[WCH], int buf) {
 #pragma unroll
     for (int j = 0; j < WCH; j++) {
       const int i = tid + 512 * j;
       const int row = i >> 2, ch = i & 3;
-      *reinterpret_cast<uint4*>(Ws + buf * W_ELEMS + row * RSW + ch * 8) = wreg[j];
+      *reinterpret_cast<uint4*>(Ws + buf * W_ELEMS + w_off(row, ch)) = w[j];
     }
   };
-  wload(0);
+#pragma unroll
+  for (int i = 0; i < PF; i++) wload(wr[i], i < steps ? i : steps - 1);
   const bool a_bf = g.io_flags & HFTT_NT_A_BF16, c_bf = g.io_flags & HFTT_NT_C_BF16, gate_bf = g.io_flags & HFTT_NT_GATE_BF16;
   if (a_bf) {                                      // A stored as bf16: 16-byte chunks straight into LDS
+    // thread t owns 16-byte chunks t, t + 512, ... of the BM_ x K block (row-major); (row, chunk) advance incrementally --
+    // one integer division per thread instead of one per load (the index math was ~20 % of this kernel's VALU time)
     const int c8r = K >> 3;
     const int total = BM_ * c8r;
+    const int drow = 512 / c8r, dc8 = 512 - drow * c8r;
+    int row = tid / c8r, c8 = tid - row * c8r;
     for (int base = 0; base < total; base += 512 * 8) {
       uint4 v[8];
+      int rr[8], cc[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int i = base + tid + 512 * u;
-        const int ic = i < total ? i : total - 1;
-        const int row = ic / c8r, c8 = ic - row * c8r;
+        rr[u] = row; cc[u] = c8;
+        const bool in = row < BM_;
         const long grow = m0 + row;
-        const long gr = grow < g.M ? grow : (long)g.M - 1;
+        const long gr = (in && grow < g.M) ? grow : (m0 < g.M ? m0 : 0);
         const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.A) + gr * g.lda + c8 * 8);
-        v[u] = (i < total && grow < g.M) ? t : make_uint4(0u, 0u, 0u, 0u);
+        v[u] = (in && grow < g.M) ? t : make_uint4(0u, 0u, 0u, 0u);
+        row += drow; c8 += dc8;
+        if (c8 >= c8r) { c8 -= c8r; row++; }
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = base + tid + 512 * u;
-        if (i < total) {
-          const int row = i / c8r, c8 = i - row * c8r;
-          *reinterpret_cast<uint4*>(As + row * RSA + c8 * 8) = v[u];
-        }
-      }
+      for (int u = 0; u < 8; u++)
+        if (rr[u] < BM_) *reinterpret_cast<uint4*>(As + a_off(rr[u], cc[u])) = v[u];
     }
   } else {
     const int f4r = K >> 2;
     const int total = BM_ * f4r;
+    const int drow = 512 / f4r, dc4 = 512 - drow * f4r;
+    int row = tid / f4r, c4 = tid - row * f4r;
     for (int base = 0; base < total; base += 512 * 8) {
       float4 v[8];
+      int rr[8], cc[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int i = base + tid + 512 * u;
-        const int ic = i < total ? i : total - 1;          // clamped: loads stay unconditional (no branch, no early vmcnt wait)
-        const int row = ic / f4r, c4 = ic - row * f4r;
+        rr[u] = row; cc[u] = c4;
+        const bool in = row < BM_;                         // clamped address: loads stay unconditional (no branch, no early vmcnt wait)
         const long grow = m0 + row;
-        const long gr = grow < g.M ? grow : (long)g.M - 1;
+        const long gr = (in && grow < g.M) ? grow : (m0 < g.M ? m0 : 0);
         const float4 t = *reinterpret_cast<const float4*>(g.A + gr * g.lda + c4 * 4);
-        v[u] = (i < total && grow < g.M) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = (in && grow < g.M) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        row += drow; c4 += dc4;
+        if (c4 >= f4r) { c4 -= f4r; row++; }
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = base + tid + 512 * u;
-        if (i < total) {
-          const int row = i / f4r, c4 = i - row * f4r;
-          uint2 ph;
-          ph.x = f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
-          ph.y = f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
-          *reinterpret_cast<uint2*>(As + row * RSA + c4 * 4) = ph;
+      for (int u = 0; u < 8; u++)
+        if (rr[u] < BM_) {
+          typedef __bf16 bf4_t __attribute__((ext_vector_type(4)));
+          const f32x4 fv = {v[u].x, v[u].y, v[u].z, v[u].w};
+          *reinterpret_cast<uint2*>(As + a_off(rr[u], cc[u] >> 1) + (cc[u] & 1) * 4) = __builtin_bit_cast(uint2, __builtin_convertvector(fv, bf4_t));
         }
-      }
     }
   }
-  wstore(0);
+  wstore(wr[0], 0);
   __syncthreads();
 
   f32x16 acc[TN];
@@ -674,83 +685,112 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
 
-  int nt = 0, kt = 0;
-  for (int s = 0; s < steps; s++) {
-    const int buf = s & 1;
-    if (s + 1 < steps) wload(s + 1);
-    const unsigned short* Wt = Ws + buf * W_ELEMS;
+  // per k step u of an unrolled group of PF (so the register sets are named statically; PF must divide K / 32): set u held tile s
+  // (already in the ring) and receives tile s + PF; set u + 1 holds tile s + 1, written to the ring once this step's MFMAs are issued
+  constexpr int U = PF;
+  int s = 0;
+  for (int nt = 0; nt < NT; nt++) {
+    for (int kt0 = 0; kt0 < KT; kt0 += U) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const bf16x8 a = lds_read_b128(As + (wm * 32 + lr) * RSA + kt * 32 + ks * 16 + lh * 8);
+      for (int u = 0; u < U; u++) {
+        const int kt = kt0 + u;
+        uint4 (&wl)[WCH] = wr[u];
+        const uint4 (&wnext)[WCH] = wr[(u + 1) % PF];
+        const int buf = (U % 2 == 0) ? (u & 1) : (s & 1);
+        // unconditional (index clamped to the last tile): a load inside a conditional block makes hipcc's s_waitcnt insertion
+        // fall back to vmcnt(0) at the ring write, which would drain the younger prefetch too
+        wload(wl, s + PF < steps ? s + PF : steps - 1);
+        const unsigned short* Wt = Ws + buf * W_ELEMS;
 #pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const bf16x8 b = lds_read_b128(Wt + (wn * TN * 32 + j * 32 + lr) * RSW + ks * 16 + lh * 8);
-        acc[j] = mfma32(a, b, acc[j]);
+        for (int ks = 0; ks < 2; ks++) {
+          const bf16x8 a = lds_read_b128(As + (wm * 32 + lr) * RSA + kt * 32 + ks * 16 + lh * 8);
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            const bf16x8 b = lds_read_b128(Wt + (wn * TN * 32 + j * 32 + lr) * RSW + ks * 16 + lh * 8);
+            acc[j] = mfma32(a, b, acc[j]);
+          }
+        }
+        const bool tile_end = (kt == KT - 1);
+        if (MODE == 0) wstore(wnext, buf ^ 1);            // past the last tile this rewrites a dead buffer
+        else if (!tile_end && s + 1 < steps) wstore(wnext, buf ^ 1);
+        if (!tile_end) {
+          __syncthreads();
+          s++;
+        }
       }
     }
-    const bool tile_end = (kt == KT - 1);
-    if ((!tile_end || MODE == 0) && s + 1 < steps) wstore(buf ^ 1);
-    if (tile_end) {
+    {                                  // N tile finished: s = its last step, tile s + 1 (if any) sits in set 0
+      const int buf = s & 1;
       const int n0 = nt * BN;
       if (MODE != 0) __syncthreads();
       if (MODE == 0 && c_bf) {
-        // bf16 C straight from the accumulators: lanes 2i / 2i+1 hold adjacent columns, so they swap one register each and
-        // every lane stores one packed pair (4 bytes) per register pair
+        // bf16 C straight from the accumulators: lanes 2i / 2i+1 hold adjacent columns and every lane two rows per register pair;
+        // pair_rows_to_cols() (cvt_pk + DPP + byte permute) gives each lane one packed pair of adjacent columns = one 4-byte store.
+        // Instruction count matters here: the VALU, not HBM, was the busiest unit of this kernel (SQ_ACTIVE_INST_VALU ~ 48 %).
         const bool odd = lane & 1;
         unsigned short* Cb = reinterpret_cast<unsigned short*>(g.C);
+        const float lo_clamp = (g.act == 1) ? 0.f : -INFINITY;
+        const bool gated = EW && g.gate != nullptr;
+        const float oscale = gated ? g.out_scale * g.gate_scale : g.out_scale;
+        auto tile_out = [&](auto full_c) {
+          constexpr bool FULL = decltype(full_c)::value;       // every row of the block is inside M: no per-store bounds test
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-          const int col = n0 + wn * TN * 32 + j * 32 + lr;
-          const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
-          unsigned rbase = (unsigned)(wm * 32 + 4 * lh);
-          if (EW) asm volatile("" : "+v"(rbase));       // opaque: keeps the per-row 64-bit index terms from being hoisted out of the k loop
-          const uint64_t ebase = (uint64_t)(m0 + rbase) * (unsigned)g.N + (unsigned)col;
+          for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * TN * 32 + j * 32 + lr;
+            const float bv = (g.bias != nullptr) ? g.bias[col] : 0.f;
+            unsigned rbase = (unsigned)(wm * 32 + 4 * lh);
+            asm volatile("" : "+v"(rbase));       // opaque: keeps the per-row address / index terms from being hoisted out of the k loop
+            const uint64_t ebase = (uint64_t)(m0 + rbase) * (unsigned)g.N + (unsigned)col;
+            const long row0 = m0 + rbase + (odd ? 1 : 0);
+            const long row0c = FULL ? row0 : (row0 < g.M ? row0 : (long)g.M - 1);
+            unsigned short* cp = Cb + row0 * g.ldc + (col & ~1);
+            const unsigned short* gpt = reinterpret_cast<const unsigned short*>(g.gate) + row0c * g.ldg + (col & ~1);
 #pragma unroll
-          for (int rp = 0; rp < 8; rp++) {
-            float own0 = acc[j][2 * rp] + bv, own1 = acc[j][2 * rp + 1] + bv;
-            acc[j][2 * rp] = 0.f; acc[j][2 * rp + 1] = 0.f;
-            if (g.act == 1) { own0 = fmaxf(own0, 0.f); own1 = fmaxf(own1, 0.f); }
-            own0 *= g.out_scale; own1 *= g.out_scale;
-            if (EW && g.drop_p > 0.f) {    // elementwise extras stay in registers (no staging pass): dropout on the own elements ...
-              // element index = row * N + col; acc_row32(r, lh) = (r & 3) + 8 * (r >> 2) + 4 * lh, so only a scalar multiple of N varies
-              const uint64_t i0 = ebase + (uint64_t)((unsigned)(((2 * rp) & 3) + 8 * ((2 * rp) >> 2)) * (unsigned)g.N);
-              own0 = hftt_keep(g.drop_seed, g.drop_site, i0, thr) ? own0 * inv_keep : 0.f;
-              own1 = hftt_keep(g.drop_seed, g.drop_site, i0 + (unsigned)g.N, thr) ? own1 * inv_keep : 0.f;
+            for (int rp = 0; rp < 8; rp++) {
+              constexpr int dummy = 0; (void)dummy;
+              const int rofs = ((2 * rp) & 3) + 8 * ((2 * rp) >> 2);     // acc_row32(2 * rp, lh) - 4 * lh: the even register's row
+              float own0 = fmaxf(acc[j][2 * rp] + bv, lo_clamp) * oscale, own1 = fmaxf(acc[j][2 * rp + 1] + bv, lo_clamp) * oscale;
+              acc[j][2 * rp] = 0.f; acc[j][2 * rp + 1] = 0.f;
+              if (EW && g.drop_p > 0.f) {    // elementwise extras stay in registers (no staging pass): dropout on the own elements ...
+                const uint64_t i0 = ebase + (uint64_t)((unsigned)rofs * (unsigned)g.N);      // element index = row * N + col
+                own0 = hftt_keep(g.drop_seed, g.drop_site, i0, thr) ? own0 * inv_keep : 0.f;
+                own1 = hftt_keep(g.drop_seed, g.drop_site, i0 + (unsigned)g.N, thr) ? own1 * inv_keep : 0.f;
+              }
+              unsigned pk = pair_rows_to_cols(own0, own1, odd);
+              const bool ok = FULL || (row0 + rofs < g.M);
+              if (gated) {                   // ... and the bf16 ReLU gate as one packed pair per lane, same footprint as the store
+                const unsigned gp = *reinterpret_cast<const unsigned*>(gpt + (ok ? (long)rofs * g.ldg : 0L));
+                // keep a half iff its gate is a positive bf16: bits in [0x0001, 0x7FFF]
+                const unsigned m = (((gp & 0xFFFFu) - 1u) < 0x7FFFu ? 0x0000FFFFu : 0u) | ((((gp >> 16) - 1u) < 0x7FFFu) ? 0xFFFF0000u : 0u);
+                pk &= m;
+              }
+              if (ok) *reinterpret_cast<unsigned*>(cp + (long)rofs * g.ldc) = pk;
+              if (EW) __builtin_amdgcn_sched_barrier(0);      // keep the hash chains of different pairs from overlapping (registers)
             }
-            const float y = __shfl_xor(odd ? own0 : own1, 1, 64);
-            float lo = odd ? y : own0, hi = odd ? own1 : y;
-            const long row = m0 + rbase + (((2 * rp) & 3) + 8 * ((2 * rp) >> 2)) + (odd ? 1 : 0);     // = acc_row32(2 * rp + odd, lh)
-            const int ce = col & ~1;
-            const bool ok = row < g.M && ce < g.N;
-            if (EW && g.gate != nullptr) { // ... and the bf16 ReLU gate as one packed pair per lane, same footprint as the store
-              const long rc = row < g.M ? row : (long)g.M - 1;
-              const int cc = ce < g.N ? ce : 0;
-              const unsigned gp = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(g.gate) + rc * g.ldg + cc);
-              lo = bf2f((unsigned short)(gp & 0xffffu)) > 0.f ? lo * g.gate_scale : 0.f;
-              hi = bf2f((unsigned short)(gp >> 16)) > 0.f ? hi * g.gate_scale : 0.f;
-            }
-            if (ok) *reinterpret_cast<unsigned*>(Cb + row * g.ldc + ce) = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-            if (EW) __builtin_amdgcn_sched_barrier(0);      // keep the 64-bit hash chains of different pairs from overlapping (registers)
           }
-        }
+        };
+        if (m0 + BM_ <= (long)g.M) tile_out(std::true_type{}); else tile_out(std::false_type{});
       } else
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         const int col_l = wn * TN * 32 + j * 32 + lr;
         const int col = n0 + col_l;
-        const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+        const float bv = (g.bias != nullptr) ? g.bias[col] : 0.f;       // N % 256 == 0 on this path: every column exists
+        const float lo_clamp = (g.act == 1) ? 0.f : -INFINITY;
+        int rb0 = wm * 32 + 4 * lh;
+        if (MODE == 0) asm volatile("" : "+v"(rb0));     // opaque: the 16 row addresses are formed here, not hoisted above the k loop
+        float* cp = g.C + (m0 + rb0) * g.ldc + col;
+        float* sp = stage + rb0 * STAGE_LD + col_l;
+        const bool full = m0 + BM_ <= (long)g.M;           // block-uniform
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int row_l = wm * 32 + acc_row32(r, lh);
-          float v = acc[j][r] + bv;
+          const int rofs = (r & 3) + 8 * (r >> 2);           // row = wm * 32 + acc_row32(r, lh) = rb0 + rofs
+          const float v = fmaxf(acc[j][r] + bv, lo_clamp) * g.out_scale;
           acc[j][r] = 0.f;
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          v *= g.out_scale;
           if (MODE != 0) {
-            stage[row_l * STAGE_LD + col_l] = v;
+            sp[rofs * STAGE_LD] = v;
           } else {
-            const long row = m0 + row_l;
-            if (row < g.M && col < g.N) g.C[row * g.ldc + col] = v;
+            if (full || m0 + rb0 + rofs < g.M) cp[(long)rofs * g.ldc] = v;
           }
         }
       }
@@ -813,32 +853,29 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
         }
         if (s + 1 < steps) {
           __syncthreads();
-          wstore(buf ^ 1);
+          wstore(wr[0], buf ^ 1);
         }
       }
-      kt = 0;
-      nt++;
-    } else {
-      kt++;
     }
     __syncthreads();
+    s++;
   }
 }
 
-template <int BM_, int MODE, bool EW = false>
+template <int BM_, int MODE, bool EW = false, int PF = 1>
 int launch_nt_as1(const hftt_gemm_nt_desc& d, hipStream_t st) {
   int lds = (BM_ * (d.K + 8) + 2 * 256 * 40) * 2;
   const int stage = BM_ * 260 * 4;
   if (MODE == 1 && stage > lds) lds = stage;
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_as1_kernel<BM_, MODE, EW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_as1_kernel<BM_, MODE, EW, PF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { hftt_set_error("gemm_nt: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e)); return 2; }
     attr_lds = lds;
   }
   dim3 grid((unsigned)((d.M + BM_ - 1) / BM_), 1, 1);
-  hipLaunchKernelGGL((gemm_nt_as1_kernel<BM_, MODE, EW>), grid, dim3(512), lds, st, d);
+  hipLaunchKernelGGL((gemm_nt_as1_kernel<BM_, MODE, EW, PF>), grid, dim3(512), lds, st, d);
   HFTT_CHECK_LAUNCH("gemm_nt");
   return 0;
 }
@@ -877,6 +914,12 @@ int dispatch_nt(const hftt_gemm_nt_desc& d, hipStream_t st) {
   return launch_nt<64, F32, false>(d, st);
 }
 
+// weight-tile prefetch distance of the one-shot kernels in k steps (HFTT_NT_PF = 1 | 2 | 4 overrides for measurements)
+int nt_pf() {
+  static const int pf = [] { const char* e = getenv("HFTT_NT_PF"); return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 2; }();
+  return pf;
+}
+
 // bf16-mode dispatch
 int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
   const bool vec_ok = (d.ldc % 4 == 0) && (((uintptr_t)d.C & 15) == 0) &&
@@ -888,17 +931,22 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
   if (d.N % 256 == 0 && d.K <= 768 && d.M >= 256 && vec_ok) {
     if (d.K <= 256) {       // one-shot form (measured: qkv 391 vs 518 us, o+LN 256 vs 300 us against the persistent form)
       const bool rich = d.add_table || d.gate || d.drop_p > 0.f || d.residual || d.ln_gamma;
-      if (!rich) return launch_nt_as1<64, 0>(d, st);
+      const int kt = d.K / 32;
+      const int pf = (nt_pf() >= 4 && kt % 4 == 0) ? 4 : (nt_pf() >= 2 && kt % 2 == 0) ? 2 : 1;
+      if (!rich) return pf == 4 ? launch_nt_as1<64, 0, false, 4>(d, st) : pf == 2 ? launch_nt_as1<64, 0, false, 2>(d, st) : launch_nt_as1<64, 0>(d, st);
       // dropout / bf16 ReLU gate on a bf16 C are elementwise: they ride in the direct packed-store epilogue (no staging pass)
       const bool elementwise = !d.add_table && !d.residual && !d.ln_gamma && (d.io_flags & HFTT_NT_C_BF16) && d.ldc % 2 == 0 &&
                                (!d.gate || ((d.io_flags & HFTT_NT_GATE_BF16) && d.ldg % 2 == 0));
-      if (elementwise) return launch_nt_as1<64, 0, true>(d, st);
-      if (d.N == 256) return launch_nt_as1<64, 1>(d, st);
+      if (elementwise) return pf == 4 ? launch_nt_as1<64, 0, true, 4>(d, st) : pf == 2 ? launch_nt_as1<64, 0, true, 2>(d, st) : launch_nt_as1<64, 0, true>(d, st);
+      if (d.N == 256) return pf == 4 ? launch_nt_as1<64, 1, false, 4>(d, st) : pf == 2 ? launch_nt_as1<64, 1, false, 2>(d, st) : launch_nt_as1<64, 1>(d, st);
       return launch_nt_as1<32, 2>(d, st);
     }
     // measured at M = 262144 (us): K=512,N=256: persistent 450 | one-shot BM=64 486;  K=768,N=256: one-shot BM=64 504 |
     // one-shot BM=32 713 | persistent double-buffered 744 | persistent 928
-    if (d.K > 512 && d.N == 256) return launch_nt_as1<64, 1>(d, st);
+    if (d.K > 512 && d.N == 256) {
+      const int kt = d.K / 32;
+      return (nt_pf() >= 4 && kt % 4 == 0) ? launch_nt_as1<64, 1, false, 4>(d, st) : (nt_pf() >= 2 && kt % 2 == 0) ? launch_nt_as1<64, 1, false, 2>(d, st) : launch_nt_as1<64, 1>(d, st);
+    }
     const bool abf = d.io_flags & HFTT_NT_A_BF16;
     if (d.K <= 512) return abf ? launch_nt_as<4, false, true>(d, st) : launch_nt_as<8, false, false>(d, st);
     return abf ? launch_nt_as<6, true, true>(d, st) : launch_nt_as<12, true, false>(d, st);

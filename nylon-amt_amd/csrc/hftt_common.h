@@ -126,13 +126,59 @@ __device__ __forceinline__ bool hftt_keep(uint64_t seed, uint32_t site, uint64_t
   return hftt_hash(seed, site, idx) < thr;
 }
 
+// ---- cross-lane traffic without the LDS crossbar ----------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS instruction + an lgkmcnt wait per use); DPP / permlane / readlane stay on the VALU.
+template <int CTRL>
+__device__ __forceinline__ float hftt_dpp(float v) {      // CTRL: 0xB1 quad_perm[1,0,3,2]  0x4E quad_perm[2,3,0,1]  0x141 row_half_mirror  0x140 row_mirror
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float hftt_readlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// sum / max over the 64 lanes, result wave-uniform (four DPP steps inside each 16-lane row, then four readlanes)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += hftt_dpp<0xB1>(v); v += hftt_dpp<0x4E>(v); v += hftt_dpp<0x141>(v); v += hftt_dpp<0x140>(v);
+  return (hftt_readlane(v, 0) + hftt_readlane(v, 16)) + (hftt_readlane(v, 32) + hftt_readlane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, hftt_dpp<0xB1>(v)); v = fmaxf(v, hftt_dpp<0x4E>(v)); v = fmaxf(v, hftt_dpp<0x141>(v)); v = fmaxf(v, hftt_dpp<0x140>(v));
+  return fmaxf(fmaxf(hftt_readlane(v, 0), hftt_readlane(v, 16)), fmaxf(hftt_readlane(v, 32), hftt_readlane(v, 48)));
+}
+// sum over aligned groups of G lanes (G = 2, 4, 8 or 16), result in every lane of the group
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group_sum: G must be a power of two <= 16");
+  if (G >= 2) v += hftt_dpp<0xB1>(v);
+  if (G >= 4) v += hftt_dpp<0x4E>(v);
+  if (G >= 8) v += hftt_dpp<0x141>(v);
+  if (G >= 16) v += hftt_dpp<0x140>(v);
   return v;
+}
+// lane l <-> lane l ^ 32 (v_permlane32_swap, gfx950): both halves end up with op(own, partner).  Inline asm: hipcc 7.2 folds the
+// two results of __builtin_amdgcn_permlane32_swap into one value.  After the swap a = [v.lo | v.lo], b = [v.hi | v.hi].
+// (s_nop: a VALU write of an operand needs wait states before / after the swap.)
+__device__ __forceinline__ void hftt_swap32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float a = v, b = v;
+  hftt_swap32(a, b);
+  return a + b;
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  float a = v, b = v;
+  hftt_swap32(a, b);
+  return fmaxf(a, b);
+}
+// Accumulator layouts put adjacent COLUMNS in lanes 2i / 2i+1 and two ROWS (a, b) in one lane.  pair_rows_to_cols() turns that
+// into one packed bf16 pair of adjacent columns per lane: the even lane gets row a = [own a | partner a], the odd lane row b =
+// [partner b | own b].  One cvt_pk + one DPP move + one byte permute for two elements.
+__device__ __forceinline__ unsigned pair_rows_to_cols(float a, float b, bool odd) {
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  const f2_t v = {a, b};
+  const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2_t));      // lo16 = a, hi16 = b
+  const unsigned q = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0xB1, 0xF, 0xF, true);   // partner's pair
+  // v_perm_b32: selector bytes 0-3 pick from the second operand (q), 4-7 from the first (pk)
+  return __builtin_amdgcn_perm(pk, q, odd ? 0x07060302u : 0x01000504u);
 }
