@@ -947,6 +947,10 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
       const int kt = d.K / 32;
       return (nt_pf() >= 4 && kt % 4 == 0) ? launch_nt_as1<64, 1, false, 4>(d, st) : (nt_pf() >= 2 && kt % 2 == 0) ? launch_nt_as1<64, 1, false, 2>(d, st) : launch_nt_as1<64, 1>(d, st);
     }
+    // K = 512, N = 256 (measured at M = 262144, us): one-shot BM=64 (1 WG/CU) 254 | one-shot BM=32 275 | persistent 288 without
+    // LayerNorm; with it 354 | 340 | 369
+    if (d.K <= 512 && d.N == 256 && (d.K / 32) % 2 == 0 && nt_pf() >= 2)
+      return d.ln_gamma ? launch_nt_as1<32, 1, false, 2>(d, st) : launch_nt_as1<64, 1, false, 2>(d, st);
     const bool abf = d.io_flags & HFTT_NT_A_BF16;
     if (d.K <= 512) return abf ? launch_nt_as<4, false, true>(d, st) : launch_nt_as<8, false, false>(d, st);
     return abf ? launch_nt_as<6, true, true>(d, st) : launch_nt_as<12, true, false>(d, st);

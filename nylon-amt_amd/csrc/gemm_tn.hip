@@ -69,6 +69,8 @@ struct TnCfg {
   static constexpr int XSPR = TILE_K / XE;
   static constexpr int YL = (BMT * YSPR + 511) / 512;   // 16-byte loads per thread
   static constexpr int XL = (BMT * XSPR + 511) / 512;
+  static constexpr bool Y_EXACT = (BMT * YSPR) % 512 == 0;   // every thread owns a valid slot in every load round
+  static constexpr bool X_EXACT = (BMT * XSPR) % 512 == 0;
 };
 
 template <int TM, int TN, int NPASS, bool DYB, bool XB>
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       const int i = tid + 512 * j;
       const int row = i / YSPR;
       const long m = mb + row;
-      // unconditional load from a clamped address + select: a branch around the load would make hipcc wait vmcnt(0) per load
+      // unconditional load from a clamped address (a branch around the load would make hipcc wait vmcnt(0) per load); slots that
+      // do not exist are zeroed when the registers are consumed (sstore) -- a select right here would wait for each load in turn
       const long mc = m < mend ? m : mend - 1;
-      const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g.dY) + (mc * g.lddy + ycol_c) * (DYB ? 2 : 4));
-      yreg[j] = (ycol_ok && m < mend && row < BMT) ? t : make_uint4(0u, 0u, 0u, 0u);
+      yreg[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g.dY) + (mc * g.lddy + ycol_c) * (DYB ? 2 : 4));
     }
 #pragma unroll
     for (int j = 0; j < Cfg::XL; j++) {
@@ -132,8 +134,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       const int col = k0 + cs * XE;
       const long mc = m < mend ? m : mend - 1;
       const int cc = col < g.K ? col : g.K - XE;
-      const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g.X) + (mc * g.ldx + cc) * (XB ? 2 : 4));
-      xreg[j] = (row < BMT && col < g.K && m < mend) ? t : make_uint4(0u, 0u, 0u, 0u);
+      xreg[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g.X) + (mc * g.ldx + cc) * (XB ? 2 : 4));
     }
   };
   // one 16-byte slot -> LDS tile (which: 0 = dY tile, 1 = X tile) at element offset off
@@ -153,21 +154,23 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
     unsigned short* base = sm16 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
     *reinterpret_cast<uint4*>(base + off) = u;
   };
-  auto sstore = [&](int buf, const uint4 (&yreg)[Cfg::YL], const uint4 (&xreg)[Cfg::XL]) {
+  auto sstore = [&](int buf, int step, const uint4 (&yreg)[Cfg::YL], const uint4 (&xreg)[Cfg::XL]) {
+    const long mb = mbeg + (long)step * BMT;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int j = 0; j < Cfg::YL; j++) {
       const int i = tid + 512 * j;
       const int row = i / YSPR;
-      if (row < BMT) {
+      const uint4 yv = (ycol_ok && mb + row < mend) ? yreg[j] : zero4;      // slots past the split / past N count as zeros
+      if (Cfg::Y_EXACT || row < BMT) {      // (a per-lane branch here would also turn the register-set wait into vmcnt(0))
         if (DYB) {
-          const unsigned w[4] = {yreg[j].x, yreg[j].y, yreg[j].z, yreg[j].w};
-#pragma unroll
-          for (int e = 0; e < 4; e++) { csum[2 * e] += bf2f(w[e] & 0xFFFFu); csum[2 * e + 1] += bf2f(w[e] >> 16); }
-          put_bf16(buf, 0, row * RSY + ycs * 8, yreg[j]);
+          csum[0] += bf2f(yv.x & 0xFFFFu); csum[1] += bf2f(yv.x >> 16); csum[2] += bf2f(yv.y & 0xFFFFu); csum[3] += bf2f(yv.y >> 16);
+          csum[4 % YE] += bf2f(yv.z & 0xFFFFu); csum[5 % YE] += bf2f(yv.z >> 16); csum[6 % YE] += bf2f(yv.w & 0xFFFFu); csum[7 % YE] += bf2f(yv.w >> 16);
+          put_bf16(buf, 0, row * RSY + ycs * 8, yv);
         } else {
-          csum[0] += __uint_as_float(yreg[j].x); csum[1] += __uint_as_float(yreg[j].y);
-          csum[2] += __uint_as_float(yreg[j].z); csum[3] += __uint_as_float(yreg[j].w);
-          put_f32(buf, 0, row * RSY + ycs * 4, yreg[j]);
+          csum[0] += __uint_as_float(yv.x); csum[1] += __uint_as_float(yv.y);
+          csum[2] += __uint_as_float(yv.z); csum[3] += __uint_as_float(yv.w);
+          put_f32(buf, 0, row * RSY + ycs * 4, yv);
         }
       }
     }
@@ -175,9 +178,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
     for (int j = 0; j < Cfg::XL; j++) {
       const int i = tid + 512 * j;
       const int row = i / XSPR, cs = i % XSPR;
-      if (row < BMT) {
-        if (XB) put_bf16(buf, 1, row * RSX + cs * 8, xreg[j]);
-        else put_f32(buf, 1, row * RSX + cs * 4, xreg[j]);
+      const uint4 xv = (k0 + cs * XE < g.K && mb + row < mend) ? xreg[j] : zero4;
+      if (Cfg::X_EXACT || row < BMT) {
+        if (XB) put_bf16(buf, 1, row * RSX + cs * 8, xv);
+        else put_f32(buf, 1, row * RSX + cs * 4, xv);
       }
     }
   };
@@ -187,17 +191,18 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   const int frag_col = 16 * (gi & 1) + 4 * pp;   // column inside a 32-wide tile
   const int frag_row = 8 * (gi >> 1) + qq;       // + 16*s + 4*half
 
-  if (nsteps > 0) {
-    gload(0, yregA, xregA);
-    sstore(0, yregA, xregA);
-    if (nsteps > 1) gload(1, yregB, xregB);
-  }
+  // Every load below is unconditional (rows past the split's end come back as zeros from a clamped address): a load inside a
+  // conditional block makes hipcc's s_waitcnt insertion fall back to vmcnt(0), which drained the two-steps-ahead prefetch.
+  gload(0, yregA, xregA);
+  sstore(0, 0, yregA, xregA);
+  gload(1, yregB, xregB);
   __syncthreads();
   // step s computes from LDS buffer (s&1); set `cur` (stored to LDS one step ago) is refilled with step s+2, set `nxt`
   // (holding step s+1, issued one step ago) is converted into the other LDS buffer after the MFMAs
   auto body = [&](int step, uint4 (&ycur)[Cfg::YL], uint4 (&xcur)[Cfg::XL], const uint4 (&ynxt)[Cfg::YL], const uint4 (&xnxt)[Cfg::XL]) {
     const int buf = step & 1;
-    if (step + 2 < nsteps) gload(step + 2, ycur, xcur);
+    gload(step + 2, ycur, xcur);
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads up here: hipcc otherwise sinks them below the MFMAs (one step of cover, not two)
     if (F32) {
       const float* Ys = sm32 + buf * Cfg::BUF_ELEMS;
       const float* Xs = Ys + Cfg::Y_ELEMS;
@@ -238,12 +243,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
           for (int j = 0; j < TN; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
       }
     }
-    if (step + 1 < nsteps) sstore(buf ^ 1, ynxt, xnxt);
+    sstore(buf ^ 1, step + 1, ynxt, xnxt);
     __syncthreads();
   };
-  for (int step = 0; step < nsteps; step += 2) {
+  for (int step = 0; step < nsteps; step += 2) {      // an odd step count runs one extra step on zeros
     body(step, yregA, xregA, yregB, xregB);
-    if (step + 1 < nsteps) body(step + 1, yregB, xregB, yregA, xregA);
+    body(step + 1, yregB, xregB, yregA, xregA);
   }
 
   // partial tile -> slab [split][nws][kws]

@@ -312,14 +312,23 @@ class HfttEngine:
             + ((2 if gate_bf else 4) * M * N if gate else 0)
         rich = bool(add_table or gate or drop_site or residual or ln is not None)
         if self.npass == 1 and N % 256 == 0 and K <= 768 and M >= 256:      # mirrors dispatch_nt_bf16 in csrc/gemm_nt.hip
+            pf = 2 if (K // 32) % 2 == 0 else 1
             if K <= 256:
                 elementwise = not (add_table or residual or ln is not None) and c_bf and (not gate or gate_bf)
-                kname = 'gemm_nt_as1_kernel<%s>' % ('64, 0, false' if not rich else ('64, 0, true' if elementwise else ('64, 1, false' if N == 256 else '32, 2, false')))
-            else:
-                if K <= 512:
-                    kname = 'gemm_nt_as_kernel<4, false, true>' if a_bf else 'gemm_nt_as_kernel<8, false, false>'
+                if not rich:
+                    kname = 'gemm_nt_as1_kernel<64, 0, false, %d>' % pf
+                elif elementwise:
+                    kname = 'gemm_nt_as1_kernel<64, 0, true, %d>' % pf
+                elif N == 256:
+                    kname = 'gemm_nt_as1_kernel<64, 1, false, %d>' % pf
                 else:
-                    kname = 'gemm_nt_as1_kernel<64, 1, false>' if N == 256 else ('gemm_nt_as_kernel<6, true, true>' if a_bf else 'gemm_nt_as_kernel<12, true, false>')
+                    kname = 'gemm_nt_as1_kernel<32, 2, false, 1>'
+            elif N == 256 and pf == 2:
+                kname = 'gemm_nt_as1_kernel<%d, 1, false, 2>' % (32 if (ln is not None and K <= 512) else 64)
+            elif K <= 512:
+                kname = 'gemm_nt_as_kernel<4, false, true>' if a_bf else 'gemm_nt_as_kernel<8, false, false>'
+            else:
+                kname = 'gemm_nt_as_kernel<6, true, true>' if a_bf else 'gemm_nt_as_kernel<12, true, false>'
         else:
             kname = 'gemm_nt_kernel<%d, %s, %s>' % (bn, 'true' if self.npass == 3 else 'false', 'true' if ln is not None else 'false')
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
