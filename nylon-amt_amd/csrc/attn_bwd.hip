@@ -8,6 +8,7 @@
 //   * only dS crosses LDS (bf16 [query][key] image) for dQ = dS.K, computed with 16x16x32 tiles spread over the waves;
 //     K for that product is the row-major LDS image read through ds_read_b64_tr_b16.
 //   * Q and dO blocks (32 rows) are staged per iteration; their transposes are again tr reads of the same image.
+#include <type_traits>
 #include "hftt_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   constexpr int QSLOT = HB ? DH / 8 : F4R;          // 16-byte slots per row (8 bf16 or 4 fp32)
   constexpr int QCNT = (32 * QSLOT + NTHR - 1) / NTHR;
   uint4 pq[QCNT], pdo[QCNT], po[QCNT];             // raw 16-byte slots
-  float pl0[QCNT], pl1[QCNT];
+  float2 pl[QCNT];
   auto qload = [&](int qb) {
 #pragma unroll
     for (int u = 0; u < QCNT; u++) {
@@ -204,9 +205,9 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         pdo[u] = make_uint4(__float_as_uint(b2.x), __float_as_uint(b2.y), __float_as_uint(b2.z), __float_as_uint(b2.w));
         po[u] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w));
       }
-      pl0[u] = g.lse[(sh * Lq + qc) * 2];
-      pl1[u] = g.lse[(sh * Lq + qc) * 2 + 1];
-      if (q >= Lq) { pq[u] = make_uint4(0u, 0u, 0u, 0u); pdo[u] = pq[u]; po[u] = pq[u]; pl0[u] = 0.f; pl1[u] = 0.f; }
+      pl[u] = *reinterpret_cast<const float2*>(g.lse + (sh * Lq + qc) * 2);
+      // rows past Lq are zeroed when the registers are consumed (stage (a) of the next block): a select here would make hipcc
+      // wait for each load right after issuing it, and the whole prefetch would sit on the critical path
     }
   };
   qload(0);
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       const int i = tid + NTHR * u;
       if (i < 32 * QSLOT) {                         // wave-uniform (32*QSLOT and NTHR are multiples of 64)
         const int row = i / QSLOT, cs = i % QSLOT;
+        if (qb * 32 + row >= Lq) { pq[u] = make_uint4(0u, 0u, 0u, 0u); pdo[u] = pq[u]; po[u] = pq[u]; pl[u] = make_float2(0.f, 0.f); }
         float dot;
         if (HB) {
           *reinterpret_cast<uint4*>(Qs16 + row * RSQ + cs * 8) = pq[u];
@@ -243,8 +245,8 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         dot = group_sum<QSLOT>(dot);
         if (cs == 0) {
           delta_s[row] = dot;
-          lse_s[row] = pl0[u];
-          inv_s[row] = pl1[u];
+          lse_s[row] = pl[u].x;
+          inv_s[row] = pl[u].y;
         }
       }
     }
@@ -270,22 +272,27 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       }
     }
     const bool key_ok = mykey < Lk;
+    // the (wave-uniform) dropout test is hoisted out of the register loop: 16 branches in it kept hipcc from interleaving the rows
+    auto softmax_bwd = [&](auto drop_c) {
+      constexpr bool DROP = decltype(drop_c)::value;
+      const uint64_t ebase = (uint64_t)((sh * Lq + (long)qb * 32 + 4 * lh) * (long)Lk + mykey);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int ql_ = acc_row32(r, lh);
-      const float arg = sacc[r] * scale - lse_s[ql_];
-      float p = (F32 ? expf(arg) : __expf(arg)) * inv_s[ql_];
-      if (!key_ok) p = 0.f;
-      float pd = p, dp = pacc[r];
-      if (g.drop_p > 0.f) {
-        const long q = qb * 32 + ql_;
-        const bool keep = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)((sh * Lq + q) * (long)Lk + mykey), thr);
-        pd = keep ? p * inv_keep : 0.f;
-        dp = keep ? dp * inv_keep : 0.f;
+      for (int r = 0; r < 16; r++) {
+        const int ql_ = acc_row32(r, lh);
+        const float arg = sacc[r] * scale - lse_s[ql_];
+        float p = (F32 ? expf(arg) : __expf(arg)) * inv_s[ql_];
+        if (!key_ok) p = 0.f;
+        float pd = p, dp = pacc[r];
+        if (DROP) {
+          const bool keep = hftt_keep(g.drop_seed, g.drop_site, ebase + (uint64_t)(((r & 3) + 8 * (r >> 2)) * Lk), thr);
+          pd = keep ? p * inv_keep : 0.f;
+          dp = keep ? dp * inv_keep : 0.f;
+        }
+        sacc[r] = pd;                                        // dropped probabilities (for dV)
+        pacc[r] = p * (dp - delta_s[ql_]) * scale;           // dS (scaled): for dK, dQ
       }
-      sacc[r] = pd;                                        // dropped probabilities (for dV)
-      pacc[r] = p * (dp - delta_s[ql_]) * scale;           // dS (scaled): for dK, dQ
-    }
+    };
+    if (g.drop_p > 0.f) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
     // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS ----
     if (F32) {
 #pragma unroll
@@ -315,11 +322,17 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       }
     }
     // ---- (g) dS -> LDS [query][key] ----
+    if (F32) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int off = acc_row32(r, lh) * RSS + wave * 32 + lr;
-      if (F32) Ss32[off] = pacc[r];
-      else Ss16[off] = f2bf(pacc[r]);
+      for (int r = 0; r < 16; r++) Ss32[acc_row32(r, lh) * RSS + wave * 32 + lr] = pacc[r];
+    } else {
+      // lanes 2i / 2i+1 hold adjacent keys: one packed pair (ds_write_b32) per register pair instead of two 2-byte writes
+      const bool odd = lane & 1;
+#pragma unroll
+      for (int rp = 0; rp < 8; rp++) {
+        const unsigned pk = pair_rows_to_cols(pacc[2 * rp], pacc[2 * rp + 1], odd);
+        *reinterpret_cast<unsigned*>(Ss16 + acc_row32(2 * rp + (odd ? 1 : 0), lh) * RSS + wave * 32 + (lr & ~1)) = pk;
+      }
     }
     __syncthreads();   // (h)
 

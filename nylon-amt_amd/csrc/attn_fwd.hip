@@ -6,6 +6,7 @@
 //   registers  -> the softmax row reduction is register-local plus ONE cross-half shuffle (lane ^ 32);
 //   the probability tile is then fed straight back as the A operand of the PV product (accumulator-as-operand,
 //   probe T4), V fragments come from the row-major LDS image through ds_read_b64_tr_b16 (probe T5).
+#include <type_traits>
 #include "hftt_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
@@ -71,13 +72,14 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
           const int kc = key < Lk ? key : Lk - 1;
           kf[u] = *reinterpret_cast<const uint4*>(kp + (long)kc * g.ldk + c8 * 8);
           vf[u] = *reinterpret_cast<const uint4*>(vp + (long)kc * g.ldv + c8 * 8);
-          if (key >= Lk) { kf[u] = make_uint4(0u, 0u, 0u, 0u); vf[u] = kf[u]; }
         }
 #pragma unroll
         for (int u = 0; u < UB8; u++) {
           const int i = base + tid + 256 * u;
           if (i < TOTAL8) {
             const int key = i / S8R, c8 = i % S8R;
+            // keys past Lk become zero rows here, not right after the load (a select there makes hipcc wait for every load in turn)
+            if (key >= Lk) { kf[u] = make_uint4(0u, 0u, 0u, 0u); vf[u] = kf[u]; }
             *reinterpret_cast<uint4*>(Ks16 + key * RSK + c8 * 8) = kf[u];
             *reinterpret_cast<uint4*>(Vs16 + key * RSV + c8 * 8) = vf[u];
           }
@@ -96,12 +98,12 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
         const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
         kf[u] = hftt_load4(g.k, kv_bf, kofs + (long)kc * g.ldk + c4 * 4);
         vf[u] = hftt_load4(g.v, kv_bf, vofs + (long)kc * g.ldv + c4 * 4);
-        if (key >= Lk) { kf[u] = make_float4(0.f, 0.f, 0.f, 0.f); vf[u] = kf[u]; }
       }
 #pragma unroll
       for (int u = 0; u < UB; u++) {
         const int i = base + tid + 256 * u;
         const int key = i / F4R, c4 = i % F4R;
+        if (key >= Lk) { kf[u] = make_float4(0.f, 0.f, 0.f, 0.f); vf[u] = kf[u]; }
         if (F32) {
           float* kd = Ks32 + key * RSK + c4 * 4;
           kd[0] = kf[u].x; kd[1] = kf[u].y; kd[2] = kf[u].z; kd[3] = kf[u].w;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
               if (key0 + e < Lk) g.probs[prow + key0 + e] = p4[e];
           }
         }
-        if (g.drop_p > 0.f) {
+        if (g.drop_p > 0.f) {        // (wave-uniform; hoisting it out of the loop lets hipcc overlap 128 hash chains and spill)
 #pragma unroll
           for (int e = 0; e < 4; e++)
             p4[e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(prow + key0 + e), thr) ? p4[e] * inv_keep : 0.f;
@@ -263,13 +265,14 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
       // lanes 2i / 2i+1 hold adjacent columns: exchange so that each lane stores one packed pair (4 bytes) per register pair
       unsigned short* op = reinterpret_cast<unsigned short*>(g.out) + oofs;
       const bool odd = lane & 1;
+      const bool full_qb = qb * 32 + 32 <= Lq;          // wave-uniform: no per-store bounds test for interior query blocks
 #pragma unroll
       for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int rp = 0; rp < 8; rp++) {
           const unsigned pk = pair_rows_to_cols(oacc[n][2 * rp], oacc[n][2 * rp + 1], odd);
           const int q = qb * 32 + acc_row32(2 * rp + (odd ? 1 : 0), lh);
-          if (q < Lq) *reinterpret_cast<unsigned*>(op + (long)q * g.ldo + n * 32 + (lr & ~1)) = pk;
+          if (full_qb || q < Lq) *reinterpret_cast<unsigned*>(op + (long)q * g.ldo + n * 32 + (lr & ~1)) = pk;
         }
     } else {
 #pragma unroll
