@@ -200,8 +200,17 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   float acc = 0.f;
-  if (c < 2 * N)
-    for (int w = rg; w < n_wg; w += 16) acc += ws[(long)w * 2 * N + c];
+  if (c < 2 * N) {
+    // eight independent loads in flight per thread (the plain loop was one dependent L2 round trip per partial: ~20 us for 2 MB)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = rg;
+    for (; w + 16 * 7 < n_wg; w += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) a8[u] += ws[(long)(w + 16 * u) * 2 * N + c];
+    }
+    for (; w < n_wg; w += 16) a8[0] += ws[(long)w * 2 * N + c];
+    acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  }
   red[rg][cl] = acc;
   __syncthreads();
   if (rg == 0 && c < 2 * N) {

@@ -745,9 +745,17 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
             const long row0c = FULL ? row0 : (row0 < g.M ? row0 : (long)g.M - 1);
             unsigned short* cp = Cb + row0 * g.ldc + (col & ~1);
             const unsigned short* gpt = reinterpret_cast<const unsigned short*>(g.gate) + row0c * g.ldg + (col & ~1);
+            unsigned gpk[8];
+            if (gated) {                     // all eight gate pairs of this column block in flight before the first one is used
+#pragma unroll
+              for (int rp = 0; rp < 8; rp++) {
+                const int rofs = ((2 * rp) & 3) + 8 * ((2 * rp) >> 2);
+                const bool ok = FULL || (row0 + rofs < g.M);
+                gpk[rp] = *reinterpret_cast<const unsigned*>(gpt + (ok ? (long)rofs * g.ldg : 0L));
+              }
+            }
 #pragma unroll
             for (int rp = 0; rp < 8; rp++) {
-              constexpr int dummy = 0; (void)dummy;
               const int rofs = ((2 * rp) & 3) + 8 * ((2 * rp) >> 2);     // acc_row32(2 * rp, lh) - 4 * lh: the even register's row
               float own0 = fmaxf(acc[j][2 * rp] + bv, lo_clamp) * oscale, own1 = fmaxf(acc[j][2 * rp + 1] + bv, lo_clamp) * oscale;
               acc[j][2 * rp] = 0.f; acc[j][2 * rp + 1] = 0.f;
@@ -759,7 +767,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
               unsigned pk = pair_rows_to_cols(own0, own1, odd);
               const bool ok = FULL || (row0 + rofs < g.M);
               if (gated) {                   // ... and the bf16 ReLU gate as one packed pair per lane, same footprint as the store
-                const unsigned gp = *reinterpret_cast<const unsigned*>(gpt + (ok ? (long)rofs * g.ldg : 0L));
+                const unsigned gp = gpk[rp];
                 // keep a half iff its gate is a positive bf16: bits in [0x0001, 0x7FFF]
                 const unsigned m = (((gp & 0xFFFFu) - 1u) < 0x7FFFu ? 0x0000FFFFu : 0u) | ((((gp >> 16) - 1u) < 0x7FFFu) ? 0xFFFF0000u : 0u);
                 pk &= m;
