@@ -70,6 +70,7 @@ int hftt_prep_weights(const float* params, uint16_t* wbf, float* wf32, float* fd
 #define HFTT_NT_A_BF16 1u
 #define HFTT_NT_C_BF16 2u      /* not with LayerNorm */
 #define HFTT_NT_GATE_BF16 4u
+#define HFTT_NT_RES_BF16 8u    /* residual stored as bf16 (A-stationary bf16-mode kernels: N % 256 == 0, M >= 256, K <= 768) */
 typedef struct {
   int32_t M, N, K, npass;
   const float* A; int64_t lda;
@@ -182,8 +183,10 @@ typedef struct {
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   float* ws;            /* [n_wg, 2, N] partial sums; n_wg = hftt_ln_bwd_wgs(M) */
   uint32_t drop_bf16;   /* dr_drop is stored as bf16 */
-  uint32_t pad;
+  uint32_t io_flags;    /* HFTT_LNB_DY_BF16: dy stored as bf16; HFTT_LNB_DR_BF16: dr stored as bf16 (bf16 gradient stream) */
 } hftt_ln_bwd_desc;
+#define HFTT_LNB_DY_BF16 1u
+#define HFTT_LNB_DR_BF16 2u
 int32_t hftt_ln_bwd_wgs(int32_t M);
 int hftt_ln_bwd(const hftt_ln_bwd_desc* d, void* stream);
 int hftt_ln_bwd_reduce(const float* ws, int32_t n_wg, int32_t N, float* dgamma, float* dbeta, float beta, void* stream);

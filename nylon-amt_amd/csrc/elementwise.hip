@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const bool dy_bf = g.io_flags & HFTT_LNB_DY_BF16, dr_bf = g.io_flags & HFTT_LNB_DR_BF16;
   float gam[VPL], dg[VPL], db[VPL];
 #pragma unroll
   for (int e = 0; e < VPL; e++) { gam[e] = g.gamma[lane * VPL + e]; dg[e] = 0.f; db[e] = 0.f; }
@@ -134,13 +135,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
     float dy[VPL], r[VPL];
     const long base = row * N + lane * VPL;
     if (VPL == 4) {
-      const float4 a = *reinterpret_cast<const float4*>(g.dy + base);
+      const float4 a = hftt_load4(g.dy, dy_bf, base);
       const float4 b = *reinterpret_cast<const float4*>(g.r + base);
       dy[0] = a.x; dy[1 % VPL] = a.y; dy[2 % VPL] = a.z; dy[3 % VPL] = a.w;
       r[0] = b.x; r[1 % VPL] = b.y; r[2 % VPL] = b.z; r[3 % VPL] = b.w;
     } else {
 #pragma unroll
-      for (int e = 0; e < VPL; e++) { dy[e] = g.dy[base + e]; r[e] = g.r[base + e]; }
+      for (int e = 0; e < VPL; e++) { dy[e] = dy_bf ? bf2f(reinterpret_cast<const unsigned short*>(g.dy)[base + e]) : g.dy[base + e]; r[e] = g.r[base + e]; }
     }
     const float mean = g.mean[row], rstd = g.rstd[row];
     float xh[VPL], gg[VPL], s1 = 0.f, s2 = 0.f;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
         od[e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(base + e), thr) ? o[e] * inv_keep : 0.f;
     }
     if (VPL == 4) {
-      *reinterpret_cast<float4*>(g.dr + base) = make_float4(o[0], o[1 % VPL], o[2 % VPL], o[3 % VPL]);
+      hftt_store4(g.dr, dr_bf, base, o[0], o[1 % VPL], o[2 % VPL], o[3 % VPL]);
       if (g.dr_drop != nullptr) {
         if (g.drop_bf16) {
           uint2 u;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
     } else {
 #pragma unroll
       for (int e = 0; e < VPL; e++) {
-        g.dr[base + e] = o[e];
+        hftt_store1(g.dr, dr_bf, base + e, o[e]);
         if (g.dr_drop != nullptr) {
           if (g.drop_bf16) reinterpret_cast<unsigned short*>(g.dr_drop)[base + e] = f2bf(od[e]);
           else g.dr_drop[base + e] = od[e];

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const h
     }
   };
   constexpr bool a_bf = ABF;                       // A stored as bf16: APF counts 16-byte chunks either way
-  const bool c_bf = g.io_flags & HFTT_NT_C_BF16, gate_bf = g.io_flags & HFTT_NT_GATE_BF16;
+  const bool c_bf = g.io_flags & HFTT_NT_C_BF16, gate_bf = g.io_flags & HFTT_NT_GATE_BF16, res_bf = g.io_flags & HFTT_NT_RES_BF16;
   const int c8r = K >> 3;                          // 16-byte chunks per row when A is stored as bf16
   const int a_total8 = BM_ * c8r;
   float4 apf[APF];
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const h
             const long rc = row < g.M ? row : (long)g.M - 1;      // clamped row: the (wave-uniform) pointer tests are the only branches
             if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(rc % g.add_mod) * g.N + c4);
             if (g.gate != nullptr) gat[rr] = load_gate4(g.gate, gate_bf, rc * g.ldg + c4);
-            if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(rc % g.res_mod) * g.ldr + c4);
+            if (g.residual != nullptr) res[rr] = load_gate4(g.residual, res_bf, (long)(rc % g.res_mod) * g.ldr + c4);
           }
 #pragma unroll
           for (int rr = 0; rr < RB; rr++) {
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
   };
 #pragma unroll
   for (int i = 0; i < PF; i++) wload(wr[i], i < steps ? i : steps - 1);
-  const bool a_bf = g.io_flags & HFTT_NT_A_BF16, c_bf = g.io_flags & HFTT_NT_C_BF16, gate_bf = g.io_flags & HFTT_NT_GATE_BF16;
+  const bool a_bf = g.io_flags & HFTT_NT_A_BF16, c_bf = g.io_flags & HFTT_NT_C_BF16, gate_bf = g.io_flags & HFTT_NT_GATE_BF16, res_bf = g.io_flags & HFTT_NT_RES_BF16;
   if (a_bf) {                                      // A stored as bf16: 16-byte chunks straight into LDS
     // thread t owns 16-byte chunks t, t + 512, ... of the BM_ x K block (row-major); (row, chunk) advance incrementally --
     // one integer division per thread instead of one per load (the index math was ~20 % of this kernel's VALU time)
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
             const long rc = row < g.M ? row : (long)g.M - 1;      // clamped row: the (wave-uniform) pointer tests are the only branches
             if (g.add_table != nullptr) tab[rr] = *reinterpret_cast<const float4*>(g.add_table + (long)(rc % g.add_mod) * g.N + c4);
             if (g.gate != nullptr) gat[rr] = load_gate4(g.gate, gate_bf, rc * g.ldg + c4);
-            if (g.residual != nullptr) res[rr] = *reinterpret_cast<const float4*>(g.residual + (long)(rc % g.res_mod) * g.ldr + c4);
+            if (g.residual != nullptr) res[rr] = load_gate4(g.residual, res_bf, (long)(rc % g.res_mod) * g.ldr + c4);
           }
 #pragma unroll
           for (int rr = 0; rr < RB; rr++) {
@@ -963,6 +963,7 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
     if (d.K <= 512) return abf ? launch_nt_as<4, false, true>(d, st) : launch_nt_as<8, false, false>(d, st);
     return abf ? launch_nt_as<6, true, true>(d, st) : launch_nt_as<12, true, false>(d, st);
   }
+  if (d.io_flags & HFTT_NT_RES_BF16) { hftt_set_error("gemm_nt: a bf16 residual needs the A-stationary path (N %% 256 == 0, M >= 256, K <= 768)"); return 1; }
   return dispatch_nt<false>(d, st);      // small / ragged shapes: the k-tiled streaming kernel
 }
 

@@ -75,7 +75,7 @@ class LnBwdDesc(C.Structure):
                 ('dy', c_f32p), ('r', c_f32p), ('mean', c_f32p), ('rstd', c_f32p), ('gamma', c_f32p),
                 ('dr', c_f32p), ('dr_drop', c_f32p),
                 ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
-                ('ws', c_f32p), ('drop_bf16', C.c_uint32), ('pad', C.c_uint32)]
+                ('ws', c_f32p), ('drop_bf16', C.c_uint32), ('io_flags', C.c_uint32)]
 
 
 class LossDesc(C.Structure):

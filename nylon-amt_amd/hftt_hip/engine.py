@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -283,10 +284,10 @@ class HfttEngine:
         return t
 
     def _nt(self, plan, ws, M, N, K, A, lda, W, bias, Cp, ldc, act=0, out_scale=1.0, add_table=0, add_mod=0,
-            gate=0, ldg=0, gate_scale=1.0, drop_site=0, residual=0, ldr=0, res_mod=0, ln=None, a_bf=False, c_bf=False, gate_bf=False):
-        a_bf, c_bf, gate_bf = (a_bf and self.sb), (c_bf and self.sb), (gate_bf and self.sb)
+            gate=0, ldg=0, gate_scale=1.0, drop_site=0, residual=0, ldr=0, res_mod=0, ln=None, a_bf=False, c_bf=False, gate_bf=False, res_bf=False):
+        a_bf, c_bf, gate_bf, res_bf = (a_bf and self.sb), (c_bf and self.sb), (gate_bf and self.sb), (res_bf and self.sb and bool(residual))
         dsc = GemmNtDesc()
-        dsc.io_flags = (1 if a_bf else 0) | (2 if c_bf else 0) | (4 if gate_bf else 0)
+        dsc.io_flags = (1 if a_bf else 0) | (2 if c_bf else 0) | (4 if gate_bf else 0) | (8 if res_bf else 0)
         dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, self.npass
         dsc.A, dsc.lda = A, lda
         dsc.W = W
@@ -308,7 +309,7 @@ class HfttEngine:
         n_pad = _align(N, 64)
         bn = N if ln is not None else (256 if n_pad % 256 == 0 else (128 if n_pad % 128 == 0 else 64))
         esz = 2 if self.npass == 1 else 4
-        nbytes = (2 if a_bf else 4) * M * K + (2 if c_bf else 4) * M * N + esz * N * K + (4 * M * N if residual else 0) + (4 * M * N if ln is not None else 0) \
+        nbytes = (2 if a_bf else 4) * M * K + (2 if c_bf else 4) * M * N + esz * N * K + ((2 if res_bf else 4) * M * N if residual else 0) + (4 * M * N if ln is not None else 0) \
             + ((2 if gate_bf else 4) * M * N if gate else 0)
         rich = bool(add_table or gate or drop_site or residual or ln is not None)
         if self.npass == 1 and N % 256 == 0 and K <= 768 and M >= 256:      # mirrors dispatch_nt_bf16 in csrc/gemm_nt.hip
@@ -394,7 +395,7 @@ class HfttEngine:
         plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd', meta))
         return dsc
 
-    def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta, drop_bf=True):
+    def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta, drop_bf=True, dy_bf=False, dr_bf=False):
         n_wg = self.lib.hftt_ln_bwd_wgs(M)
         ws['ln_need'] = max(ws.get('ln_need', 0), n_wg * 2 * self.d * 4)
         dsc = LnBwdDesc()
@@ -402,6 +403,7 @@ class HfttEngine:
         dsc.dy, dsc.r, dsc.mean, dsc.rstd, dsc.gamma = dy, r, mean, rstd, gamma
         dsc.dr, dsc.dr_drop = dr, dr_drop
         dsc.drop_bf16 = 1 if (drop_bf and self.sb and dr_drop) else 0
+        dsc.io_flags = (1 if (dy_bf and self.sb) else 0) | (2 if (dr_bf and self.sb) else 0)
         dsc.drop_p, dsc.drop_site, dsc.drop_seed = 0.0, drop_site, 0
         ws['ln'].append(dsc)
         if drop_site:
@@ -569,7 +571,8 @@ class HfttEngine:
         ws['enc'] = enc
 
     # ---- backward of one EncoderLayer; dx_out lives in GA on entry (grad of the layer output) and on exit (grad of input)
-    def _enc_layer_bwd(self, plan, ws, tag, key, pre, S, n_seq, L, H, x_in, G, extra_dx=0):
+    def _enc_layer_bwd(self, plan, ws, tag, key, pre, S, n_seq, L, H, x_in, G, extra_dx=0, in_bf=False, gbf=False, out_bf=False):
+        """in_bf / out_bf: the gradient stream GA arrives / leaves stored as bf16; gbf: GA and GB are bf16 inside the layer."""
         d, p = self.d, self.p
         b = ws['bufs']
         sa, so, sh, sf = ws['sites'][tag]
@@ -582,8 +585,8 @@ class HfttEngine:
         use_drop = self.dropout > 0.0
         # LN2 backward
         self._lnb(plan, ws, S, GA, b[tag + '.r2'].data_ptr(), b[tag + '.m2'].data_ptr(), b[tag + '.s2'].data_ptr(), gam,
-                  GB, GC if use_drop else 0, sf, dgam, dbet, 0.0)
-        dbr, dbr_bf = (GC, True) if use_drop else (GB, False)
+                  GB, GC if use_drop else 0, sf, dgam, dbet, 0.0, dy_bf=in_bf, dr_bf=gbf)
+        dbr, dbr_bf = (GC, True) if use_drop else (GB, gbf)
         # fc_2
         self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))],
                  dy_bf=dbr_bf, x_bf=True)
@@ -591,10 +594,10 @@ class HfttEngine:
                  gate_scale=('inv_keep',), a_bf=dbr_bf, c_bf=True, gate_bf=True)
         # fc_1
         self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True)
-        self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True)
+        self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True, res_bf=gbf, c_bf=gbf)
         # LN1 backward
         self._lnb(plan, ws, S, GA, b[tag + '.r1'].data_ptr(), b[tag + '.m1'].data_ptr(), b[tag + '.s1'].data_ptr(), gam,
-                  GB, GC if use_drop else 0, so, dgam, dbet, 1.0)
+                  GB, GC if use_drop else 0, so, dgam, dbet, 1.0, dy_bf=gbf, dr_bf=gbf)
         # fc_o
         self._tn(plan, ws, S, d, d, dbr, d, b[tag + '.ctx'].data_ptr(), d, [(0, d, self.G(pa + 'fc_o.weight'), self.G(pa + 'fc_o.bias'))],
                  dy_bf=dbr_bf, x_bf=True)
@@ -609,7 +612,7 @@ class HfttEngine:
         self._tn(plan, ws, S, 3 * d, d, Gq, 3 * d, x_in, d,
                  [(0, d, self.G(pa + 'fc_q.weight'), self.G(pa + 'fc_q.bias')), (d, d, self.G(pa + 'fc_k.weight'), self.G(pa + 'fc_k.bias')),
                   (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))], dy_bf=True)
-        self._nt(plan, ws, S, d, 3 * d, Gq, 3 * d, self.Wp(key + '.sa.qkv_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True)
+        self._nt(plan, ws, S, d, 3 * d, Gq, 3 * d, self.Wp(key + '.sa.qkv_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True, res_bf=gbf, c_bf=out_bf)
 
     def _ffn_bwd(self, plan, ws, tag, key, pre, S, x_in, G, ln_beta):
         """FFN + LN block of the decoder layers: grad of output in GA -> grad of x_in in GA."""
@@ -640,6 +643,14 @@ class HfttEngine:
         dd = 'decoder_spec2midi.'
         e = 'encoder_spec2midi.'
         use_drop = self.dropout > 0.0
+        # bf16 gradient stream on the bin-token (encoder-sized) set: the residual-stream gradient and the LN-backward output stored
+        # as bf16 between the decoder's cross-attention and the first encoder layer.  Built, parity-tested and MEASURED (r01, B=8):
+        # ln_bwd 90.9 -> 79.5 us, but the dX GEMMs' row-pass epilogue then moves 8 bytes per lane instead of 16 and gets slower
+        # (K=512: 253 -> 284 us, K=768: 324 -> 366 us) -- net zero, so it is OFF by default (HFTT_BF16_GRAD=1 enables) until the
+        # row pass handles 8 columns per lane for bf16 residual / C.
+        # (needs the A-stationary GEMM on every encoder dX: d % 256 == 0, K = ff and 3d <= 768, >= 256 bin tokens)
+        egb = (self.sb and os.environ.get('HFTT_BF16_GRAD', '0') == '1' and d % 256 == 0 and max(p, 3 * d) <= 768 and Se >= 256)
+        ws['bf16_grad'] = bool(egb)
         # gradient scratch: note-token sized and bin-token sized sets
         nGA = self._buf(ws, 'g.nA', Sn, d).data_ptr(); nGB = self._buf(ws, 'g.nB', Sn, d).data_ptr()
         hz = 2 if self.sb else 4
@@ -719,10 +730,10 @@ class HfttEngine:
             self._tn(plan, ws, Se, 2 * d, d, eGq, 2 * d, enc, d,
                      [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))], dy_bf=True)
             if first_enc_grad:
-                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, a_bf=True)
+                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, a_bf=True, c_bf=egb)
                 first_enc_grad = False
             else:
-                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, residual=eGA, ldr=d, a_bf=True)
+                self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, residual=eGA, ldr=d, a_bf=True, res_bf=egb, c_bf=egb)
             if j > 0:
                 # q projection of the cross attention (input sx, which is also the residual of this block)
                 self._tn(plan, ws, Sn, d, d, Q1, d, b[tag + '.sx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
@@ -757,7 +768,8 @@ class HfttEngine:
         # ---- encoder layers ----
         Ge = (eGA, eGB, eGC, eGh, eGq, eGx)
         for i in reversed(range(self.Le)):
-            self._enc_layer_bwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, ws['enc_in'][i], Ge)
+            self._enc_layer_bwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, ws['enc_in'][i], Ge,
+                                in_bf=egb, gbf=egb, out_bf=(egb and i > 0))     # the embedding stage below reads fp32
         # ---- embedding ----
         plan.append(('dropout_bwd', (eGA, Se * d, ws['sites']['embed']), 'dropout_bwd', None))
         plan.append(('colsum', (eGA, BT, F * d, F * d, self.G(e + 'pos_embedding_freq.weight'), 0.0, cs_ws), 'colsum', None))

@@ -24,7 +24,7 @@ def _need_cuda(*ts):
 
 
 BF16 = torch.bfloat16
-NT_A_BF16, NT_C_BF16, NT_GATE_BF16 = 1, 2, 4
+NT_A_BF16, NT_C_BF16, NT_GATE_BF16, NT_RES_BF16 = 1, 2, 4, 8
 TN_DY_BF16, TN_X_BF16 = 1, 2
 ATTN_Q_BF16, ATTN_KV_BF16, ATTN_O_BF16, ATTN_DQ_BF16, ATTN_DKV_BF16 = 1, 2, 4, 8, 16
 
@@ -64,7 +64,8 @@ def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_
     d.A, d.lda = A.data_ptr(), A.stride(0)
     d.W = Wprep.data_ptr()
     d.debug = debug
-    d.io_flags = (NT_A_BF16 if A.dtype == BF16 else 0) | (NT_C_BF16 if out_dtype == BF16 else 0) | (NT_GATE_BF16 if (gate is not None and gate.dtype == BF16) else 0)
+    d.io_flags = (NT_A_BF16 if A.dtype == BF16 else 0) | (NT_C_BF16 if out_dtype == BF16 else 0) | (NT_GATE_BF16 if (gate is not None and gate.dtype == BF16) else 0) \
+        | (NT_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0)
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc = Cout.data_ptr(), N
     d.act, d.out_scale = act, out_scale
@@ -158,13 +159,14 @@ def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0,
     return dq, dk, dv
 
 
-def ln_bwd(dy, r, mean, rstd, gamma, drop_p=0.0, drop_site=0, drop_seed=0, drop_dtype=torch.float32):
+def ln_bwd(dy, r, mean, rstd, gamma, drop_p=0.0, drop_site=0, drop_seed=0, drop_dtype=torch.float32, dr_dtype=torch.float32):
+    """dy may be stored as bf16 (bf16 gradient stream); dr is written as dr_dtype."""
     _need_cuda(dy, r)
     M, N = dy.shape
     L = lib()
     n_wg = L.hftt_ln_bwd_wgs(M)
     ws = torch.empty(n_wg * 2 * N, device=dy.device)
-    dr = torch.empty_like(dy)
+    dr = torch.empty(dy.shape, device=dy.device, dtype=dr_dtype)
     drd = torch.empty(dy.shape, device=dy.device, dtype=drop_dtype) if drop_p > 0 else None
     d = LnBwdDesc()
     d.M, d.N = M, N
@@ -173,6 +175,7 @@ def ln_bwd(dy, r, mean, rstd, gamma, drop_p=0.0, drop_site=0, drop_seed=0, drop_
     d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
     d.ws = ws.data_ptr()
     d.drop_bf16 = 1 if drop_dtype == BF16 else 0
+    d.io_flags = (1 if dy.dtype == BF16 else 0) | (2 if dr_dtype == BF16 else 0)
     st = _stream(dy.device)
     check(L.hftt_ln_bwd(C.byref(d), st), 'ln_bwd')
     dg = torch.empty(N, device=dy.device)

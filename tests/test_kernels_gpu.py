@@ -275,6 +275,44 @@ def test_attention_bf16_storage(dev, n, H, Lq, Lk, dh):
     assert rel_err(out.float(), out32) < 1e-2
 
 
+def test_bf16_gradient_stream_flags(dev):
+    """bf16 gradient stream (ABI: HFTT_LNB_DY_BF16 / HFTT_LNB_DR_BF16, HFTT_NT_RES_BF16): with values that are exactly
+    representable in bf16 the bf16-stored inputs give bitwise the fp32-stored result; a bf16 output differs by its rounding only."""
+    ops = _ops()
+    M, N, K = 1500, 256, 256
+    g = torch.Generator().manual_seed(12)
+    r = torch.randn(M, N, generator=g); dy = _bf(torch.randn(M, N, generator=g)); gam = torch.randn(N, generator=g)
+    mean = r.mean(1); rstd = 1.0 / torch.sqrt(r.var(1, unbiased=False) + 1e-5)
+    args = (r.to(dev), mean.to(dev), rstd.to(dev), gam.to(dev))
+    a = ops.ln_bwd(dy.float().to(dev), *args, drop_p=0.2, drop_site=3, drop_seed=9, drop_dtype=torch.bfloat16)
+    b = ops.ln_bwd(dy.to(dev), *args, drop_p=0.2, drop_site=3, drop_seed=9, drop_dtype=torch.bfloat16)                       # bf16 dy
+    c = ops.ln_bwd(dy.to(dev), *args, drop_p=0.2, drop_site=3, drop_seed=9, drop_dtype=torch.bfloat16, dr_dtype=torch.bfloat16)  # + bf16 dr
+    assert b[0].dtype == torch.float32 and max_err(a[0], b[0]) == 0.0 and max_err(a[2], b[2]) == 0.0 and max_err(a[3], b[3]) == 0.0
+    assert torch.equal(a[1], b[1]) and torch.equal(a[1], c[1])
+    assert c[0].dtype == torch.bfloat16 and torch.equal(c[0], a[0].to(torch.bfloat16))
+    # NT with a bf16-stored residual, fp32 and bf16 C (row-pass epilogue), and under the LayerNorm epilogue
+    A = _bf(torch.randn(M, K, generator=g)); W = torch.randn(N, K, generator=g) / math.sqrt(K); res = _bf(torch.randn(M, N, generator=g))
+    x0 = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=1, residual=res.float().to(dev))
+    x1 = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=1, residual=res.to(dev))
+    x2 = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=1, residual=res.to(dev), out_dtype=torch.bfloat16)
+    assert x1.dtype == torch.float32 and torch.equal(x0, x1) and torch.equal(x2, x0.to(torch.bfloat16))
+    ref = A.double() @ _bf(W).double().T + res.double()
+    assert rel_err(x1, ref) < 1e-5
+    gam2 = torch.randn(N, generator=g); bet2 = torch.randn(N, generator=g)
+    l0 = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=1, residual=res.float().to(dev), ln=(gam2.to(dev), bet2.to(dev)))
+    l1 = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=1, residual=res.to(dev), ln=(gam2.to(dev), bet2.to(dev)))
+    assert all(torch.equal(p, q) for p, q in zip(l0, l1))
+    # K = 512 / 768 shapes take other instantiations of the same kernel
+    for K2 in (512, 768):
+        A2 = _bf(torch.randn(M, K2, generator=g)); W2 = torch.randn(N, K2, generator=g) / math.sqrt(K2)
+        y0 = ops.gemm_nt(A2.to(dev), W2.to(dev), None, npass=1, residual=res.float().to(dev))
+        y1 = ops.gemm_nt(A2.to(dev), W2.to(dev), None, npass=1, residual=res.to(dev), out_dtype=torch.bfloat16)
+        assert torch.equal(y1, y0.to(torch.bfloat16))
+    # a bf16 residual on a shape that falls back to the k-tiled kernel is refused, not mis-read
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(A[:100].to(dev), W.to(dev), None, npass=1, residual=res[:100].to(dev))
+
+
 def test_ln_bwd_bf16_dropped_output(dev):
     ops = _ops()
     M, N = 777, 256

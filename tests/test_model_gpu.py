@@ -209,6 +209,45 @@ def test_dropout_training_mode(dev):
     assert all(max_err(p, q) == 0.0 for p, q in zip(a, b))
 
 
+def test_bf16_gradient_stream_option_matches_default_within_rounding(dev, monkeypatch):
+    """HFTT_BF16_GRAD=1 (opt-in, off by default because it measured net-zero): the encoder-side gradient stream stored as bf16.
+    Every gradient must stay within bf16 rounding of the default bf16-mode gradient (same seed, dropout on, same masks)."""
+    from hftt_hip.trainer import TrainStep
+    # the option needs the paper's width (d = 256, ff = 512: every encoder dX on the A-stationary GEMM); frames/bins/notes stay small
+    cfg = O.HfttConfig(n_margin=4, n_frame=16, n_bin=48, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512,
+                       enc_layer=2, dec_layer=2, enc_head=4, dec_head=4, n_note=12, n_velocity=16)
+    B = 2
+    x = (O.synth_spec(B, cfg, salt=21) * 0.5).to(dev)
+    ld = _to_dev(O.synth_labels(B, cfg, salt=22), dev)
+    grads = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('HFTT_BF16_GRAD', flag)
+        model = util.build_model(cfg, 7, dropout=0.1).to(dev)
+        model.hftt_precision = 'bf16'
+        model.train()
+        ts = TrainStep(model, lr=1e-3)
+        ts.forward_backward(x, *ld)
+        torch.cuda.synchronize()
+        eng = ts.engine
+        assert torch.isfinite(eng.flat_grads).all()
+        assert eng._ws[B]['bf16_grad'] == (flag == '1')          # the option engaged (and only when asked for)
+        grads[flag] = {name: eng.flat_grads[o:o + n].clone() for (name, _, o, n) in eng._bound}
+    worst = 0.0
+    for name, g0 in grads['0'].items():
+        g1 = grads['1'][name]
+        scale = g0.abs().max().item()
+        if name.endswith('fc_k.bias'):
+            # true gradient is identically zero (softmax ignores a constant added to every key's logit): what both runs hold is
+            # bf16-mode rounding noise (measured 3e-5 .. 3e-3 here), so a relative difference is noise / noise.  The option must
+            # not make that noise bigger.
+            assert g1.abs().max().item() <= 2.0 * scale + 1e-6, (name, scale, g1.abs().max().item())
+            continue
+        if scale < 1e-7:
+            continue
+        worst = max(worst, (g1 - g0).abs().max().item() / scale)
+    assert 0.0 < worst < 3e-2, worst          # measured 9e-3; > 0: the option really changed the arithmetic
+
+
 def test_backward_reports_gradient_buckets_when_final(dev):
     """HfttEngine.backward(on_ready=...) (the hook hftt_hip/ddp.py overlaps its all-reduce on): the three flat ranges tile
     the gradient buffer, and each range already holds its final value at the moment it is reported (stream-ordered
