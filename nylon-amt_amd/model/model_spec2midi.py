@@ -36,7 +36,7 @@ class Model_SPEC2MIDI(nn.Module):
         super().__init__()
         self.encoder_spec2midi = encoder
         self.decoder_spec2midi = decoder
-        self.hftt_precision = os.environ.get('HFTT_PRECISION', 'parity')   # 'parity' (split-bf16, <=1e-3) or 'bf16'
+        self.hftt_precision = os.environ.get('HFTT_PRECISION', 'parity')   # 'parity' (exact-fp32 MFMA, <= 1e-3 of the reference) or 'bf16' (throughput mode)
         self.hftt_seed = 1234
 
     # ---- engine management -------------------------------------------------------------------
