@@ -17,9 +17,11 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, 'nylon-amt_amd'), os.path.join(ROOT, 'tests')):
+for p in (ROOT, os.path.join(ROOT, 'nylon-amt_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+import collections   # noqa: E402
 
 import torch   # noqa: E402
 
@@ -29,19 +31,52 @@ PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_CLIP = 249.44    # SURVEY.md section 8(d), paper size, forward; training = 3x
 
 
+# Workload definitions of the MEASURED leg.  Nothing on this leg touches oracle/ (test infrastructure): the configurations restate
+# the reference's defaults (m_training.py:55-60 tiny, hFT paper size), the model is built from the product package exactly as
+# m_training.py:117-141 does, and the clips are random tensors of the MAESTRO clip contract (training/dataset.py:49-71).
+# tests/test_boundary.py checks these dictionaries against the oracle's configurations so they cannot drift apart.
+BenchCfg = collections.namedtuple('BenchCfg', 'n_margin n_frame n_bin cnn_channel cnn_kernel hid_dim pf_dim enc_layer dec_layer enc_head dec_head n_note n_velocity')
+CONFIGS = {'paper': BenchCfg(32, 128, 256, 4, 5, 256, 512, 3, 3, 4, 4, 88, 128),
+           'tiny': BenchCfg(32, 128, 256, 4, 5, 64, 128, 2, 2, 2, 2, 88, 128)}
+
+
 def build_model(cfg, seed, dropout, dev):
-    import util
-    model = util.build_model(cfg, seed, dropout=dropout)
+    """m_training.py:109-141: seed, positional construction, xavier_uniform on every weight with dim > 1, .to(device)."""
+    from model.model_spec2midi import Encoder_SPEC2MIDI, Decoder_SPEC2MIDI, Model_SPEC2MIDI
+    torch.manual_seed(seed)
+    enc = Encoder_SPEC2MIDI(cfg.n_margin, cfg.n_frame, cfg.n_bin, cfg.cnn_channel, cfg.cnn_kernel, cfg.hid_dim, cfg.enc_layer, cfg.enc_head,
+                            cfg.pf_dim, dropout, 'cpu')
+    dec = Decoder_SPEC2MIDI(cfg.n_frame, cfg.n_bin, cfg.n_note, cfg.n_velocity, cfg.hid_dim, cfg.dec_layer, cfg.dec_head, cfg.pf_dim, dropout, 'cpu')
+    model = Model_SPEC2MIDI(enc, dec)
+    for m in model.modules():
+        if hasattr(m, 'weight') and m.weight is not None and m.weight.dim() > 1:
+            torch.nn.init.xavier_uniform_(m.weight.data)
     return model.to(dev)
+
+
+def synthetic_batch(cfg, B, seed, dev):
+    """One batch of the clip contract: log-mel-like spectrogram [B, n_bin, margin+frames+margin] (N(-7, 3^2) clipped to the
+    reference's [-18.42, 6] range), onset/offset targets in [0, 1], binary mpe, velocity classes (int64)."""
+    g = torch.Generator().manual_seed(seed)
+    W = cfg.n_frame + 2 * cfg.n_margin
+    spec = (torch.randn(B, cfg.n_bin, W, generator=g) * 3.0 - 7.0).clamp_(-18.420681, 6.0)
+    shp = (B, cfg.n_frame, cfg.n_note)
+    active = torch.rand(shp, generator=g) < 0.05
+    onset = torch.rand(shp, generator=g) * (torch.rand(shp, generator=g) < 0.02)
+    offset = torch.rand(shp, generator=g) * (torch.rand(shp, generator=g) < 0.02)
+    velocity = torch.randint(1, cfg.n_velocity, shp, generator=g) * active
+    return spec.to(dev), (onset.to(dev).contiguous(), offset.to(dev).contiguous(), active.float().to(dev).contiguous(),
+                          velocity.to(torch.int64).to(dev).contiguous())
 
 
 def cpu_baseline(cfg, threads):
     """CPU oracle (port of the reference algorithm), one training step of batch 1 at the SAME model config."""
-    from oracle import hftt_oracle as O
-    import util
+    from oracle import hftt_oracle as O       # the ONLY use of oracle/ in this file: the reported CPU baseline
     torch.set_num_threads(threads)
-    model = util.build_model(cfg, 1234)
-    sd = {k: v.clone().requires_grad_(True) for k, v in util.sd_cpu(model).items()}
+    ocfg = O.HfttConfig(**cfg._asdict())
+    model = build_model(cfg, 1234, 0.1, 'cpu')
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    cfg = ocfg
     names = list(sd.keys())
     m = [torch.zeros_like(sd[k]) for k in names]
     v = [torch.zeros_like(sd[k]) for k in names]
@@ -90,7 +125,6 @@ def main():
     ap.add_argument('--no-profile', action='store_true', help='skip per-launch HIP events (roofline object becomes null)')
     args = ap.parse_args()
 
-    from oracle import hftt_oracle as O       # cpu_baseline leg + synthetic data generators only
     from hftt_hip.trainer import TrainStep
     from hftt_hip.profiler import LaunchProfiler
 
@@ -113,7 +147,7 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
-    cfg = O.PAPER if args.config == 'paper' else O.TINY
+    cfg = CONFIGS[args.config]
     B = args.batch
     model = build_model(cfg, 1234, args.dropout, dev)
     model.hftt_precision = args.precision
@@ -131,9 +165,7 @@ def main():
     n_batches = 4
     data = []
     for i in range(n_batches):
-        x = O.synth_spec(B, cfg, salt=1000 * (rank + 1) + i).to(dev)
-        lab = tuple(t.to(dev).contiguous() for t in O.synth_labels(B, cfg, salt=5000 * (rank + 1) + i))
-        data.append((x, lab))
+        data.append(synthetic_batch(cfg, B, 1234 + 1000 * rank + i, dev))
 
     def sync():
         torch.cuda.synchronize()

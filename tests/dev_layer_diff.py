@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): compare every engine activation buffer against the CPU oracle's intermediates, layer by layer,
-and every gradient, to localise numerical error.  Usage: python tools/layer_diff.py [tiny|paper|mini] [parity|bf16]"""
+and every gradient, to localise numerical error.  Usage: python tests/dev_layer_diff.py [tiny|paper|mini] [parity|bf16]"""
 import os, sys, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))

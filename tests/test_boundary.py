@@ -83,3 +83,27 @@ def test_no_cpu_fallback():
     import os
     src = open(os.path.join(util.ROOT, 'nylon-amt_amd', 'hftt_hip', 'engine.py')).read() + open(os.path.join(util.ROOT, 'nylon-amt_amd', 'model', 'model_spec2midi.py')).read()
     assert 'oracle' not in src                      # the product path never touches the oracle
+
+
+def test_bench_measured_leg_is_oracle_free_and_configs_match():
+    """bench.py may use oracle/ only for its reported cpu_baseline; its own workload tables must equal the oracle's configurations
+    (both restate m_training.py's defaults), and its model builder must produce the reference's parameter set."""
+    import os
+    import re
+    import bench
+    from oracle import hftt_oracle as O
+    for name, ocfg in (('paper', O.PAPER), ('tiny', O.TINY)):
+        assert bench.CONFIGS[name]._asdict() == {k: getattr(ocfg, k) for k in bench.BenchCfg._fields}, name
+    src = open(os.path.join(util.ROOT, 'bench.py')).read()
+    imports = [m.start() for m in re.finditer(r'^\s*(from oracle|import oracle)', src, re.M)]
+    a, b = src.index('def cpu_baseline('), src.index('def pmc_traffic_bytes(')
+    assert len(imports) == 1 and a < imports[0] < b            # the single import sits inside cpu_baseline()
+    assert 'tests' not in src[src.index('for p in (ROOT'):src.index('import collections')]     # tests/ is not on bench's path
+    m1 = bench.build_model(bench.CONFIGS['tiny'], 5, 0.1, 'cpu')
+    m2 = util.build_model(O.TINY, 5, dropout=0.1)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    assert list(sd1.keys()) == list(sd2.keys())
+    assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)        # same construction order and init stream as m_training.py
+    x, lab = bench.synthetic_batch(bench.CONFIGS['tiny'], 2, 1, 'cpu')
+    assert x.shape == (2, 256, 192) and x.min() >= -18.420681 - 1e-6 and x.max() <= 6.0
+    assert [t.shape for t in lab] == [(2, 128, 88)] * 4 and lab[3].dtype == torch.int64 and int(lab[3].max()) < 128

@@ -8,11 +8,10 @@ about transcription accuracy -- they only show that decode + scoring run on real
 One process = one GPU; with N GPUs the clips of a file are sharded N ways with no collective (replicas only)."""
 import json, os, pickle, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd'))
 import numpy as np
 import torch
-from oracle import hftt_oracle as O          # synthetic-input helpers / config only
-import util
+import bench                                  # paper-size workload table + model builder (no oracle on this path)
 from model.amt import AMT
 from evaluation.metrics import note_metrics, frame_metrics
 
@@ -34,7 +33,7 @@ for n in notes:                                     # decaying harmonic pluck
 config = json.loads('{"feature": {"sr": 16000, "hop_sample": 256, "mel_bins": 256, "n_bins": 256, "fft_bins": 2048, "window_length": 2048,'
                     ' "log_offset": 1e-8, "window": "hann", "pad_mode": "constant"}, "input": {"margin_b": 32, "margin_f": 32, "num_frame": 128,'
                     ' "min_value": -18.420681}, "midi": {"note_min": 21, "note_max": 108, "num_note": 88, "num_velocity": 128}}')
-model = util.build_model(O.PAPER, 1234)
+model = bench.build_model(bench.CONFIGS['paper'], 1234, 0.1, 'cpu')
 model.hftt_precision = precision
 tmp = tempfile.mkdtemp()
 with open(os.path.join(tmp, 'model.pkl'), 'wb') as fh:

@@ -2,20 +2,17 @@
 """Dev tool (GPU box): gradient differences between HFTT_BF16_GRAD settings at a d=256 mini config, per tensor."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd'))
 import torch
-from oracle import hftt_oracle as O
+import bench
 from hftt_hip.trainer import TrainStep
-import util
 dev = torch.device('cuda:0')
-cfg = O.HfttConfig(n_margin=4, n_frame=16, n_bin=48, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512,
-                   enc_layer=2, dec_layer=2, enc_head=4, dec_head=4, n_note=12, n_velocity=16)
+cfg = bench.BenchCfg(4, 16, 48, 4, 5, 256, 512, 2, 2, 4, 4, 12, 16)
 B = 2
-x = (O.synth_spec(B, cfg, salt=21) * 0.5).to(dev)
-ld = tuple(t.to(dev).contiguous() for t in O.synth_labels(B, cfg, salt=22))
+x, ld = bench.synthetic_batch(cfg, B, 21, dev)
 def run(flag, p):
     os.environ['HFTT_BF16_GRAD'] = flag
-    model = util.build_model(cfg, 7, dropout=p).to(dev)
+    model = bench.build_model(cfg, 7, p, dev)
     model.hftt_precision = 'bf16'
     model.train()
     ts = TrainStep(model, lr=1e-3)

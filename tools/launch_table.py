@@ -3,12 +3,11 @@
 Usage: python tools/launch_table.py [--precision bf16|parity] [--steps N] [--raw]"""
 import os, sys, argparse
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd'))
 import torch
-from oracle import hftt_oracle as O
+import bench                      # workload tables / model builder / synthetic clips of the measured leg (no oracle)
 from hftt_hip.trainer import TrainStep
 from hftt_hip.profiler import LaunchProfiler
-import util
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--precision', default='bf16')
@@ -18,13 +17,12 @@ ap.add_argument('--raw', action='store_true', help='print every launch of one st
 args = ap.parse_args()
 
 dev = torch.device('cuda:0')
-cfg, B = O.PAPER, args.batch
-model = util.build_model(cfg, 1234, dropout=0.1).to(dev)
+cfg, B = bench.CONFIGS['paper'], args.batch
+model = bench.build_model(cfg, 1234, 0.1, dev)
 model.hftt_precision = args.precision
 model.train()
 ts = TrainStep(model, lr=1e-4)
-x = O.synth_spec(B, cfg, salt=1).to(dev)
-lab = tuple(t.to(dev).contiguous() for t in O.synth_labels(B, cfg, salt=2))
+x, lab = bench.synthetic_batch(cfg, B, 1, dev)
 for _ in range(3):
     ts(x, *lab)
 torch.cuda.synchronize()
