@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HFTT_ABI_VERSION 2
+#define HFTT_ABI_VERSION 3
 
 int hftt_abi_version(void);
 const char* hftt_last_error(void);
@@ -87,6 +87,84 @@ typedef struct {
   const float* ln_gamma; const float* ln_beta; float* pre_ln_out; float* ln_mean; float* ln_rstd;
 } hftt_gemm_nt_desc;
 int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * "Strip" kernels (bf16 mode): the MI355X-first form of every nn.Linear on the path whose output width is a multiple of
+ * 256 -- MultiHeadAttentionLayer.fc_q/k/v/o (model_spec2midi.py:328-330,357), PositionwiseFeedforwardLayer (:362-378),
+ * the post-norm residual blocks of EncoderLayer / DecoderLayer (:236,242,262,268,289,295,301) and their dX in backward.
+ *
+ * Geometry: a workgroup of 4 waves owns 128 consecutive tokens; a wave owns a 32-token strip and keeps it in registers as the
+ * MFMA *B* operand (lane = (token, half): for every 32-feature group it holds 16 consecutive features).  The weights are the
+ * *A* operand: pre-packed once per step into 1 KB MFMA fragments in consumption order ("strip pack"), streamed L2 -> LDS by
+ * LDS-DMA through a 4 x 16 KB ring shared by the four waves.  v_mfma_f32_32x32x16_bf16 then leaves C^T in the same
+ * (token, half) x 16-consecutive-features layout, so bias / ReLU / dropout / gate / residual / LayerNorm are per-lane register
+ * work (row statistics = 128 own values + one v_permlane32_swap), the result of one GEMM is directly the B operand of the
+ * next (fused FFN: the p-wide hidden never leaves the registers), and every global access is 16 bytes per lane.
+ *
+ * strip pack: logical weight matrix Wl[N, K] (out x in features, i.e. the nn.Linear weight for a forward GEMM, its transpose
+ * for a dX GEMM).  Fragment(tile, pt, u), 64 lanes x 8 bf16: lane (i = lane & 31, hk = lane >> 5) holds
+ *   Wl[32*tile + c(i)][32*pt + 16*hk + 8*u + 0..7],   c(i) = 16*((i >> 2) & 1) + (i & 3) + 4*(i >> 3).
+ * Slots of 16 fragments (16 KB), order 0 ("linear"): slot = pass*(K/32) + pt, fragment = u*8 + (tile & 7), pass = tile >> 3;
+ * order 1 ("tile-major", K == 256): slot = tile, fragment = 2*pt + u.  The stream position of a slot is
+ * slot_offset + slot_stride*slot (the fused FFN interleaves fc_1 tiles with fc_2 K-slices: stride 2, offsets 0 / 1).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t src_off;              /* element offset of the fp32 source matrix inside params */
+  int64_t dst_off;              /* bf16-element offset of stream slot 0 inside wstrip */
+  int32_t rows, cols, src_ld;   /* source [rows, cols], row stride src_ld */
+  int32_t transpose;            /* 0: Wl[n0 + r][k0 + c] = src[r][c];  1: Wl[n0 + c][k0 + r] = src[r][c] */
+  int32_t n0, k0;               /* position inside the logical matrix (k0 % 8 == 0) */
+  int32_t K;                    /* logical K (multiple of 32) */
+  int32_t order;                /* 0 linear, 1 tile-major */
+  int32_t slot_stride, slot_offset;
+} hftt_strip_pack_entry;
+int hftt_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_pack_entry* table_dev, int n_entries, void* stream);
+
+#define HFTT_SL_X_BF16 1u       /* x stored as bf16 (else fp32, rounded to bf16 on load) */
+#define HFTT_SL_C_BF16 2u       /* C (and pre_ln_out) stored as bf16 */
+#define HFTT_SL_RES_BF16 4u     /* residual stored as bf16 */
+#define HFTT_SL_RELU 8u
+/* C[M,N] = epi(x[M,K] . Wl[N,K]^T + bias): same epilogue order as hftt_gemm_nt (relu, out_scale, gate, dropout, residual,
+ * LayerNorm over N == 256).  N % 256 == 0; K % 32 == 0 and (K <= 256 or K % 256 == 0); gate is bf16. */
+typedef struct {
+  int32_t M, N, K; uint32_t flags;
+  const void* x; int64_t ldx;
+  const uint16_t* w;                  /* strip pack, order 0 */
+  const float* bias;                  /* [N] or NULL */
+  void* C; int64_t ldc;
+  float out_scale;
+  float gate_scale;
+  const uint16_t* gate; int64_t ldg;  /* bf16 [M, N] or NULL: v = gate > 0 ? v*gate_scale : 0 */
+  float drop_p; uint32_t drop_site; uint64_t drop_seed;
+  const void* residual; int64_t ldr; int32_t res_mod; int32_t pad;
+  const float* ln_gamma; const float* ln_beta; void* pre_ln_out; float* ln_mean; float* ln_rstd;
+} hftt_strip_desc;
+int hftt_strip_linear(const hftt_strip_desc* d, void* stream);
+
+/* Fused position-wise feed-forward block (model_spec2midi.py:369-378 + the post-norm of :242/:268/:301), d == 256:
+ *   h = dropout_h(relu(x W1^T + b1))      [M, p] stays in registers (optionally also written as bf16 for backward)
+ *   y = LayerNorm(x + dropout_o(h W2^T + b2)) * gamma + beta
+ * and, with mode 1, the dX half of its backward:
+ *   dh = gate(h) * (dy W2) * gate_scale   (written as bf16 for the weight-gradient GEMMs)
+ *   dx = dh W1 + residual
+ * w = ONE interleaved strip stream: slot 2t = tile t of the first matrix (order 1), slot 2t+1 = K-slice t of the second
+ * (order 0).  p % 32 == 0. */
+typedef struct {
+  int32_t M, d, p; uint32_t flags;    /* HFTT_SL_X_BF16 / C_BF16 / RES_BF16 */
+  int32_t mode; int32_t pad;
+  const void* x; int64_t ldx;
+  const uint16_t* w;
+  const float* b1; const float* b2;   /* [p], [d] (mode 0) */
+  uint16_t* h_out; int64_t ldh;       /* mode 0: post-dropout hidden (bf16) or NULL; mode 1: dh (bf16, required) */
+  const uint16_t* gate; int64_t ldg;  /* mode 1: stored hidden (bf16) */
+  float gate_scale;
+  float drop_p; uint32_t site_h, site_o; uint64_t drop_seed;
+  const void* residual; int64_t ldr;  /* mode 0: NULL = x itself; mode 1: added to dx (or NULL) */
+  const float* ln_gamma; const float* ln_beta; void* pre_ln_out; float* ln_mean; float* ln_rstd;   /* mode 0 */
+  void* y; int64_t ldy;
+} hftt_ffn_desc;
+int hftt_ffn_res_ln_fwd(const hftt_ffn_desc* d, void* stream);   /* mode 0 */
+int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream);       /* mode 1 */
 
 /* ---------------------------------------------------------------------------------------------
  * TN GEMM (weight gradient):  dW[N,K] = out_scale * dY[M,N]^T . X[M,K],  db[N] = colsum(dY)

@@ -115,15 +115,24 @@ __device__ __forceinline__ uint32_t hftt_hash(uint64_t seed, uint32_t site, uint
   x ^= x >> 16;
   return x;
 }
-// keep threshold: keep iff hash < thr, thr = (1-p)*2^32 (clamped)
+// One 32-bit hash serves TWO consecutive elements (2q, 2q+1): each gets a 16-bit field compared with a 16-bit threshold, so
+// the keep probability is quantised to 1/65536 (p = 0.1 -> 0.100006).  keep(idx) = field(idx & 1) of hash(idx >> 1) < thr.
+// Kernels whose lanes own adjacent elements hash once per pair (hftt_keep_pair); every other site calls hftt_keep per element
+// and gets the same decisions.
 __host__ __device__ inline uint32_t hftt_keep_thr(float p) {
-  double k = (1.0 - (double)p) * 4294967296.0;
-  if (k >= 4294967295.0) return 0xFFFFFFFFu;
+  double k = (1.0 - (double)p) * 65536.0;
+  if (k >= 65536.0) return 65536u;
   if (k <= 0.0) return 0u;
   return (uint32_t)k;
 }
 __device__ __forceinline__ bool hftt_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr) {
-  return hftt_hash(seed, site, idx) < thr;
+  const uint32_t w = hftt_hash(seed, site, idx >> 1);
+  return ((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) < thr;
+}
+// both decisions of the pair (2q, 2q+1), q = pair index: bit 0 = keep(2q), bit 1 = keep(2q+1)
+__device__ __forceinline__ uint32_t hftt_keep_pair(uint64_t seed, uint32_t site, uint64_t q, uint32_t thr) {
+  const uint32_t w = hftt_hash(seed, site, q);
+  return ((w & 0xFFFFu) < thr ? 1u : 0u) | ((w >> 16) < thr ? 2u : 0u);
 }
 
 // ---- cross-lane traffic without the LDS crossbar ----------------------------------------------------------------

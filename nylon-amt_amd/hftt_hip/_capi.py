@@ -78,6 +78,42 @@ class LnBwdDesc(C.Structure):
                 ('ws', c_f32p), ('drop_bf16', C.c_uint32), ('io_flags', C.c_uint32)]
 
 
+class StripPackEntry(C.Structure):
+    _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64),
+                ('rows', C.c_int32), ('cols', C.c_int32), ('src_ld', C.c_int32), ('transpose', C.c_int32),
+                ('n0', C.c_int32), ('k0', C.c_int32), ('K', C.c_int32), ('order', C.c_int32),
+                ('slot_stride', C.c_int32), ('slot_offset', C.c_int32)]
+
+
+class StripDesc(C.Structure):
+    _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('flags', C.c_uint32),
+                ('x', C.c_void_p), ('ldx', C.c_int64),
+                ('w', C.c_void_p), ('bias', c_f32p),
+                ('C', C.c_void_p), ('ldc', C.c_int64),
+                ('out_scale', C.c_float), ('gate_scale', C.c_float),
+                ('gate', C.c_void_p), ('ldg', C.c_int64),
+                ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
+                ('residual', C.c_void_p), ('ldr', C.c_int64), ('res_mod', C.c_int32), ('pad', C.c_int32),
+                ('ln_gamma', c_f32p), ('ln_beta', c_f32p), ('pre_ln_out', C.c_void_p), ('ln_mean', c_f32p), ('ln_rstd', c_f32p)]
+
+
+class FfnDesc(C.Structure):
+    _fields_ = [('M', C.c_int32), ('d', C.c_int32), ('p', C.c_int32), ('flags', C.c_uint32),
+                ('mode', C.c_int32), ('pad', C.c_int32),
+                ('x', C.c_void_p), ('ldx', C.c_int64),
+                ('w', C.c_void_p), ('b1', c_f32p), ('b2', c_f32p),
+                ('h_out', C.c_void_p), ('ldh', C.c_int64),
+                ('gate', C.c_void_p), ('ldg', C.c_int64),
+                ('gate_scale', C.c_float),
+                ('drop_p', C.c_float), ('site_h', C.c_uint32), ('site_o', C.c_uint32), ('drop_seed', C.c_uint64),
+                ('residual', C.c_void_p), ('ldr', C.c_int64),
+                ('ln_gamma', c_f32p), ('ln_beta', c_f32p), ('pre_ln_out', C.c_void_p), ('ln_mean', c_f32p), ('ln_rstd', c_f32p),
+                ('y', C.c_void_p), ('ldy', C.c_int64)]
+
+
+SL_X_BF16, SL_C_BF16, SL_RES_BF16, SL_RELU = 1, 2, 4, 8
+
+
 class LossDesc(C.Structure):
     _fields_ = [('n', C.c_int64), ('V', C.c_int32), ('pad', C.c_int32),
                 ('prob', c_f32p * 6), ('vel', c_f32p * 2),
@@ -103,6 +139,10 @@ SIGNATURES = {
     'hftt_device_cus': (C.c_int, []),
     'hftt_prep_weights': (C.c_int, [c_f32p, c_u16p, c_u16p, c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
     'hftt_gemm_nt': (C.c_int, [C.POINTER(GemmNtDesc), C.c_void_p]),
+    'hftt_strip_pack': (C.c_int, [c_f32p, c_u16p, C.c_void_p, C.c_int, C.c_void_p]),
+    'hftt_strip_linear': (C.c_int, [C.POINTER(StripDesc), C.c_void_p]),
+    'hftt_ffn_res_ln_fwd': (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
+    'hftt_ffn_bwd_dx': (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
     'hftt_gemm_tn_ws_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'hftt_gemm_tn': (C.c_int, [C.POINTER(GemmTnDesc), C.c_void_p]),
     'hftt_attn_fwd': (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
@@ -132,6 +172,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 3
 
 
 class HfttError(RuntimeError):
@@ -151,7 +192,7 @@ def lib():
             fn = getattr(handle, name)   # AttributeError if the symbol is missing: also loud
             fn.restype = res
             fn.argtypes = args
-        if handle.hftt_abi_version() != 2:
+        if handle.hftt_abi_version() != ABI_VERSION:
             raise HfttError('libhftt_hip.so ABI version mismatch')
         _lib = handle
     return _lib

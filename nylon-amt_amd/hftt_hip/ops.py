@@ -10,7 +10,8 @@ import math
 import numpy as np
 import torch
 
-from ._capi import (AttnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, check, lib)
+from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
+                    SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, check, lib)
 
 
 def _stream(dev):
@@ -86,6 +87,114 @@ def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_
         extra = (pre, mean, rstd)
     check(lib().hftt_gemm_nt(C.byref(d), _stream(A.device)), 'gemm_nt')
     return (Cout,) + extra if extra else Cout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# strip kernels (bf16 mode): packed weights, token strips
+# ---------------------------------------------------------------------------------------------------------------------
+def strip_pack_table(entries, device):
+    arr = (StripPackEntry * len(entries))(*[StripPackEntry(*e) for e in entries])
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(entries)
+
+
+def strip_pack(w: torch.Tensor, transpose=False, order=0, out=None, slot_stride=1, slot_offset=0):
+    """fp32 [rows, cols] -> strip-packed bf16 stream of the logical matrix Wl = w (or w.T): int16 tensor of Wl.numel() elements
+    (or written into `out` at the given slot stride / offset)."""
+    _need_cuda(w)
+    w = w.contiguous().float()
+    rows, cols = w.shape
+    K = rows if transpose else cols
+    if out is None:
+        out = torch.zeros(w.numel() * slot_stride, dtype=torch.int16, device=w.device)
+    table, n = strip_pack_table([(0, 0, rows, cols, cols, 1 if transpose else 0, 0, 0, K, order, slot_stride, slot_offset)], w.device)
+    check(lib().hftt_strip_pack(w.data_ptr(), out.data_ptr(), table.data_ptr(), n, _stream(w.device)), 'strip_pack')
+    return out
+
+
+def ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
+    """Interleaved stream of the fused FFN.  forward: slot 2t = tile t of fc_1.weight [p, d] (tile-major), slot 2t+1 = K-slice t
+    of fc_2.weight [d, p].  backward (dX): first matrix = fc_2.weight^T [p, d], second = fc_1.weight^T [d, p]."""
+    out = torch.zeros(w1.numel() + w2.numel(), dtype=torch.int16, device=w1.device)
+    if not backward:
+        strip_pack(w1, False, 1, out, 2, 0)
+        strip_pack(w2, False, 0, out, 2, 1)
+    else:
+        strip_pack(w2, True, 1, out, 2, 0)
+        strip_pack(w1, True, 0, out, 2, 1)
+    return out
+
+
+def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, drop_seed=0,
+                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True):
+    """C = epi(x @ Wl.T + bias) with Wl given as its strip pack.  ln = (gamma, beta) -> (C, pre_ln, mean, rstd)."""
+    _need_cuda(x, wpack)
+    M, K = x.shape
+    Cout = torch.empty(M, N, device=x.device, dtype=out_dtype)
+    d = StripDesc()
+    d.M, d.N, d.K = M, N, K
+    d.flags = (SL_X_BF16 if x.dtype == BF16 else 0) | (SL_C_BF16 if out_dtype == BF16 else 0) | (SL_RELU if relu else 0) \
+        | (SL_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0)
+    d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else 0
+    d.C, d.ldc, d.out_scale, d.gate_scale = Cout.data_ptr(), N, out_scale, gate_scale
+    if gate is not None:
+        d.gate, d.ldg = gate.data_ptr(), gate.stride(0)
+    d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
+    if residual is not None:
+        d.residual, d.ldr, d.res_mod = residual.data_ptr(), residual.stride(0), res_mod
+    extra = ()
+    if ln is not None:
+        pre = torch.empty(M, N, device=x.device, dtype=out_dtype) if save_pre else None
+        mean = torch.empty(M, device=x.device)
+        rstd = torch.empty(M, device=x.device)
+        d.ln_gamma, d.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+        d.pre_ln_out, d.ln_mean, d.ln_rstd = (pre.data_ptr() if save_pre else 0), mean.data_ptr(), rstd.data_ptr()
+        extra = (pre, mean, rstd)
+    check(lib().hftt_strip_linear(C.byref(d), _stream(x.device)), 'strip_linear')
+    return (Cout,) + extra if extra else Cout
+
+
+def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_o=0, seed=0, save_hidden=True, save_pre=True, residual=None):
+    """Fused FFN block: y = LN(x + drop(fc_2(drop(relu(fc_1 x))))) -> (y, hidden | None, pre_ln | None, mean, rstd); all bf16."""
+    _need_cuda(x, wpack)
+    M, dm = x.shape
+    y = torch.empty(M, dm, device=x.device, dtype=BF16)
+    hid = torch.empty(M, p, device=x.device, dtype=BF16) if save_hidden else None
+    pre = torch.empty(M, dm, device=x.device, dtype=BF16) if save_pre else None
+    mean = torch.empty(M, device=x.device); rstd = torch.empty(M, device=x.device)
+    d = FfnDesc()
+    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, SL_X_BF16 | SL_C_BF16 | SL_RES_BF16, 0
+    d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
+    d.b1, d.b2 = b1.data_ptr(), b2.data_ptr()
+    if save_hidden:
+        d.h_out, d.ldh = hid.data_ptr(), p
+    d.drop_p, d.site_h, d.site_o, d.drop_seed = drop_p, site_h, site_o, seed
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    d.ln_gamma, d.ln_beta = gamma.data_ptr(), beta.data_ptr()
+    d.pre_ln_out = pre.data_ptr() if save_pre else 0
+    d.ln_mean, d.ln_rstd = mean.data_ptr(), rstd.data_ptr()
+    d.y, d.ldy = y.data_ptr(), dm
+    check(lib().hftt_ffn_res_ln_fwd(C.byref(d), _stream(x.device)), 'ffn_res_ln_fwd')
+    return y, hid, pre, mean, rstd
+
+
+def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None):
+    """dh = (hidden > 0) * (dy @ fc_2.weight) * gate_scale;  dx = dh @ fc_1.weight (+ residual) -> (dx, dh); all bf16."""
+    _need_cuda(dy, wpack_bwd, hidden)
+    M, dm = dy.shape
+    dx = torch.empty(M, dm, device=dy.device, dtype=BF16)
+    dh = torch.empty(M, p, device=dy.device, dtype=BF16)
+    d = FfnDesc()
+    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, SL_X_BF16 | SL_C_BF16 | SL_RES_BF16, 1
+    d.x, d.ldx, d.w = dy.data_ptr(), dy.stride(0), wpack_bwd.data_ptr()
+    d.h_out, d.ldh = dh.data_ptr(), p
+    d.gate, d.ldg, d.gate_scale = hidden.data_ptr(), hidden.stride(0), gate_scale
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    d.y, d.ldy = dx.data_ptr(), dm
+    check(lib().hftt_ffn_bwd_dx(C.byref(d), _stream(dy.device)), 'ffn_bwd_dx')
+    return dx, dh
 
 
 def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True):

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(_capi.SIGNATURES.keys()), declared ^ set(_capi.SIGNATURES.keys())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hftt_abi_version() == 2
+    assert lib.hftt_abi_version() == _capi.ABI_VERSION == 3
     assert lib.hftt_last_error() is not None
     # pure host helpers can be called without a GPU
     assert lib.hftt_gemm_tn_ws_bytes(1000, 256, 256) > 0
@@ -52,6 +52,15 @@ def test_argument_validation_without_gpu(lib):
     a.n_seq, a.n_heads, a.Lq, a.Lk, a.dh, a.npass = 1, 1, 300, 10, 64, 1
     assert lib.hftt_attn_fwd(C.byref(a), None) != 0
     assert b'1..256' in lib.hftt_last_error()
+    sd = _capi.StripDesc()
+    sd.M, sd.N, sd.K = 128, 200, 256
+    assert lib.hftt_strip_linear(C.byref(sd), None) != 0
+    assert b'multiple of 256' in lib.hftt_last_error()
+    fd = _capi.FfnDesc()
+    fd.M, fd.d, fd.p, fd.mode = 128, 128, 512, 0
+    assert lib.hftt_ffn_res_ln_fwd(C.byref(fd), None) != 0
+    assert b'd == 256' in lib.hftt_last_error()
+    assert lib.hftt_ffn_bwd_dx(C.byref(fd), None) != 0          # mode 0 descriptor handed to the mode 1 entry point
     with pytest.raises(_capi.HfttError):
         _capi.check(1, 'x')
 
@@ -60,7 +69,8 @@ def test_struct_layouts_match_the_c_compiler(lib, tmp_path):
     from hftt_hip import _capi
     structs = {'hftt_prep_entry': _capi.PrepEntry, 'hftt_gemm_nt_desc': _capi.GemmNtDesc, 'hftt_gemm_tn_desc': _capi.GemmTnDesc,
                'hftt_attn_desc': _capi.AttnDesc, 'hftt_fold_desc': _capi.FoldDesc, 'hftt_ln_bwd_desc': _capi.LnBwdDesc,
-               'hftt_loss_desc': _capi.LossDesc, 'hftt_logmel_desc': _capi.LogmelDesc}
+               'hftt_loss_desc': _capi.LossDesc, 'hftt_logmel_desc': _capi.LogmelDesc,
+               'hftt_strip_pack_entry': _capi.StripPackEntry, 'hftt_strip_desc': _capi.StripDesc, 'hftt_ffn_desc': _capi.FfnDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HDR, 'int main(void) {']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -1,0 +1,184 @@
+"""Strip kernels (csrc/strip_gemm.hip) through the C ABI against fp64 references on the same bf16-rounded operands:
+weight packing, hftt_strip_linear with every epilogue, the fused FFN block (hftt_ffn_res_ln_fwd) and the dX half of its
+backward (hftt_ffn_bwd_dx).  Reference of the arithmetic: model_spec2midi.py:322-378 (Linear / FFN), :236,242 (post-norm)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from util import rel_err, max_err, keep_mask_t
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _ops():
+    from hftt_hip import ops
+    return ops
+
+
+def bfr(t):
+    """round to bf16, back to fp64 (what the kernel's operands are)"""
+    return t.to(BF).double()
+
+
+def c_of_i(i):
+    return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3)
+
+
+def ref_pack(Wl, order):
+    """numpy restatement of the strip pack (include/hftt_hip.h): Wl [N, K] fp32 -> int16 stream."""
+    N, K = Wl.shape
+    wb = Wl.to(BF).view(torch.int16).numpy()
+    out = np.zeros(N * K, dtype=np.int16)
+    lane = np.arange(64)
+    i, hk = lane & 31, lane >> 5
+    for tile in range(N // 32):
+        for pt in range(K // 32):
+            for u in range(2):
+                if order == 0:
+                    slot, frag = (tile >> 3) * (K // 32) + pt, u * 8 + (tile & 7)
+                else:
+                    slot, frag = tile, pt * 2 + u
+                rows = 32 * tile + c_of_i(i)
+                cols = 32 * pt + 16 * hk + 8 * u
+                base = (slot * 16 + frag) * 512 + lane * 8
+                for j in range(8):
+                    out[base + j] = wb[rows, cols + j]
+    return out
+
+
+@pytest.mark.parametrize('N,K,order,transpose', [(256, 256, 0, False), (768, 256, 0, False), (256, 512, 0, True), (512, 256, 1, False), (512, 256, 1, True)])
+def test_strip_pack_matches_the_layout_definition(dev, N, K, order, transpose):
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + K + order)
+    Wl = torch.randn(N, K, generator=g)
+    src = Wl.T.contiguous() if transpose else Wl
+    got = ops.strip_pack(src.to(dev), transpose=transpose, order=order).cpu().numpy()
+    assert np.array_equal(got, ref_pack(Wl, order))
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 768, 256), (333, 256, 512), (4096, 512, 256), (130, 256, 768), (256, 256, 128)])
+@pytest.mark.parametrize('xdt,cdt', [(BF, BF), (torch.float32, torch.float32), (BF, torch.float32)])
+def test_strip_linear_plain(dev, M, N, K, xdt, cdt):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    ref = bfr(x) @ bfr(W).T + b.double()
+    wp = ops.strip_pack(W.to(dev))
+    out = ops.strip_linear(x.to(dev).to(xdt), wp, N, bias=b.to(dev), out_dtype=cdt)
+    assert out.dtype == cdt and rel_err(out, ref) < (6e-3 if cdt == BF else 1e-5)
+    out = ops.strip_linear(x.to(dev).to(xdt), wp, N, bias=b.to(dev), relu=True, out_scale=2.5, out_dtype=cdt)
+    assert rel_err(out, torch.relu(ref) * 2.5) < (6e-3 if cdt == BF else 1e-5)
+
+
+def test_strip_linear_epilogues(dev):
+    ops = _ops()
+    M, N, K = 777, 512, 256
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    gate = torch.randn(M, N, generator=g); res = torch.randn(M, N, generator=g); res7 = torch.randn(7, N, generator=g)
+    lin = bfr(x) @ bfr(W).T
+    wp = ops.strip_pack(W.to(dev))
+    xd = x.to(dev).to(BF)
+    rows = torch.arange(M)
+    # gate (ReLU / dropout backward of the hidden layer)
+    out = ops.strip_linear(xd, wp, N, gate=gate.to(dev).to(BF), gate_scale=1.25, out_dtype=torch.float32)
+    ref = torch.where(bfr(gate) > 0, lin * 1.25, torch.zeros((), dtype=torch.float64))
+    assert rel_err(out, ref) < 1e-5
+    # dropout, then a residual broadcast over rows (res_mod), fp32 and bf16 residual storage
+    p, site, seed = 0.3, 9, 1234567
+    mask = keep_mask_t(seed, site, (M, N), p).double()
+    for rdt in (torch.float32, BF):
+        out = ops.strip_linear(xd, wp, N, bias=b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res7.to(dev).to(rdt), res_mod=7,
+                               out_dtype=torch.float32)
+        rr = res7.to(rdt).double()[rows % 7]
+        ref = (lin + b.double()) * mask / (1.0 - float(np.float32(p))) + rr
+        assert rel_err(out, ref) < 1e-5
+    out = ops.strip_linear(xd, wp, N, residual=res.to(dev), out_dtype=BF)
+    assert rel_err(out, lin + res.double()) < 6e-3
+
+
+@pytest.mark.parametrize('M,K,p', [(1000, 256, 0.0), (515, 256, 0.2), (384, 512, 0.1), (256, 768, 0.0)])
+def test_strip_linear_residual_layernorm(dev, M, K, p):
+    """fc_o + dropout + residual + LayerNorm (model_spec2midi.py:236), all-bf16 storage, statistics in fp32."""
+    ops = _ops()
+    N = 256
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g); gam = 1 + 0.3 * torch.randn(N, generator=g); bet = torch.randn(N, generator=g)
+    wp = ops.strip_pack(W.to(dev))
+    site, seed = 4, 99
+    out, pre, mean, rstd = ops.strip_linear(x.to(dev).to(BF), wp, N, bias=b.to(dev), drop_p=p, drop_site=site, drop_seed=seed,
+                                            residual=res.to(dev).to(BF), ln=(gam.to(dev), bet.to(dev)))
+    lin = bfr(x) @ bfr(W).T + b.double()
+    if p > 0:
+        lin = lin * keep_mask_t(seed, site, (M, N), p).double() / (1.0 - float(np.float32(p)))
+    r = lin + bfr(res)
+    mu = r.mean(1, keepdim=True); var = r.var(1, unbiased=False, keepdim=True)
+    y = (r - mu) / torch.sqrt(var + 1e-5) * gam.double() + bet.double()
+    assert rel_err(pre, r) < 6e-3
+    assert max_err(mean, mu.squeeze(1)) < 1e-5 and rel_err(rstd, (1 / torch.sqrt(var + 1e-5)).squeeze(1)) < 1e-5
+    assert rel_err(out, y) < 8e-3
+    out2, pre2, _, _ = ops.strip_linear(x.to(dev).to(BF), wp, N, bias=b.to(dev), drop_p=p, drop_site=site, drop_seed=seed,
+                                        residual=res.to(dev).to(BF), ln=(gam.to(dev), bet.to(dev)), save_pre=False)
+    assert pre2 is None and torch.equal(out2, out)
+
+
+def _ffn_ref(x, W1, b1, W2, b2, gam, bet, p, site_h, site_o, seed):
+    M = x.shape[0]
+    h = torch.relu(bfr(x) @ bfr(W1).T + b1.double())
+    if p > 0:
+        h = h * keep_mask_t(seed, site_h, tuple(h.shape), p).double() / (1.0 - float(np.float32(p)))
+    hb = bfr(h)                                   # the hidden is the bf16 B operand of the second GEMM
+    o = hb @ bfr(W2).T + b2.double()
+    if p > 0:
+        o = o * keep_mask_t(seed, site_o, tuple(o.shape), p).double() / (1.0 - float(np.float32(p)))
+    r = bfr(x) + o
+    mu = r.mean(1, keepdim=True); var = r.var(1, unbiased=False, keepdim=True)
+    y = (r - mu) / torch.sqrt(var + 1e-5) * gam.double() + bet.double()
+    return hb, r, y, mu.squeeze(1), (1 / torch.sqrt(var + 1e-5)).squeeze(1)
+
+
+@pytest.mark.parametrize('M,pf,p', [(1000, 512, 0.0), (643, 512, 0.1), (256, 128, 0.25), (4096, 1024, 0.0)])
+def test_fused_ffn_forward(dev, M, pf, p):
+    """PositionwiseFeedforwardLayer + residual + LayerNorm in one launch (model_spec2midi.py:369-378, :242)."""
+    ops = _ops()
+    d = 256
+    g = torch.Generator().manual_seed(M + pf)
+    x = torch.randn(M, d, generator=g)
+    W1 = torch.randn(pf, d, generator=g) / math.sqrt(d); b1 = 0.5 * torch.randn(pf, generator=g)
+    W2 = torch.randn(d, pf, generator=g) / math.sqrt(pf); b2 = 0.5 * torch.randn(d, generator=g)
+    gam = 1 + 0.3 * torch.randn(d, generator=g); bet = torch.randn(d, generator=g)
+    wp = ops.ffn_pack(W1.to(dev), W2.to(dev))
+    site_h, site_o, seed = 11, 12, 424242
+    y, hid, pre, mean, rstd = ops.ffn_res_ln_fwd(x.to(dev).to(BF), wp, pf, b1.to(dev), b2.to(dev), gam.to(dev), bet.to(dev),
+                                                 drop_p=p, site_h=site_h, site_o=site_o, seed=seed)
+    hb, r, yr, mu, rs = _ffn_ref(x, W1, b1, W2, b2, gam, bet, p, site_h, site_o, seed)
+    assert rel_err(hid, hb) < 6e-3
+    assert rel_err(pre, r) < 6e-3
+    assert max_err(mean, mu) < 2e-3 and rel_err(rstd, rs) < 2e-3
+    assert rel_err(y, yr) < 1e-2
+    # inference form: nothing saved, same y
+    y2, hid2, pre2, _, _ = ops.ffn_res_ln_fwd(x.to(dev).to(BF), wp, pf, b1.to(dev), b2.to(dev), gam.to(dev), bet.to(dev),
+                                              drop_p=p, site_h=site_h, site_o=site_o, seed=seed, save_hidden=False, save_pre=False)
+    assert hid2 is None and pre2 is None and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize('M,pf', [(1000, 512), (384, 128)])
+def test_fused_ffn_backward_dx(dev, M, pf):
+    """dh = 1[h > 0] * (dy . W2) / keep;  dx = dh . W1 + residual -- the dX chain of the FFN block in loss.backward()."""
+    ops = _ops()
+    d = 256
+    g = torch.Generator().manual_seed(M * 3 + pf)
+    dy = torch.randn(M, d, generator=g)
+    W1 = torch.randn(pf, d, generator=g) / math.sqrt(d); W2 = torch.randn(d, pf, generator=g) / math.sqrt(pf)
+    hid = torch.relu(torch.randn(M, pf, generator=g)); res = torch.randn(M, d, generator=g)
+    wpb = ops.ffn_pack(W1.to(dev), W2.to(dev), backward=True)
+    dx, dh = ops.ffn_bwd_dx(dy.to(dev).to(BF), wpb, pf, hid.to(dev).to(BF), gate_scale=1.0 / 0.9, residual=res.to(dev).to(BF))
+    dh_ref = torch.where(bfr(hid) > 0, (bfr(dy) @ bfr(W2)) / 0.9, torch.zeros((), dtype=torch.float64))
+    assert rel_err(dh, dh_ref) < 6e-3
+    dx_ref = bfr(dh_ref) @ bfr(W1) + bfr(res)
+    assert rel_err(dx, dx_ref) < 1e-2

@@ -65,7 +65,8 @@ def sd_cpu(model):
 
 # ---- numpy emulation of the device dropout RNG (csrc/hftt_common.h: hftt_hash / hftt_keep_thr) ----
 def keep_mask(seed, site, idx, p):
-    """numpy emulation of hftt_hash / hftt_keep (csrc/hftt_common.h): splitmix64 key over (seed, site), 32-bit mixer per element."""
+    """numpy emulation of hftt_hash / hftt_keep (csrc/hftt_common.h): splitmix64 key over (seed, site), one 32-bit mixer per
+    PAIR of elements (idx >> 1); element idx takes the low (even) or high (odd) 16-bit field, compared with (1-p)*65536."""
     M64, M32 = np.uint64, np.uint32
     with np.errstate(over='ignore'):
         k = M64(seed) + M64(0x9E3779B97F4A7C15) * M64(site + 1)
@@ -73,14 +74,16 @@ def keep_mask(seed, site, idx, p):
         k ^= k >> M64(27); k *= M64(0x94D049BB133111EB)
         k ^= k >> M64(31)
         idx = idx.astype(np.uint64)
-        lo = (idx & M64(0xFFFFFFFF)).astype(np.uint32); hi = (idx >> M64(32)).astype(np.uint32)
+        q = idx >> M64(1)
+        lo = (q & M64(0xFFFFFFFF)).astype(np.uint32); hi = (q >> M64(32)).astype(np.uint32)
         x = (lo + M32(int(k) & 0xFFFFFFFF)) ^ (hi ^ (hi << M32(16)))
         x ^= x >> M32(16); x *= M32(0x7FEB352D)
         x ^= x >> M32(15); x ^= M32(int(k) >> 32); x *= M32(0x846CA68B)
         x ^= x >> M32(16)
-    k = (1.0 - float(np.float32(p))) * 4294967296.0
-    thr = 0xFFFFFFFF if k >= 4294967295.0 else int(k)
-    return x.astype(np.uint64) < np.uint64(thr)
+    field = np.where((idx & M64(1)).astype(bool), x >> M32(16), x & M32(0xFFFF)).astype(np.uint32)
+    kk = (1.0 - float(np.float32(p))) * 65536.0
+    thr = 65536 if kk >= 65536.0 else int(kk)
+    return field < np.uint32(thr)
 
 
 def keep_mask_t(seed, site, shape, p):
