@@ -261,10 +261,12 @@ typedef struct {
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   float* ws;            /* [n_wg, 2, N] partial sums; n_wg = hftt_ln_bwd_wgs(M) */
   uint32_t drop_bf16;   /* dr_drop is stored as bf16 */
-  uint32_t io_flags;    /* HFTT_LNB_DY_BF16: dy stored as bf16; HFTT_LNB_DR_BF16: dr stored as bf16 (bf16 gradient stream) */
+  uint32_t io_flags;    /* HFTT_LNB_DY_BF16: dy stored as bf16; HFTT_LNB_DR_BF16: dr stored as bf16 (bf16 gradient stream);
+                           HFTT_LNB_R_BF16: the saved pre-LayerNorm sum r stored as bf16 (strip forward kernels) */
 } hftt_ln_bwd_desc;
 #define HFTT_LNB_DY_BF16 1u
 #define HFTT_LNB_DR_BF16 2u
+#define HFTT_LNB_R_BF16 4u
 int32_t hftt_ln_bwd_wgs(int32_t M);
 int hftt_ln_bwd(const hftt_ln_bwd_desc* d, void* stream);
 int hftt_ln_bwd_reduce(const float* ws, int32_t n_wg, int32_t N, float* dgamma, float* dbeta, float beta, void* stream);
@@ -272,16 +274,20 @@ int hftt_ln_bwd_reduce(const float* ws, int32_t n_wg, int32_t N, float* dgamma, 
 /* ---------------------------------------------------------------------------------------------
  * Small data-movement kernels of the decoder (model_spec2midi.py:189-191, :172-175, :203-206).
  * --------------------------------------------------------------------------------------------- */
-/* y[(b,n), t, :] = dropout( x[(b,t), n, :]*scale + pos[t, :] )  */
+/* y[(b,n), t, :] = dropout( x[(b,t), n, :]*scale + pos[t, :] );  io_flags: HFTT_TE_X_BF16 (x), HFTT_TE_Y_BF16 (y) stored as bf16 */
+#define HFTT_TE_X_BF16 1u
+#define HFTT_TE_Y_BF16 2u
+#define HFTT_TE_M_BF16 4u
 int hftt_time_embed_fwd(const float* x, const float* pos, float* y, int32_t B, int32_t T, int32_t Nn, int32_t d,
-                        float scale, float drop_p, uint32_t site, uint64_t seed, void* stream);
-/* dx[(b,t), n, :] (+)= mask*dy[(b,n), t, :]*scale ; dym (optional, [(b,n),t,:]) = masked dy (for the pos-emb colsum) */
+                        float scale, float drop_p, uint32_t site, uint64_t seed, uint32_t io_flags, void* stream);
+/* dx[(b,t), n, :] (+)= mask*dy[(b,n), t, :]*scale ; dym (optional, [(b,n),t,:]) = masked dy (for the pos-emb colsum);
+ * io_flags: HFTT_TE_X_BF16 (dy), HFTT_TE_Y_BF16 (dx), HFTT_TE_M_BF16 (dym) stored as bf16 */
 int hftt_time_embed_bwd(const float* dy, float* dx, float* dym, int32_t B, int32_t T, int32_t Nn, int32_t d,
-                        float scale, float drop_p, uint32_t site, uint64_t seed, int32_t accumulate, void* stream);
-/* in-place dropout backward: g *= mask/(1-p) (same indexing as the forward epilogue: idx = row*N+col) */
-int hftt_dropout_bwd(float* g, int64_t n, float drop_p, uint32_t site, uint64_t seed, void* stream);
-/* colsum: out[j] = beta*out[j] + sum_r x[r*ld + j], j < n */
-int hftt_colsum(const float* x, int64_t rows, int64_t n, int64_t ld, float* out, float beta, float* ws, void* stream);
+                        float scale, float drop_p, uint32_t site, uint64_t seed, int32_t accumulate, uint32_t io_flags, void* stream);
+/* in-place dropout backward: g *= mask/(1-p) (same indexing as the forward epilogue: idx = row*N+col); n % 4 == 0; bf16 != 0: g is bf16 */
+int hftt_dropout_bwd(float* g, int64_t n, float drop_p, uint32_t site, uint64_t seed, uint32_t bf16, void* stream);
+/* colsum: out[j] = beta*out[j] + sum_r x[r*ld + j], j < n (x fp32, or bf16 when x_bf16 != 0; out fp32) */
+int hftt_colsum(const float* x, int64_t rows, int64_t n, int64_t ld, float* out, float beta, float* ws, uint32_t x_bf16, void* stream);
 int64_t hftt_colsum_ws_bytes(int64_t rows, int64_t n);
 /* heads: logits [S, ldl] with cols [0,V) velocity, V onset, V+1 offset, V+2 mpe ->
  *   velocity [.,V] raw, onset/offset/mpe sigmoid; time_major!=0: rows are (b,n,t) and outputs are (b,t,n). */

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
-  const bool dy_bf = g.io_flags & HFTT_LNB_DY_BF16, dr_bf = g.io_flags & HFTT_LNB_DR_BF16;
+  const bool dy_bf = g.io_flags & HFTT_LNB_DY_BF16, dr_bf = g.io_flags & HFTT_LNB_DR_BF16, r_bf = g.io_flags & HFTT_LNB_R_BF16;
   float gam[VPL], dg[VPL], db[VPL];
 #pragma unroll
   for (int e = 0; e < VPL; e++) { gam[e] = g.gamma[lane * VPL + e]; dg[e] = 0.f; db[e] = 0.f; }
@@ -136,12 +136,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
     const long base = row * N + lane * VPL;
     if (VPL == 4) {
       const float4 a = hftt_load4(g.dy, dy_bf, base);
-      const float4 b = *reinterpret_cast<const float4*>(g.r + base);
+      const float4 b = hftt_load4(g.r, r_bf, base);
       dy[0] = a.x; dy[1 % VPL] = a.y; dy[2 % VPL] = a.z; dy[3 % VPL] = a.w;
       r[0] = b.x; r[1 % VPL] = b.y; r[2 % VPL] = b.z; r[3 % VPL] = b.w;
     } else {
 #pragma unroll
-      for (int e = 0; e < VPL; e++) { dy[e] = dy_bf ? bf2f(reinterpret_cast<const unsigned short*>(g.dy)[base + e]) : g.dy[base + e]; r[e] = g.r[base + e]; }
+      for (int e = 0; e < VPL; e++) { dy[e] = dy_bf ? bf2f(reinterpret_cast<const unsigned short*>(g.dy)[base + e]) : g.dy[base + e]; r[e] = r_bf ? bf2f(reinterpret_cast<const unsigned short*>(g.r)[base + e]) : g.r[base + e]; }
     }
     const float mean = g.mean[row], rstd = g.rstd[row];
     float xh[VPL], gg[VPL], s1 = 0.f, s2 = 0.f;
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 
 // ------------------------------------------------------------------ decoder time transpose (+scale, +pos, dropout)
 __global__ void time_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ y,
-                                      int B, int T, int Nn, int d, float scale, float drop_p, uint32_t site, uint64_t seed) {
+                                      int B, int T, int Nn, int d, float scale, float drop_p, uint32_t site, uint64_t seed, uint32_t io_flags) {
+  const bool x_bf = io_flags & HFTT_TE_X_BF16, y_bf = io_flags & HFTT_TE_Y_BF16;
   const int d4 = d / 4;
   const long total = (long)B * Nn * T * d4;
   const uint32_t thr = hftt_keep_thr(drop_p);
@@ -236,18 +237,19 @@ __global__ void time_embed_fwd_kernel(const float* __restrict__ x, const float* 
     const int n = (int)((orow / T) % Nn);
     const int b = (int)(orow / ((long)T * Nn));
     const long irow = ((long)b * T + t) * Nn + n;
-    const float4 a = *reinterpret_cast<const float4*>(x + irow * d + c4 * 4);
+    const float4 a = hftt_load4(x, x_bf, irow * d + c4 * 4);
     const float4 p = *reinterpret_cast<const float4*>(pos + (long)t * d + c4 * 4);
     float v[4] = {a.x * scale + p.x, a.y * scale + p.y, a.z * scale + p.z, a.w * scale + p.w};
     if (drop_p > 0.f) {
 #pragma unroll
       for (int e = 0; e < 4; e++) v[e] = hftt_keep(seed, site, (uint64_t)(orow * d + c4 * 4 + e), thr) ? v[e] * inv_keep : 0.f;
     }
-    *reinterpret_cast<float4*>(y + orow * d + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    hftt_store4(y, y_bf, orow * d + c4 * 4, v[0], v[1], v[2], v[3]);
   }
 }
 __global__ void time_embed_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dym,
-                                      int B, int T, int Nn, int d, float scale, float drop_p, uint32_t site, uint64_t seed, int accumulate) {
+                                      int B, int T, int Nn, int d, float scale, float drop_p, uint32_t site, uint64_t seed, int accumulate, uint32_t io_flags) {
+  const bool dy_bf = io_flags & HFTT_TE_X_BF16, dx_bf = io_flags & HFTT_TE_Y_BF16, dym_bf = io_flags & HFTT_TE_M_BF16;
   const int d4 = d / 4;
   const long total = (long)B * Nn * T * d4;
   const uint32_t thr = hftt_keep_thr(drop_p);
@@ -259,29 +261,38 @@ __global__ void time_embed_bwd_kernel(const float* __restrict__ dy, float* __res
     const int n = (int)((orow / T) % Nn);
     const int b = (int)(orow / ((long)T * Nn));
     const long irow = ((long)b * T + t) * Nn + n;
-    const float4 a = *reinterpret_cast<const float4*>(dy + orow * d + c4 * 4);
+    const float4 a = hftt_load4(dy, dy_bf, orow * d + c4 * 4);
     float v[4] = {a.x, a.y, a.z, a.w};
     if (drop_p > 0.f) {
 #pragma unroll
       for (int e = 0; e < 4; e++) v[e] = hftt_keep(seed, site, (uint64_t)(orow * d + c4 * 4 + e), thr) ? v[e] * inv_keep : 0.f;
     }
-    if (dym != nullptr) *reinterpret_cast<float4*>(dym + orow * d + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
-    float4* dst = reinterpret_cast<float4*>(dx + irow * d + c4 * 4);
+    if (dym != nullptr) hftt_store4(dym, dym_bf, orow * d + c4 * 4, v[0], v[1], v[2], v[3]);
     float4 o = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
-    if (accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-    *dst = o;
+    if (accumulate) { const float4 old = hftt_load4(dx, dx_bf, irow * d + c4 * 4); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+    hftt_store4(dx, dx_bf, irow * d + c4 * 4, o.x, o.y, o.z, o.w);
   }
 }
-__global__ void dropout_bwd_kernel(float* __restrict__ gbuf, long n, float drop_p, uint32_t site, uint64_t seed) {
+__global__ void dropout_bwd_kernel(float* __restrict__ gbuf, long n, float drop_p, uint32_t site, uint64_t seed, uint32_t bf) {
   const uint32_t thr = hftt_keep_thr(drop_p);
   const float inv_keep = 1.0f / (1.0f - drop_p);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    gbuf[i] = hftt_keep(seed, site, (uint64_t)i, thr) ? gbuf[i] * inv_keep : 0.f;
+  const long n4 = n >> 2;                          // n % 4 == 0 (host check): 4 consecutive elements = 2 hash pairs per thread
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = hftt_load4(gbuf, bf, i * 4);
+    float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const uint32_t k2 = hftt_keep_pair(seed, site, (uint64_t)(i * 2 + e), thr);
+      v[2 * e] = (k2 & 1u) ? v[2 * e] * inv_keep : 0.f;
+      v[2 * e + 1] = (k2 & 2u) ? v[2 * e + 1] * inv_keep : 0.f;
+    }
+    hftt_store4(gbuf, bf, i * 4, v[0], v[1], v[2], v[3]);
+  }
 }
 
 // ------------------------------------------------------------------ column sums (two-stage)
 constexpr int CS_SPLITS = 16;
-__global__ void colsum_stage1_kernel(const float* __restrict__ x, long rows, long n, long ld, float* __restrict__ ws) {
+__global__ void colsum_stage1_kernel(const float* __restrict__ x, long rows, long n, long ld, float* __restrict__ ws, uint32_t bf) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int sp = blockIdx.y;
@@ -289,7 +300,8 @@ __global__ void colsum_stage1_kernel(const float* __restrict__ x, long rows, lon
   const long r0 = sp * per;
   long r1 = r0 + per; if (r1 > rows) r1 = rows;
   float acc = 0.f;
-  for (long r = r0; r < r1; r++) acc += x[r * ld + j];
+  if (bf) { for (long r = r0; r < r1; r++) acc += bf2f(reinterpret_cast<const unsigned short*>(x)[r * ld + j]); }
+  else { for (long r = r0; r < r1; r++) acc += x[r * ld + j]; }
   ws[(long)sp * n + j] = acc;
 }
 __global__ void colsum_stage2_kernel(const float* __restrict__ ws, long n, float* __restrict__ out, float beta) {
@@ -531,32 +543,32 @@ extern "C" int hftt_ln_bwd_reduce(const float* ws, int32_t n_wg, int32_t N, floa
 }
 
 extern "C" int hftt_time_embed_fwd(const float* x, const float* pos, float* y, int32_t B, int32_t T, int32_t Nn, int32_t d,
-                                   float scale, float drop_p, uint32_t site, uint64_t seed, void* stream) {
+                                   float scale, float drop_p, uint32_t site, uint64_t seed, uint32_t io_flags, void* stream) {
   HFTT_REQUIRE(x && pos && y && d % 4 == 0, "time_embed_fwd: bad arguments");
   hipLaunchKernelGGL(time_embed_fwd_kernel, dim3(grid_for((long)B * T * Nn * (d / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     x, pos, y, B, T, Nn, d, scale, drop_p, site, seed);
+                     x, pos, y, B, T, Nn, d, scale, drop_p, site, seed, io_flags);
   HFTT_CHECK_LAUNCH("time_embed_fwd");
   return 0;
 }
 extern "C" int hftt_time_embed_bwd(const float* dy, float* dx, float* dym, int32_t B, int32_t T, int32_t Nn, int32_t d,
-                                   float scale, float drop_p, uint32_t site, uint64_t seed, int32_t accumulate, void* stream) {
+                                   float scale, float drop_p, uint32_t site, uint64_t seed, int32_t accumulate, uint32_t io_flags, void* stream) {
   HFTT_REQUIRE(dy && dx && d % 4 == 0, "time_embed_bwd: bad arguments");
   hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(grid_for((long)B * T * Nn * (d / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     dy, dx, dym, B, T, Nn, d, scale, drop_p, site, seed, accumulate);
+                     dy, dx, dym, B, T, Nn, d, scale, drop_p, site, seed, accumulate, io_flags);
   HFTT_CHECK_LAUNCH("time_embed_bwd");
   return 0;
 }
-extern "C" int hftt_dropout_bwd(float* g, int64_t n, float drop_p, uint32_t site, uint64_t seed, void* stream) {
-  HFTT_REQUIRE(g && n > 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_bwd: bad arguments");
+extern "C" int hftt_dropout_bwd(float* g, int64_t n, float drop_p, uint32_t site, uint64_t seed, uint32_t bf16, void* stream) {
+  HFTT_REQUIRE(g && n > 0 && n % 4 == 0 && drop_p >= 0.f && drop_p < 1.f && ((uintptr_t)g & 15) == 0, "dropout_bwd: bad arguments (n %% 4 == 0, 16-byte aligned)");
   if (drop_p == 0.f) return 0;
-  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, g, (long)n, drop_p, site, seed);
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, g, (long)n, drop_p, site, seed, bf16);
   HFTT_CHECK_LAUNCH("dropout_bwd");
   return 0;
 }
 extern "C" int64_t hftt_colsum_ws_bytes(int64_t rows, int64_t n) { (void)rows; return (int64_t)CS_SPLITS * n * 4; }
-extern "C" int hftt_colsum(const float* x, int64_t rows, int64_t n, int64_t ld, float* out, float beta, float* ws, void* stream) {
+extern "C" int hftt_colsum(const float* x, int64_t rows, int64_t n, int64_t ld, float* out, float beta, float* ws, uint32_t x_bf16, void* stream) {
   HFTT_REQUIRE(x && out && ws && rows > 0 && n > 0 && ld >= n, "colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)((n + 255) / 256), CS_SPLITS), dim3(256), 0, (hipStream_t)stream, x, (long)rows, (long)n, (long)ld, ws);
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)((n + 255) / 256), CS_SPLITS), dim3(256), 0, (hipStream_t)stream, x, (long)rows, (long)n, (long)ld, ws, x_bf16);
   HFTT_CHECK_LAUNCH("colsum(1)");
   hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, (long)n, out, beta);
   HFTT_CHECK_LAUNCH("colsum(2)");

@@ -154,11 +154,11 @@ SIGNATURES = {
     'hftt_ln_bwd': (C.c_int, [C.POINTER(LnBwdDesc), C.c_void_p]),
     'hftt_ln_bwd_reduce': (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_float, C.c_void_p]),
     'hftt_time_embed_fwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                      C.c_float, C.c_float, C.c_uint32, C.c_uint64, C.c_void_p]),
+                                      C.c_float, C.c_float, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]),
     'hftt_time_embed_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                      C.c_float, C.c_float, C.c_uint32, C.c_uint64, C.c_int32, C.c_void_p]),
-    'hftt_dropout_bwd': (C.c_int, [c_f32p, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_void_p]),
-    'hftt_colsum': (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_float, c_f32p, C.c_void_p]),
+                                      C.c_float, C.c_float, C.c_uint32, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p]),
+    'hftt_dropout_bwd': (C.c_int, [c_f32p, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]),
+    'hftt_colsum': (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_float, c_f32p, C.c_uint32, C.c_void_p]),
     'hftt_colsum_ws_bytes': (C.c_int64, [C.c_int64, C.c_int64]),
     'hftt_heads_split': (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p,
                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -11,7 +11,7 @@ _D_NAMES = ('onset_A', 'offset_A', 'mpe_A', 'velocity_A', None, 'onset_B', 'offs
 class HfttModelFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, engine, training, *params):
-        outs = engine.forward(spec, training=training)
+        outs = engine.forward(spec, training=training, save=True)
         ctx.engine = engine
         ctx.B = spec.shape[0]
         ctx.generation = engine.generation

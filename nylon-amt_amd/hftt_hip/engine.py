@@ -22,7 +22,8 @@ from collections import OrderedDict
 import torch
 
 from . import _capi
-from ._capi import (AttnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, check, lib)
+from ._capi import (AttnDesc, FfnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
+                    SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, check, lib)
 
 PRECISION_NPASS = {'parity': 3, 'bf16': 1}
 
@@ -74,8 +75,8 @@ class HfttEngine:
             raise _capi.HfttError('n_velocity must be a multiple of 4')
         self.NH = self.V + 3                       # packed head rows: velocity[0:V], onset, offset, mpe
         self.NHp = _align(self.NH + 1, 64)
-        import os as _os0
-        self.store_bf16_opt = _os0.environ.get('HFTT_BF16_STORE', '1') != '0'
+        self.store_bf16_opt = os.environ.get('HFTT_BF16_STORE', '1') != '0'
+        self.strip_opt = os.environ.get('HFTT_STRIP', '1') != '0'
         self.set_precision(precision)
         self.dropout = float(dropout)
         self.base_seed = int(seed)
@@ -85,8 +86,6 @@ class HfttEngine:
         self._ws = {}
         self._site = 0
         self.profiler = None                        # optional per-launch HIP-event timer (bench.py)
-        import os as _os
-        self.store_bf16_opt = _os.environ.get('HFTT_BF16_STORE', '1') != '0'
 
     # ------------------------------------------------------------------ precision / parameters
     def set_precision(self, precision):
@@ -98,6 +97,9 @@ class HfttEngine:
         # bf16 mode: tensors consumed only as MFMA operands (projections, attention context, FFN hidden and their gradients)
         # are STORED as bf16 -- identical numerics (they were rounded at load time anyway), half the traffic
         self.sb = (self.npass == 1) and getattr(self, 'store_bf16_opt', True)
+        # strip kernels (csrc/strip_gemm.hip): bf16 mode at the paper's width.  Then the WHOLE activation stream between kernels is
+        # bf16 (residual stream, pre-LayerNorm sums, hidden), fp32 lives only inside a kernel (accumulators, LayerNorm statistics).
+        self.strip = self.sb and getattr(self, 'strip_opt', True) and self.d == 256 and self.p % 64 == 0
         if getattr(self, '_bound', None) is not None:
             self._build_prep()
 
@@ -210,26 +212,69 @@ class HfttEngine:
             for i, nm in enumerate(('onset', 'offset', 'mpe')):
                 entries.append((self.poff[f'{pre}fc_{nm}_{tag}.bias'], ob + V + i, 1, 1, 1, 1, 2))
 
+        sl = _Flat()
+        sentries = []
+
+        def spack(key, parts, Ktot, transpose=False, order=0, stride=1, offset=0, base=None, numel=None):
+            """parts: (parameter name, n0, k0) blocks of the logical [N, Ktot] matrix; returns the stream's element offset."""
+            if base is None:
+                base = sl.add(key, numel, 512)
+                W['s.' + key] = base
+            for name, n0, k0 in parts:
+                rows, cols = self.pshape[name]
+                sentries.append((self.poff[name], base, rows, cols, cols, 1 if transpose else 0, n0, k0, Ktot, order, stride, offset))
+            return base
+
+        def strip_attn(pre, key, cross):
+            wq, wk, wv, wo = (pre + n + '.weight' for n in ('fc_q', 'fc_k', 'fc_v', 'fc_o'))
+            if cross:
+                spack(key + '.q', [(wq, 0, 0)], d, numel=d * d)
+                spack(key + '.kv', [(wk, 0, 0), (wv, d, 0)], d, numel=2 * d * d)
+                spack(key + '.q_t', [(wq, 0, 0)], d, transpose=True, numel=d * d)
+                spack(key + '.kv_t', [(wk, 0, 0), (wv, 0, d)], 2 * d, transpose=True, numel=2 * d * d)
+            else:
+                spack(key + '.qkv', [(wq, 0, 0), (wk, d, 0), (wv, 2 * d, 0)], d, numel=3 * d * d)
+                spack(key + '.qkv_t', [(wq, 0, 0), (wk, 0, d), (wv, 0, 2 * d)], 3 * d, transpose=True, numel=3 * d * d)
+            spack(key + '.o', [(wo, 0, 0)], d, numel=d * d)
+            spack(key + '.o_t', [(wo, 0, 0)], d, transpose=True, numel=d * d)
+
+        def strip_ffn(pre, key):
+            w1, w2 = pre + 'fc_1.weight', pre + 'fc_2.weight'          # [p, d], [d, p]
+            base = spack(key + '.ffn', [(w1, 0, 0)], d, order=1, stride=2, offset=0, numel=2 * d * p)
+            spack(key + '.ffn', [(w2, 0, 0)], p, order=0, stride=2, offset=1, base=base)
+            # dX half of the backward: first matrix fc_2.weight^T [p, d], second fc_1.weight^T [d, p]
+            base = spack(key + '.ffn_t', [(w2, 0, 0)], d, transpose=True, order=1, stride=2, offset=0, numel=2 * d * p)
+            spack(key + '.ffn_t', [(w1, 0, 0)], p, transpose=True, order=0, stride=2, offset=1, base=base)
+
         W['embed'] = wl.add('embed', _align(d, 64) * self.Kp, 64)
         W['embed_b'] = fl.add('embed_b', d, 8)
+        blocks = []                                  # (prefix, key, has self attention, has cross attention)
         for i in range(self.Le):
-            pre = f'encoder_spec2midi.layers_freq.{i}.'
-            attn_self(pre + 'self_attention.', f'enc{i}.sa')
-            ffn(pre + 'positionwise_feedforward.', f'enc{i}')
-        pre = 'decoder_spec2midi.layer_zero_freq.'
-        attn_cross(pre + 'encoder_attention.', 'dec0.ca')
-        ffn(pre + 'positionwise_feedforward.', 'dec0')
+            blocks.append((f'encoder_spec2midi.layers_freq.{i}.', f'enc{i}', True, False))
+        blocks.append(('decoder_spec2midi.layer_zero_freq.', 'dec0', False, True))
         for i in range(self.Ld - 1):
-            pre = f'decoder_spec2midi.layers_freq.{i}.'
-            attn_self(pre + 'self_attention.', f'dec{i + 1}.sa')
-            attn_cross(pre + 'encoder_attention.', f'dec{i + 1}.ca')
-            ffn(pre + 'positionwise_feedforward.', f'dec{i + 1}')
-        heads('freq', 'heads_f')
+            blocks.append((f'decoder_spec2midi.layers_freq.{i}.', f'dec{i + 1}', True, True))
         for i in range(self.Ld):
-            pre = f'decoder_spec2midi.layers_time.{i}.'
-            attn_self(pre + 'self_attention.', f'time{i}.sa')
-            ffn(pre + 'positionwise_feedforward.', f'time{i}')
+            blocks.append((f'decoder_spec2midi.layers_time.{i}.', f'time{i}', True, False))
+        for pre, key, has_self, has_cross in blocks:
+            if key == 'time0':
+                heads('freq', 'heads_f')
+            if has_self:
+                attn_self(pre + 'self_attention.', key + '.sa')
+            if has_cross:
+                attn_cross(pre + 'encoder_attention.', key + '.ca')
+            ffn(pre + 'positionwise_feedforward.', key)
+            if self.strip:
+                if has_self:
+                    strip_attn(pre + 'self_attention.', key + '.sa', False)
+                if has_cross:
+                    strip_attn(pre + 'encoder_attention.', key + '.ca', True)
+                strip_ffn(pre + 'positionwise_feedforward.', key)
         heads('time', 'heads_t')
+        if self.strip:                               # bf16 copy of the note position table: the (broadcast) residual of decoder layer zero
+            off = wl.add('dec_pos_bf', self.N * d, 64)
+            W['dec_pos_bf'] = off
+            entries.append((self.poff['decoder_spec2midi.pos_embedding_freq.weight'], off, self.N, d, d, d, 0))
 
         self.Woff = W
         # prepared matrices: bf16 plane (npass 1) or fp32 copy (npass 3, parity) -- same element offsets
@@ -243,6 +288,11 @@ class HfttEngine:
         raw = bytes(arr)
         self.prep_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         self.n_prep = len(entries)
+        self.n_spack = len(sentries)
+        if sentries:
+            self.wstrip = torch.zeros(_align(sl.off, 512), dtype=torch.int16, device=self.device)
+            arr2 = (StripPackEntry * len(sentries))(*[StripPackEntry(*e) for e in sentries])
+            self.spack_table = torch.frombuffer(bytearray(bytes(arr2)), dtype=torch.uint8).to(self.device)
         # embed-fold scratch (dWeff, dbeff)
         self.dweff = torch.zeros(self.d * self.Kp, dtype=torch.float32, device=self.device)
         self.dbeff = torch.zeros(self.d, dtype=torch.float32, device=self.device)
@@ -264,11 +314,16 @@ class HfttEngine:
     def Fp(self, key):
         return self.fprep.data_ptr() + 4 * self.Woff[key]
 
+    def Ws(self, key):   # device address of a strip-packed weight stream
+        return self.wstrip.data_ptr() + 2 * self.Woff['s.' + key]
+
     def prepare_weights(self, stream):
         check(self.lib.hftt_prep_weights(self.flat_params.data_ptr(), self.wbf.data_ptr() if self.npass == 1 else 0,
                                          self.wf32.data_ptr() if self.npass == 3 else 0,
                                          self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights')
         check(self.lib.hftt_embed_fold_fwd(C.byref(self.fold), stream), 'embed_fold_fwd')
+        if self.strip and self.n_spack:
+            check(self.lib.hftt_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, stream), 'strip_pack')
 
     # ------------------------------------------------------------------ plan building helpers
     def _new_site(self):
@@ -279,9 +334,18 @@ class HfttEngine:
         """half=True: a GEMM-only tensor -> bf16 when the engine stores such tensors as bf16."""
         if half and self.sb:
             dtype = torch.bfloat16
+        t = ws['bufs'].get(name)
+        if t is not None:
+            if tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+                raise _capi.HfttError('workspace buffer %s re-declared with a different shape / dtype' % name)
+            return t
         t = torch.empty(*shape, dtype=dtype, device=self.device)
         ws['bufs'][name] = t
         return t
+
+    def _abuf(self, ws, name, *shape):
+        """activation-stream tensor: bf16 when the strip kernels run (bf16 residual stream), fp32 otherwise"""
+        return self._buf(ws, name, *shape, dtype=torch.bfloat16 if self.strip else torch.float32)
 
     def _nt(self, plan, ws, M, N, K, A, lda, W, bias, Cp, ldc, act=0, out_scale=1.0, add_table=0, add_mod=0,
             gate=0, ldg=0, gate_scale=1.0, drop_site=0, residual=0, ldr=0, res_mod=0, ln=None, a_bf=False, c_bf=False, gate_bf=False, res_bf=False):
@@ -334,6 +398,64 @@ class HfttEngine:
             kname = 'gemm_nt_kernel<%d, %s, %s>' % (bn, 'true' if self.npass == 3 else 'false', 'true' if ln is not None else 'false')
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_gemm_nt, (C.byref(dsc),), 'gemm_nt', meta))
+        return dsc
+
+    def _sl(self, plan, ws, M, N, K, x, ldx, wkey, bias, Cp, ldc, relu=False, out_scale=1.0, gate=0, ldg=0, gate_scale=1.0, drop_site=0,
+            residual=0, ldr=0, res_mod=0, res_bf=True, ln=None, x_bf=True, c_bf=True):
+        """hftt_strip_linear plan entry (bf16 mode, N % 256 == 0): C = epi(x . Wl^T + bias), Wl = strip pack `wkey`."""
+        dsc = StripDesc()
+        dsc.M, dsc.N, dsc.K = M, N, K
+        dsc.flags = (SL_X_BF16 if x_bf else 0) | (SL_C_BF16 if c_bf else 0) | (SL_RES_BF16 if (residual and res_bf) else 0) | (SL_RELU if relu else 0)
+        dsc.x, dsc.ldx, dsc.w, dsc.bias = x, ldx, self.Ws(wkey), bias
+        dsc.C, dsc.ldc, dsc.out_scale = Cp, ldc, out_scale
+        if isinstance(gate_scale, tuple):
+            ws.setdefault('gate_descs', []).append(dsc)
+            gate_scale = 1.0
+        dsc.gate, dsc.ldg, dsc.gate_scale = gate, ldg, gate_scale
+        dsc.drop_p, dsc.drop_site, dsc.drop_seed = 0.0, drop_site, 0
+        dsc.residual, dsc.ldr, dsc.res_mod = residual, ldr, res_mod
+        pre_saved = False
+        if ln is not None:
+            dsc.ln_gamma, dsc.ln_beta, dsc.pre_ln_out, dsc.ln_mean, dsc.ln_rstd = ln
+            pre_saved = bool(ln[2])
+        if drop_site:
+            ws['drop'].append(dsc)
+        ws['keep'].append(dsc)
+        tf = lambda v: 'true' if v else 'false'
+        nbytes = (2 if x_bf else 4) * M * K + (2 if c_bf else 4) * M * N * (2 if pre_saved else 1) + 2 * N * K \
+            + ((2 if res_bf else 4) * M * N if residual else 0) + (2 * M * N if gate else 0)
+        meta = {'kernel': 'strip_linear_kernel<%s, %s, %s>' % (tf(x_bf), tf(c_bf), tf(ln is not None)), 'flops': 2.0 * M * N * K, 'bytes': float(nbytes),
+                'shape': (M, N, K)}
+        plan.append((self.lib.hftt_strip_linear, (C.byref(dsc),), 'strip_linear', meta))
+        return dsc
+
+    def _mlp(self, plan, ws, mode, M, x, wkey, y, b1=0, b2=0, h_out=0, gate=0, gate_scale=1.0, site_h=0, site_o=0, residual=0, ln=None):
+        """fused two-GEMM block: mode 0 = hftt_ffn_res_ln_fwd (x -> relu/dropout hidden -> + x -> LayerNorm), mode 1 = hftt_ffn_bwd_dx."""
+        d, p = self.d, self.p
+        dsc = FfnDesc()
+        dsc.M, dsc.d, dsc.p, dsc.mode = M, d, p, mode
+        dsc.flags = SL_X_BF16 | SL_C_BF16 | SL_RES_BF16
+        dsc.x, dsc.ldx, dsc.w = x, d, self.Ws(wkey)
+        dsc.b1, dsc.b2 = b1, b2
+        dsc.h_out, dsc.ldh = h_out, p
+        dsc.gate, dsc.ldg = gate, p
+        if isinstance(gate_scale, tuple):
+            ws.setdefault('gate_descs', []).append(dsc)
+            gate_scale = 1.0
+        dsc.gate_scale = gate_scale
+        dsc.drop_p, dsc.site_h, dsc.site_o, dsc.drop_seed = 0.0, site_h, site_o, 0
+        dsc.residual, dsc.ldr = residual, d
+        pre_saved = False
+        if ln is not None:
+            dsc.ln_gamma, dsc.ln_beta, dsc.pre_ln_out, dsc.ln_mean, dsc.ln_rstd = ln
+            pre_saved = bool(ln[2])
+        dsc.y, dsc.ldy = y, d
+        if mode == 0 and (site_h or site_o):
+            ws['drop'].append(dsc)
+        ws['keep'].append(dsc)
+        nbytes = 2.0 * M * d * (2 + (1 if pre_saved else 0) + (1 if residual else 0)) + (2.0 * M * p if h_out else 0) + (2.0 * M * p if gate else 0) + 4.0 * d * p
+        meta = {'kernel': 'strip_mlp_kernel<%d>' % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes, 'shape': (M, d, p)}
+        plan.append((self.lib.hftt_ffn_res_ln_fwd if mode == 0 else self.lib.hftt_ffn_bwd_dx, (C.byref(dsc),), 'ffn_fwd' if mode == 0 else 'ffn_bwd_dx', meta))
         return dsc
 
     def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0, dy_bf=False, x_bf=False):
@@ -396,6 +518,7 @@ class HfttEngine:
         return dsc
 
     def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta, drop_bf=True, dy_bf=False, dr_bf=False):
+        r_bf = self.strip                           # the strip forward kernels save the pre-LayerNorm sum as bf16
         n_wg = self.lib.hftt_ln_bwd_wgs(M)
         ws['ln_need'] = max(ws.get('ln_need', 0), n_wg * 2 * self.d * 4)
         dsc = LnBwdDesc()
@@ -403,7 +526,7 @@ class HfttEngine:
         dsc.dy, dsc.r, dsc.mean, dsc.rstd, dsc.gamma = dy, r, mean, rstd, gamma
         dsc.dr, dsc.dr_drop = dr, dr_drop
         dsc.drop_bf16 = 1 if (drop_bf and self.sb and dr_drop) else 0
-        dsc.io_flags = (1 if (dy_bf and self.sb) else 0) | (2 if (dr_bf and self.sb) else 0)
+        dsc.io_flags = (1 if (dy_bf and self.sb) else 0) | (2 if (dr_bf and self.sb) else 0) | (4 if r_bf else 0)
         dsc.drop_p, dsc.drop_site, dsc.drop_seed = 0.0, drop_site, 0
         ws['ln'].append(dsc)
         if drop_site:
@@ -420,7 +543,12 @@ class HfttEngine:
             raise _capi.HfttError('engine parameters are not bound')
         ws = {'bufs': {}, 'drop': [], 'keep': [], 'tn': [], 'ln': [], 'B': B}
         self._site = 0
-        self._build_forward(ws)
+        self._build_forward(ws, save=True)
+        if self.strip:                               # inference plan: same buffers, nothing saved for a backward
+            n_sites = self._site
+            self._site = 0
+            self._build_forward(ws, save=False)
+            assert self._site == n_sites
         self._build_backward(ws)
         tnb = torch.empty(max(ws.get('tn_need', 8), 8) // 4 + 16, dtype=torch.float32, device=self.device)
         lnb = torch.empty(max(ws.get('ln_need', 8), 8) // 4 + 16, dtype=torch.float32, device=self.device)
@@ -433,7 +561,7 @@ class HfttEngine:
         self._ws[B] = ws
         return ws
 
-    def _enc_layer_fwd(self, plan, ws, tag, key, pre, S, n_seq, L, H, x_in, x_in_ld=None):
+    def _enc_layer_fwd(self, plan, ws, tag, key, pre, S, n_seq, L, H, x_in, save=True):
         """EncoderLayer (model_spec2midi.py:230-245).  Returns address of the layer output [S, d]."""
         d, p = self.d, self.p
         b = ws['bufs']
@@ -441,15 +569,26 @@ class HfttEngine:
         qkv = self._buf(ws, tag + '.qkv', S, 3 * d, half=True)
         ctx = self._buf(ws, tag + '.ctx', S, d, half=True)
         lse = self._buf(ws, tag + '.lse', n_seq * H * L * 2)
-        r1 = self._buf(ws, tag + '.r1', S, d); x1 = self._buf(ws, tag + '.x1', S, d)
+        r1 = self._abuf(ws, tag + '.r1', S, d); x1 = self._abuf(ws, tag + '.x1', S, d)
         m1 = self._buf(ws, tag + '.m1', S); s1 = self._buf(ws, tag + '.s1', S)
         h = self._buf(ws, tag + '.h', S, p, half=True)
-        r2 = self._buf(ws, tag + '.r2', S, d); x2 = self._buf(ws, tag + '.x2', S, d)
+        r2 = self._abuf(ws, tag + '.r2', S, d); x2 = self._abuf(ws, tag + '.x2', S, d)
         m2 = self._buf(ws, tag + '.m2', S); s2 = self._buf(ws, tag + '.s2', S)
         sites = ws.setdefault('sites', {})
         sa, so, sh, sf = (self._new_site() for _ in range(4))
         sites[tag] = (sa, so, sh, sf)
         gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
+        if self.strip:
+            sv = (lambda t: t.data_ptr()) if save else (lambda t: 0)
+            self._sl(plan, ws, S, 3 * d, d, x_in, d, key + '.sa.qkv', self.Fp(key + '.sa.qkv_b'), qkv.data_ptr(), 3 * d)
+            q = qkv.data_ptr()
+            self._attn(plan, ws, False, n_seq, H, L, L, q, L * 3 * d, 3 * d, q + hz * d, L * 3 * d, 3 * d, q + 2 * hz * d, L * 3 * d, 3 * d,
+                       ctx.data_ptr(), L * d, d, lse.data_ptr(), drop_site=sa, flags=1 | 2 | 4)
+            self._sl(plan, ws, S, d, d, ctx.data_ptr(), d, key + '.sa.o', self.P(pre + 'self_attention.fc_o.bias'), x1.data_ptr(), d,
+                     drop_site=so, residual=x_in, ldr=d, ln=(gam, bet, sv(r1), sv(m1), sv(s1)))
+            self._mlp(plan, ws, 0, S, x1.data_ptr(), key + '.ffn', x2.data_ptr(), b1=self.P(pre + 'positionwise_feedforward.fc_1.bias'),
+                      b2=self.P(pre + 'positionwise_feedforward.fc_2.bias'), h_out=sv(h), site_h=sh, site_o=sf, ln=(gam, bet, sv(r2), sv(m2), sv(s2)))
+            return x2.data_ptr()
         self._nt(plan, ws, S, 3 * d, d, x_in, d, self.Wp(key + '.sa.qkv'), self.Fp(key + '.sa.qkv_b'), qkv.data_ptr(), 3 * d, c_bf=True)
         q = qkv.data_ptr()
         self._attn(plan, ws, False, n_seq, H, L, L, q, L * 3 * d, 3 * d, q + hz * d, L * 3 * d, 3 * d, q + 2 * hz * d, L * 3 * d, 3 * d,
@@ -462,38 +601,46 @@ class HfttEngine:
                  drop_site=sf, residual=x1.data_ptr(), ldr=d, ln=(gam, bet, r2.data_ptr(), m2.data_ptr(), s2.data_ptr()), a_bf=True)
         return x2.data_ptr()
 
-    def _ffn_fwd(self, plan, ws, tag, key, pre, S, x_in, sites):
+    def _ffn_fwd(self, plan, ws, tag, key, pre, S, x_in, sites, save=True):
         d, p = self.d, self.p
         h = self._buf(ws, tag + '.h', S, p, half=True)
-        r = self._buf(ws, tag + '.fr', S, d); x = self._buf(ws, tag + '.fx', S, d)
+        r = self._abuf(ws, tag + '.fr', S, d); x = self._abuf(ws, tag + '.fx', S, d)
         m = self._buf(ws, tag + '.fm', S); s = self._buf(ws, tag + '.fs', S)
         sh, sf = self._new_site(), self._new_site()
         sites['ffn'] = (sh, sf)
         gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
+        if self.strip:
+            sv = (lambda t: t.data_ptr()) if save else (lambda t: 0)
+            self._mlp(plan, ws, 0, S, x_in, key + '.ffn', x.data_ptr(), b1=self.P(pre + 'positionwise_feedforward.fc_1.bias'),
+                      b2=self.P(pre + 'positionwise_feedforward.fc_2.bias'), h_out=sv(h), site_h=sh, site_o=sf, ln=(gam, bet, sv(r), sv(m), sv(s)))
+            return x.data_ptr()
         self._nt(plan, ws, S, p, d, x_in, d, self.Wp(key + '.f1'), self.P(pre + 'positionwise_feedforward.fc_1.bias'), h.data_ptr(), p,
                  act=1, drop_site=sh, c_bf=True)
         self._nt(plan, ws, S, d, p, h.data_ptr(), p, self.Wp(key + '.f2'), self.P(pre + 'positionwise_feedforward.fc_2.bias'), x.data_ptr(), d,
                  drop_site=sf, residual=x_in, ldr=d, ln=(gam, bet, r.data_ptr(), m.data_ptr(), s.data_ptr()), a_bf=True)
         return x.data_ptr()
 
-    def _build_forward(self, ws):
+    def _build_forward(self, ws, save=True):
+        """save=True: the training plan (everything a backward needs is written); save=False (strip mode only): the inference plan --
+        no pre-LayerNorm sums, statistics or hidden activations are stored."""
         B, T, F, N, V, d, p = ws['B'], self.T, self.F, self.N, self.V, self.d, self.p
         Se, Sn, BT, BN = B * T * F, B * T * N, B * T, B * N
         plan = []
         ws['sites'] = {}
+        st = self.strip
         spec = self._buf(ws, 'spec', B, F, self.W)
         win = self._buf(ws, 'win', Se, self.Kp)
-        x0 = self._buf(ws, 'x0', Se, d)
+        x0 = self._abuf(ws, 'x0', Se, d)
         e = 'encoder_spec2midi.'
         plan.append((self.lib.hftt_im2win, (spec.data_ptr(), win.data_ptr(), B, F, T, self.n_proc, self.Kp), 'im2win', None))
         s_emb = self._new_site()
         ws['sites']['embed'] = s_emb
         self._nt(plan, ws, Se, d, self.Kp, win.data_ptr(), self.Kp, self.Wp('embed'), self.Fp('embed_b'), x0.data_ptr(), d,
-                 out_scale=math.sqrt(d), add_table=self.P(e + 'pos_embedding_freq.weight'), add_mod=F, drop_site=s_emb)
+                 out_scale=math.sqrt(d), add_table=self.P(e + 'pos_embedding_freq.weight'), add_mod=F, drop_site=s_emb, c_bf=st)
         x = x0.data_ptr()
         ws['enc_in'] = [x]
         for i in range(self.Le):
-            x = self._enc_layer_fwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, x)
+            x = self._enc_layer_fwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, x, save=save)
             ws['enc_in'].append(x)
         enc = x
         # ---------------- decoder, frequency axis (cross attention notes x bins) ----------------
@@ -510,64 +657,80 @@ class HfttEngine:
             ws['sites'][tag] = sites
             pre = dd + ('layer_zero_freq.' if j == 0 else f'layers_freq.{j - 1}.')
             gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
+            sv = (lambda t: t.data_ptr()) if save else (lambda t: 0)
             if j > 0:
                 sqkv = self._buf(ws, tag + '.sqkv', Sn, 3 * d, half=True)
                 sctx = self._buf(ws, tag + '.sctx', Sn, d, half=True)
                 slse = self._buf(ws, tag + '.slse', BT * H * N * 2)
-                sr = self._buf(ws, tag + '.sr', Sn, d); sx = self._buf(ws, tag + '.sx', Sn, d)
+                sr = self._abuf(ws, tag + '.sr', Sn, d); sx = self._abuf(ws, tag + '.sx', Sn, d)
                 sm = self._buf(ws, tag + '.sm', Sn); ss = self._buf(ws, tag + '.ss', Sn)
                 s_a, s_o = self._new_site(), self._new_site()
                 sites['self'] = (s_a, s_o)
-                self._nt(plan, ws, Sn, 3 * d, d, trg, d, self.Wp(tag + '.sa.qkv'), self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d, c_bf=True)
+                if st:
+                    self._sl(plan, ws, Sn, 3 * d, d, trg, d, tag + '.sa.qkv', self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d)
+                else:
+                    self._nt(plan, ws, Sn, 3 * d, d, trg, d, self.Wp(tag + '.sa.qkv'), self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d, c_bf=True)
                 q = sqkv.data_ptr()
                 self._attn(plan, ws, False, BT, H, N, N, q, N * 3 * d, 3 * d, q + hz * d, N * 3 * d, 3 * d, q + 2 * hz * d, N * 3 * d, 3 * d,
                            sctx.data_ptr(), N * d, d, slse.data_ptr(), drop_site=s_a, flags=1 | 2 | 4)
-                self._nt(plan, ws, Sn, d, d, sctx.data_ptr(), d, self.Wp(tag + '.sa.o'), self.P(pre + 'self_attention.fc_o.bias'), sx.data_ptr(), d,
-                         drop_site=s_o, residual=trg, ldr=d, ln=(gam, bet, sr.data_ptr(), sm.data_ptr(), ss.data_ptr()), a_bf=True)
-                cross_in = sx.data_ptr()
                 cq = self._buf(ws, tag + '.cq', Sn, d, half=True)
-                self._nt(plan, ws, Sn, d, d, cross_in, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), cq.data_ptr(), d, c_bf=True)
+                if st:
+                    self._sl(plan, ws, Sn, d, d, sctx.data_ptr(), d, tag + '.sa.o', self.P(pre + 'self_attention.fc_o.bias'), sx.data_ptr(), d,
+                             drop_site=s_o, residual=trg, ldr=d, ln=(gam, bet, sv(sr), sv(sm), sv(ss)))
+                    self._sl(plan, ws, Sn, d, d, sx.data_ptr(), d, tag + '.ca.q', self.P(pre + 'encoder_attention.fc_q.bias'), cq.data_ptr(), d)
+                else:
+                    self._nt(plan, ws, Sn, d, d, sctx.data_ptr(), d, self.Wp(tag + '.sa.o'), self.P(pre + 'self_attention.fc_o.bias'), sx.data_ptr(), d,
+                             drop_site=s_o, residual=trg, ldr=d, ln=(gam, bet, sr.data_ptr(), sm.data_ptr(), ss.data_ptr()), a_bf=True)
+                    self._nt(plan, ws, Sn, d, d, sx.data_ptr(), d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), cq.data_ptr(), d, c_bf=True)
+                cross_in = sx.data_ptr()
                 qaddr, qss = cq.data_ptr(), N * d
                 res, res_mod = cross_in, 0
             else:
                 self._nt(plan, ws, N, d, d, pos_dec, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), q0.data_ptr(), d, c_bf=True)
                 qaddr, qss = q0.data_ptr(), 0
-                res, res_mod = pos_dec, N
+                res, res_mod = (self.wbf.data_ptr() + 2 * self.Woff['dec_pos_bf'] if st else pos_dec), N
             ckv = self._buf(ws, tag + '.ckv', Se, 2 * d, half=True)
             cctx = self._buf(ws, tag + '.cctx', Sn, d, half=True)
             clse = self._buf(ws, tag + '.clse', BT * H * N * 2)
-            cr = self._buf(ws, tag + '.cr', Sn, d); cx = self._buf(ws, tag + '.cx', Sn, d)
+            cr = self._abuf(ws, tag + '.cr', Sn, d); cx = self._abuf(ws, tag + '.cx', Sn, d)
             cm = self._buf(ws, tag + '.cm', Sn); cs = self._buf(ws, tag + '.cs', Sn)
             c_a, c_o = self._new_site(), self._new_site()
             sites['cross'] = (c_a, c_o)
-            self._nt(plan, ws, Se, 2 * d, d, enc, d, self.Wp(tag + '.ca.kv'), self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d, c_bf=True)
+            if st:
+                self._sl(plan, ws, Se, 2 * d, d, enc, d, tag + '.ca.kv', self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d)
+            else:
+                self._nt(plan, ws, Se, 2 * d, d, enc, d, self.Wp(tag + '.ca.kv'), self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d, c_bf=True)
             kk = ckv.data_ptr()
             ad = self._attn(plan, ws, False, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
                             cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a, flags=1 | 2 | 4)
             if j == self.Ld - 1:
-                ws['attn_out_desc'] = ad
-            self._nt(plan, ws, Sn, d, d, cctx.data_ptr(), d, self.Wp(tag + '.ca.o'), self.P(pre + 'encoder_attention.fc_o.bias'), cx.data_ptr(), d,
-                     drop_site=c_o, residual=res, ldr=d, res_mod=res_mod, ln=(gam, bet, cr.data_ptr(), cm.data_ptr(), cs.data_ptr()), a_bf=True)
-            trg = self._ffn_fwd(plan, ws, tag, tag, pre, Sn, cx.data_ptr(), sites)
+                ws.setdefault('attn_out_descs', []).append(ad)
+            if st:
+                self._sl(plan, ws, Sn, d, d, cctx.data_ptr(), d, tag + '.ca.o', self.P(pre + 'encoder_attention.fc_o.bias'), cx.data_ptr(), d,
+                         drop_site=c_o, residual=res, ldr=d, res_mod=res_mod, ln=(gam, bet, sv(cr), sv(cm), sv(cs)))
+            else:
+                self._nt(plan, ws, Sn, d, d, cctx.data_ptr(), d, self.Wp(tag + '.ca.o'), self.P(pre + 'encoder_attention.fc_o.bias'), cx.data_ptr(), d,
+                         drop_site=c_o, residual=res, ldr=d, res_mod=res_mod, ln=(gam, bet, cr.data_ptr(), cm.data_ptr(), cs.data_ptr()), a_bf=True)
+            trg = self._ffn_fwd(plan, ws, tag, tag, pre, Sn, cx.data_ptr(), sites, save=save)
             ws['dec_out'].append(trg)
         # ---------------- heads A ----------------
         logits_f = self._buf(ws, 'logits_f', Sn, self.NHp)
-        self._nt(plan, ws, Sn, self.NH, d, trg, d, self.Wp('heads_f'), self.Fp('heads_f_b'), logits_f.data_ptr(), self.NHp)
+        self._nt(plan, ws, Sn, self.NH, d, trg, d, self.Wp('heads_f'), self.Fp('heads_f_b'), logits_f.data_ptr(), self.NHp, a_bf=st)
         plan.append(('heads', (logits_f.data_ptr(), 0), 'heads_split', None))
         # ---------------- decoder, time axis ----------------
-        y0 = self._buf(ws, 'y0', Sn, d)
+        y0 = self._abuf(ws, 'y0', Sn, d)
         s_t = self._new_site()
         ws['sites']['time_embed'] = s_t
-        plan.append(('time_embed', (trg, self.P(dd + 'pos_embedding_time.weight'), y0.data_ptr(), s_t), 'time_embed_fwd', None))
+        plan.append(('time_embed', (trg, self.P(dd + 'pos_embedding_time.weight'), y0.data_ptr(), s_t, 3 if st else 0), 'time_embed_fwd', None))
         y = y0.data_ptr()
         ws['time_in'] = [y]
         for i in range(self.Ld):
-            y = self._enc_layer_fwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, y)
+            y = self._enc_layer_fwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, y, save=save)
             ws['time_in'].append(y)
         logits_t = self._buf(ws, 'logits_t', Sn, self.NHp)
-        self._nt(plan, ws, Sn, self.NH, d, y, d, self.Wp('heads_t'), self.Fp('heads_t_b'), logits_t.data_ptr(), self.NHp)
+        self._nt(plan, ws, Sn, self.NH, d, y, d, self.Wp('heads_t'), self.Fp('heads_t_b'), logits_t.data_ptr(), self.NHp, a_bf=st)
         plan.append(('heads', (logits_t.data_ptr(), 1), 'heads_split', None))
-        ws['fwd'] = plan
+        ws['fwd' if save else 'fwd_inf'] = plan
         ws['enc'] = enc
 
     # ---- backward of one EncoderLayer; dx_out lives in GA on entry (grad of the layer output) and on exit (grad of input)
@@ -593,7 +756,7 @@ class HfttEngine:
         self._nt(plan, ws, S, p, d, dbr, d, self.Wp(key + '.f2_t'), 0, Gh, p, gate=b[tag + '.h'].data_ptr(), ldg=p,
                  gate_scale=('inv_keep',), a_bf=dbr_bf, c_bf=True, gate_bf=True)
         # fc_1
-        self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True)
+        self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=self.strip)
         self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True, res_bf=gbf, c_bf=gbf)
         # LN1 backward
         self._lnb(plan, ws, S, GA, b[tag + '.r1'].data_ptr(), b[tag + '.m1'].data_ptr(), b[tag + '.s1'].data_ptr(), gam,
@@ -611,7 +774,7 @@ class HfttEngine:
         # qkv projection
         self._tn(plan, ws, S, 3 * d, d, Gq, 3 * d, x_in, d,
                  [(0, d, self.G(pa + 'fc_q.weight'), self.G(pa + 'fc_q.bias')), (d, d, self.G(pa + 'fc_k.weight'), self.G(pa + 'fc_k.bias')),
-                  (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))], dy_bf=True)
+                  (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
         self._nt(plan, ws, S, d, 3 * d, Gq, 3 * d, self.Wp(key + '.sa.qkv_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True, res_bf=gbf, c_bf=out_bf)
 
     def _ffn_bwd(self, plan, ws, tag, key, pre, S, x_in, G, ln_beta):
@@ -631,7 +794,7 @@ class HfttEngine:
                  dy_bf=dbr_bf, x_bf=True)
         self._nt(plan, ws, S, p, d, dbr, d, self.Wp(key + '.f2_t'), 0, Gh, p, gate=b[tag + '.h'].data_ptr(), ldg=p, gate_scale=('inv_keep',),
                  a_bf=dbr_bf, c_bf=True, gate_bf=True)
-        self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True)
+        self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=self.strip)
         self._nt(plan, ws, S, d, p, Gh, p, self.Wp(key + '.f1_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True)
 
     def _build_backward(self, ws):
@@ -679,7 +842,7 @@ class HfttEngine:
         # ---- heads B + time layers ----
         plan.append(('heads_bwd', ('B', dlog, 1), 'heads_split_bwd', None))
         y_last = ws['time_in'][-1]
-        self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, y_last, d, head_segs('time'))
+        self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, y_last, d, head_segs('time'), x_bf=self.strip)
         self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_t_t'), 0, nGA, d)
         Gn = (nGA, nGB, nGC, nGh, nGq, nGx)
         for i in reversed(range(self.Ld)):
@@ -687,7 +850,7 @@ class HfttEngine:
         # ---- heads A, then the time-embedding transpose back onto the note-major gradient ----
         plan.append(('heads_bwd', ('A', dlog, 0), 'heads_split_bwd', None))
         f_last = ws['dec_out'][-1]
-        self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, f_last, d, head_segs('freq'))
+        self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, f_last, d, head_segs('freq'), x_bf=self.strip)
         self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_f_t'), 0, nGD, d)
         plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed']), 'time_embed_bwd', None))
         plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws), 'colsum', None))
@@ -728,7 +891,7 @@ class HfttEngine:
                        dq=Q1, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + hz * d, dvss=F * 2 * d, lddv=2 * d,
                        flags=1 | 2 | 4 | 16)
             self._tn(plan, ws, Se, 2 * d, d, eGq, 2 * d, enc, d,
-                     [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))], dy_bf=True)
+                     [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
             if first_enc_grad:
                 self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, a_bf=True, c_bf=egb)
                 first_enc_grad = False
@@ -736,7 +899,7 @@ class HfttEngine:
                 self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, residual=eGA, ldr=d, a_bf=True, res_bf=egb, c_bf=egb)
             if j > 0:
                 # q projection of the cross attention (input sx, which is also the residual of this block)
-                self._tn(plan, ws, Sn, d, d, Q1, d, b[tag + '.sx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
+                self._tn(plan, ws, Sn, d, d, Q1, d, b[tag + '.sx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))], x_bf=self.strip)
                 self._nt(plan, ws, Sn, d, d, Q1, d, self.Wp(tag + '.ca.q_t'), 0, A, d, residual=Bf, ldr=d)
                 # self-attention block (input trg = previous layer output)
                 s_a, s_o = sites['self']
@@ -754,7 +917,7 @@ class HfttEngine:
                            flags=1 | 2 | 4 | 8 | 16)
                 self._tn(plan, ws, Sn, 3 * d, d, nGq, 3 * d, trg, d,
                          [(0, d, self.G(ps + 'fc_q.weight'), self.G(ps + 'fc_q.bias')), (d, d, self.G(ps + 'fc_k.weight'), self.G(ps + 'fc_k.bias')),
-                          (2 * d, d, self.G(ps + 'fc_v.weight'), self.G(ps + 'fc_v.bias'))], dy_bf=True)
+                          (2 * d, d, self.G(ps + 'fc_v.weight'), self.G(ps + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
                 self._nt(plan, ws, Sn, d, 3 * d, nGq, 3 * d, self.Wp(tag + '.sa.qkv_t'), 0, A, d, residual=Bf, ldr=d, a_bf=True)
             else:
                 # layer zero: query = fc_q(pos_embedding_freq) shared by all sequences, residual = pos_embedding_freq
@@ -806,17 +969,17 @@ class HfttEngine:
                                             b['d.onset_' + side].data_ptr(), b['d.offset_' + side].data_ptr(), b['d.mpe_' + side].data_ptr(),
                                             b['d.velocity_' + side].data_ptr(), dlog, self.NHp, B, T, N, V, tm, stream)
             elif fn == 'time_embed':
-                x, pos, y, site = args
-                rc = L.hftt_time_embed_fwd(x, pos, y, B, T, N, d, math.sqrt(d), p, site, seed, stream)
+                x, pos, y, site, iof = args
+                rc = L.hftt_time_embed_fwd(x, pos, y, B, T, N, d, math.sqrt(d), p, site, seed, iof, stream)
             elif fn == 'time_embed_bwd':
                 dy, dx, dym, site = args
-                rc = L.hftt_time_embed_bwd(dy, dx, dym, B, T, N, d, math.sqrt(d), p, site, seed, 1, stream)
+                rc = L.hftt_time_embed_bwd(dy, dx, dym, B, T, N, d, math.sqrt(d), p, site, seed, 1, 0, stream)
             elif fn == 'colsum':
                 x, rows, n, ld, out, beta, wsp = args
-                rc = L.hftt_colsum(x, rows, n, ld, out, beta, wsp, stream)
+                rc = L.hftt_colsum(x, rows, n, ld, out, beta, wsp, 0, stream)
             elif fn == 'dropout_bwd':
                 g, n, site = args
-                rc = L.hftt_dropout_bwd(g, n, p, site, seed, stream) if p > 0.0 else 0
+                rc = L.hftt_dropout_bwd(g, n, p, site, seed, 0, stream) if p > 0.0 else 0
             else:
                 raise _capi.HfttError('unknown plan op %s' % fn)
             if prof is not None:
@@ -832,7 +995,7 @@ class HfttEngine:
         for dsc in ws.get('gate_descs', ()):
             dsc.gate_scale = inv_keep
 
-    def forward(self, spec, training=False, outputs=None):
+    def forward(self, spec, training=False, outputs=None, save=None):
         """spec [B, n_bin, M+T+M] (any device/dtype/strides) -> 9-tuple of fresh fp32 tensors on the engine's device."""
         if spec.dim() != 3 or spec.shape[1] != self.F or spec.shape[2] != self.W:
             raise _capi.HfttError('input_spec must be [B, %d, %d], got %s' % (self.F, self.W, tuple(spec.shape)))
@@ -849,7 +1012,8 @@ class HfttEngine:
             outs = [torch.empty(B, T, N, device=dev) for _ in range(3)] + [torch.empty(B, T, N, V, device=dev)] \
                 + [torch.empty(B, T, self.Hd, N, self.F, device=dev)] \
                 + [torch.empty(B, T, N, device=dev) for _ in range(3)] + [torch.empty(B, T, N, V, device=dev)]
-        ws['attn_out_desc'].probs = outs[4].data_ptr()
+        for ad in ws['attn_out_descs']:
+            ad.probs = outs[4].data_ptr()
         p = self.dropout if training else 0.0
         if training:
             self.step_counter += 1
@@ -858,7 +1022,11 @@ class HfttEngine:
         self._patch(ws, p, seed)
         stream = torch.cuda.current_stream(dev).cuda_stream
         self.prepare_weights(stream)
-        self._run(ws, ws['fwd'], stream, outs=outs, seed=seed, p=p)
+        if save is None:
+            save = training
+        plan = ws['fwd'] if (save or 'fwd_inf' not in ws) else ws['fwd_inf']      # inference plan: nothing is saved for a backward
+        ws['saved'] = plan is ws['fwd']
+        self._run(ws, plan, stream, outs=outs, seed=seed, p=p)
         self.generation += 1
         ws['generation'] = self.generation
         return tuple(outs)
@@ -872,6 +1040,8 @@ class HfttEngine:
         ws = self._ws.get(B)
         if ws is None or 'outs' not in ws:
             raise _capi.HfttError('backward called without a forward')
+        if not ws.get('saved', True):
+            raise _capi.HfttError('backward after an inference-plan forward (model.eval()): nothing was saved; run the forward in training mode')
         if generation is not None and generation != ws['generation']:
             raise _capi.HfttError('backward called for a stale forward (activations were overwritten by a later forward)')
         self._cur_ws = ws

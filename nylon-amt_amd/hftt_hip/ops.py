@@ -300,7 +300,7 @@ def colsum(x, beta=0.0, out=None):
     ws = torch.empty(L.hftt_colsum_ws_bytes(rows, n) // 4 + 16, device=x.device)
     if out is None:
         out = torch.zeros(n, device=x.device)
-    check(L.hftt_colsum(x.data_ptr(), rows, n, x.stride(0), out.data_ptr(), beta, ws.data_ptr(), _stream(x.device)), 'colsum')
+    check(L.hftt_colsum(x.data_ptr(), rows, n, x.stride(0), out.data_ptr(), beta, ws.data_ptr(), 1 if x.dtype == BF16 else 0, _stream(x.device)), 'colsum')
     return out
 
 

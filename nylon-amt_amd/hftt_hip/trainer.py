@@ -56,7 +56,7 @@ class TrainStep:
         if eng is not self.engine:
             raise HfttError('model was moved / re-bound after the TrainStep was created')
         B = spec.shape[0]
-        eng.forward(spec, training=self.model.training)
+        eng.forward(spec, training=self.model.training, save=True)
         loss = eng.loss(B, (label_onset, label_offset, label_mpe, label_velocity), self.weight_A, self.weight_B, with_grad=True)
         eng.backward(B, on_ready=getattr(self.grad_sync, 'bucket_ready', None))
         return loss

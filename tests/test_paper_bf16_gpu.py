@@ -1,0 +1,212 @@
+"""The BENCHMARKED arithmetic (hftt_precision = 'bf16', the mode bench.py times) at the paper size, against
+  (a) the reference-generated golden fixture tests/golden/paper_b1.npz (same seed / inputs as test_golden_fixture),
+  (b) this repo's <= 1e-3 parity mode on the device at B = 8 (BASELINE config 3: full tensors, loss, every gradient),
+  (c) BASELINE config 5 at full size: 60 s of audio = 30 clips through model.amt.AMT (decode determinism, outputs vs parity mode).
+Budgets: SURVEY.md section 7 measured, on the reference itself, what bf16 arithmetic costs at this size -- bf16-rounded GEMM operands
+with fp32 accumulate: posteriors 2.5e-2, velocity logits 1.8e-1, attention 6.8e-3; torch.autocast (bf16 GEMMs AND a bf16 residual
+stream, which is what this build's bf16 mode stores): 2.8e-2 / 2.0e-1 / 6.8e-3.  Those were one seed; the budgets below are the
+autocast row with 1.4x headroom for other seeds / inputs, and every test prints what it measured."""
+import json
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from util import O, OUT_NAMES, max_err
+
+pytestmark = pytest.mark.gpu
+
+LOSS_REL = 5e-3          # the velocity cross-entropies (ln 128 each at init) carry the logit error: relative, not absolute
+BUDGET = {'onset_A': 4e-2, 'offset_A': 4e-2, 'mpe_A': 4e-2, 'onset_B': 4e-2, 'offset_B': 4e-2, 'mpe_B': 4e-2,
+          'velocity_A': 2.8e-1, 'velocity_B': 2.8e-1, 'attention': 2.5e-2}
+
+
+def _to_dev(labels, dev):
+    return tuple(t.to(dev).contiguous() for t in labels)
+
+
+def _cos(a, b):
+    a = a.double().reshape(-1); b = b.double().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def test_bf16_mode_against_the_paper_size_golden(dev):
+    """hftt_precision='bf16' vs reference outputs / loss / gradient samples of golden/paper_b1 (no oracle in the loop)."""
+    from hftt_hip.trainer import TrainStep
+    g = util.golden('paper_b1')
+    cfg = util.cfg_from_golden(g)
+    seed, B = int(g['seed']), int(g['bsz'])
+    model = util.build_model(cfg, seed)
+    util.perturb(model, seed + 1)
+    model = model.to(dev)
+    model.hftt_precision = 'bf16'
+    model.train()                                 # dropout 0: identical to eval
+    x = O.synth_spec(B, cfg, salt=seed)
+    labels = O.synth_labels(B, cfg, salt=seed + 7)
+    ts = TrainStep(model)
+    ts.engine.flat_grads.fill_(float('nan'))
+    loss = ts.forward_backward(x.to(dev), *_to_dev(labels, dev))
+    outs = ts.engine._ws[B]['outs']
+    rep = {}
+    for n, t in zip(OUT_NAMES, outs):
+        st = int(g['out.' + n + '.stride'])
+        ref = torch.from_numpy(g['out.' + n + '.sample'])
+        mine = t.reshape(-1)[::st].cpu()
+        rep[n] = max_err(mine, ref)
+        if n.startswith('mpe'):
+            # thresholded frame decisions (evaluation/m_mpe.py:101) may differ from the reference only inside the error band
+            flip = (mine >= 0.5) != (ref >= 0.5)
+            band = (ref[flip] - 0.5).abs().max().item() if flip.any() else 0.0
+            rep[n + '.flipped'] = float(flip.float().mean())
+            assert band <= rep[n] + 1e-6
+    rep['loss_rel_err'] = abs(loss[0].item() - float(g['loss'])) / float(g['loss'])
+    cos = {}
+    for (pname, _, o, n) in ts.engine._bound:
+        gr = ts.engine.flat_grads[o:o + n].cpu()
+        assert torch.isfinite(gr).all(), pname
+        stats = g['grad.' + pname + '.stats']
+        if stats[1] < 1e-7:                       # fc_k.bias: structurally zero gradient
+            continue
+        st = max(1, n // 64) | 1
+        c = _cos(gr[::st], torch.from_numpy(g['grad.' + pname + '.sample']))
+        # first-layer tensors are ill-conditioned on raw log-mel input (see test_golden_fixture); everything else is tight
+        first = pname.startswith('encoder') and any(t in pname for t in ('conv', 'tok_embedding_freq', 'encoder_spec2midi.pos_embedding_freq',
+                                                                         'layers_freq.0.self_attention.fc_q', 'layers_freq.0.self_attention.fc_k'))
+        cos[pname] = (c, first, abs(gr.double().norm().item() - stats[2]) / stats[2])
+    _report_cosines(rep, {n: (c, f) for n, (c, f, _) in cos.items()})
+    print('bf16 mode vs paper_b1 golden:', json.dumps(rep))
+    for n in OUT_NAMES:
+        assert rep[n] <= BUDGET[n], (n, rep[n])
+    assert rep['loss_rel_err'] < LOSS_REL
+    _assert_cosines(rep)
+
+
+def _report_cosines(rep, cos):
+    """cos: name -> (cosine vs the fp32 gradient, is a first-layer tensor)"""
+    down = sorted(c for c, f in cos.values() if not f)
+    rep['grad_cos.first_layer_tensors'] = sorted((round(c, 4), n) for n, (c, f) in cos.items() if f)
+    rep['grad_cos.downstream.worst'] = sorted((round(c, 4), n) for n, (c, f) in cos.items() if not f)[:6]
+    rep['grad_cos.downstream.count'] = len(down)
+    for thr in (0.999, 0.99, 0.9):
+        rep['grad_cos.downstream.frac>=%g' % thr] = round(sum(c >= thr for c in down) / len(down), 4)
+    rep['grad_cos.downstream.median'] = round(down[len(down) // 2], 5)
+
+
+def _assert_cosines(rep):
+    # What bf16 arithmetic can and cannot track at random init (documented in DESIGN.md section 2):
+    #  * tensors fed THROUGH the first encoder layer's attention (conv, tok_embedding, pos_embedding, layer-0 fc_q/fc_k): on raw log-mel
+    #    input its logits reach ~1e4, the softmax is one-hot except at near-ties, and those near-tie terms -- which dominate these
+    #    gradients -- are re-ranked by a bf16 product: cosine vs fp32 is NOT near 1 (printed, not asserted; the parity mode is exact);
+    #  * fc_q / fc_k of an attention whose keys are near-identical across the sequence (decoder self-attention over the 88 note
+    #    queries of one frame): dW = sum_k dk_k (x) x_k with sum_k dk_k = 0 is a difference of large cancelling terms.
+    # Everything else must follow the fp32 gradient closely.
+    assert rep['grad_cos.downstream.frac>=0.99'] >= 0.9, rep['grad_cos.downstream.worst']
+    assert rep['grad_cos.downstream.median'] >= 0.999
+
+
+def test_bf16_mode_paper_b8_against_parity_mode(dev):
+    """BASELINE config 3 (paper size, batch 8): full tensors of the benchmarked mode vs the <= 1e-3 mode on the same device."""
+    from hftt_hip.trainer import TrainStep
+    cfg, B = O.PAPER, 8
+    model = util.build_model(cfg, 2024)
+    util.perturb(model, 2025)
+    model = model.to(dev)
+    model.train()
+    x = O.synth_spec(B, cfg, salt=31).to(dev)
+    labels = _to_dev(O.synth_labels(B, cfg, salt=32), dev)
+    res = {}
+    for mode in ('parity', 'bf16'):
+        model.hftt_precision = mode
+        ts = TrainStep(model)
+        loss = ts.forward_backward(x, *labels)
+        torch.cuda.synchronize()
+        eng = ts.engine
+        res[mode] = ([t.clone() for t in eng._ws[B]['outs']], loss[0].item(),
+                     {name: eng.flat_grads[o:o + n].clone() for (name, _, o, n) in eng._bound})
+        del ts
+        eng._ws.clear()
+        torch.cuda.empty_cache()
+    rep = {}
+    for n, a, b in zip(OUT_NAMES, res['bf16'][0], res['parity'][0]):
+        rep[n] = max_err(a, b)
+    for i in (2, 7):
+        a, b = res['bf16'][0][i] >= 0.5, res['parity'][0][i] >= 0.5
+        tp = (a & b).sum().item(); fp = (a & ~b).sum().item(); fn = (~a & b).sum().item()
+        rep[OUT_NAMES[i] + '.frame_f1'] = 2 * tp / (2 * tp + fp + fn) if (tp + fp + fn) else 1.0
+        flip = a != b
+        band = (res['parity'][0][i][flip] - 0.5).abs().max().item() if flip.any() else 0.0
+        assert band <= rep[OUT_NAMES[i]] + 1e-6
+    rep['loss_rel_err'] = abs(res['bf16'][1] - res['parity'][1]) / res['parity'][1]
+    cos = {}
+    for name, gp in res['parity'][2].items():
+        if gp.abs().max().item() < 1e-7:
+            continue
+        first = name.startswith('encoder') and any(t in name for t in ('conv', 'tok_embedding_freq', 'encoder_spec2midi.pos_embedding_freq',
+                                                                       'layers_freq.0.self_attention.fc_q', 'layers_freq.0.self_attention.fc_k'))
+        cos[name] = (_cos(res['bf16'][2][name], gp), first)
+    _report_cosines(rep, cos)
+    print('bf16 mode vs parity mode, paper B=8:', json.dumps(rep))
+    for n in OUT_NAMES:
+        assert rep[n] <= BUDGET[n], (n, rep[n])
+    assert rep['mpe_A.frame_f1'] > 0.98 and rep['mpe_B.frame_f1'] > 0.98
+    assert rep['loss_rel_err'] < LOSS_REL
+    _assert_cosines(rep)
+
+
+def test_config5_paper_size_inference(dev, tmp_path):
+    """BASELINE config 5 on one GPU: 60 s synthetic plucked-string audio -> HIP log-mel -> 30 paper-size clips through AMT.transcript
+    in the benchmarked bf16 mode: deterministic, within budget of the parity mode on the same features, decodes to a MIDI file."""
+    from model.amt import AMT
+    cfg = O.PAPER
+    model = util.build_model(cfg, 1234)
+    util.perturb(model, 1235)
+    f = tmp_path / 'model.pkl'
+    with open(f, 'wb') as fh:
+        pickle.dump(model, fh, protocol=4)
+    config = json.loads('{"feature": {"sr": 16000, "hop_sample": 256, "mel_bins": 256, "n_bins": 256, "fft_bins": 2048, "window_length": 2048,'
+                        ' "log_offset": 1e-8, "window": "hann", "pad_mode": "constant"}, "input": {"margin_b": 32, "margin_f": 32, "num_frame": 128,'
+                        ' "min_value": -18.420681}, "midi": {"note_min": 21, "note_max": 108, "num_note": 88, "num_velocity": 128}}')
+    amt = AMT(config, str(f), batch_size=32)
+    sr, dur = 16000, 60.0
+    rng = np.random.RandomState(1234)
+    tt = torch.arange(int(sr * dur), dtype=torch.float32) / sr
+    wave = torch.zeros_like(tt)
+    t = 0.25
+    while t < dur - 2.0:
+        pitch, length, vel = int(rng.randint(40, 89)), float(rng.uniform(0.3, 1.2)), int(rng.randint(40, 110))
+        f0 = 440.0 * 2.0 ** ((pitch - 69) / 12.0)
+        lo, hi = int(t * sr), min(len(tt), int((t + length + 0.3) * sr))
+        seg = tt[lo:hi] - t
+        wave[lo:hi] += (vel / 127.0) * 0.1 * torch.exp(-3.0 * seg) * (torch.sin(2 * np.pi * f0 * seg) + 0.5 * torch.sin(4 * np.pi * f0 * seg))
+        t += float(rng.uniform(0.08, 0.35))
+    feat = amt.wave2feature(wave.unsqueeze(0), sr)
+    assert feat.shape == (3751, 256)
+    amt.model.hftt_precision = 'bf16'
+    outs = amt.transcript(feat.numpy())
+    again = amt.transcript(feat.numpy())
+    for a, b in zip(outs, again):
+        assert a.shape == (3840, 88) and np.array_equal(a, b)          # 30 clips, bit-deterministic
+    amt.model.hftt_precision = 'parity'
+    ref = amt.transcript(feat.numpy())
+    rep = {}
+    names = ['onset_A', 'offset_A', 'mpe_A', 'velocity_A', 'onset_B', 'offset_B', 'mpe_B', 'velocity_B']
+    for k, (a, b) in enumerate(zip(outs, ref)):
+        if k % 4 == 3:
+            rep[names[k] + '.argmax_differs'] = float((a != b).mean())
+        else:
+            rep[names[k]] = float(np.abs(a - b).max())
+            rep[names[k] + '.mean'] = float(np.abs(a - b).mean())
+    notes = amt.mpe2note(a_onset=outs[4], a_offset=outs[5], a_mpe=outs[6], a_velocity=outs[7])
+    mid = tmp_path / 'out.mid'
+    amt.note2midi(notes, str(mid))
+    assert mid.read_bytes()[:4] == b'MThd'
+    print('config 5, paper size, bf16 vs parity mode:', json.dumps(rep), 'notes decoded:', len(notes))
+    for k, nm in enumerate(names):
+        if k % 4 == 3:
+            assert rep[nm + '.argmax_differs'] < 0.08, nm
+        else:
+            # harmonic audio over a silent floor is harder than noise-like clips: most bins sit at the -18.42 floor, the first encoder
+            # layer's attention logits reach ~1e4 and a bf16 product (2^-9 relative) re-ranks near-tied keys.  Worst element / mean:
+            assert rep[nm] <= 0.12 and rep[nm + '.mean'] <= 5e-3, (nm, rep[nm], rep[nm + '.mean'])
