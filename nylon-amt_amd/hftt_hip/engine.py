@@ -777,6 +777,40 @@ class HfttEngine:
                   (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
         self._nt(plan, ws, S, d, 3 * d, Gq, 3 * d, self.Wp(key + '.sa.qkv_t'), 0, GA, d, residual=GB, ldr=d, a_bf=True, res_bf=gbf, c_bf=out_bf)
 
+    def _enc_layer_bwd_strip(self, plan, ws, tag, key, pre, S, n_seq, L, H, x_in, G):
+        """strip-mode backward of one EncoderLayer: the whole gradient stream (GA, GB, GC, Gh, Gq, Gx) is bf16; the two dX GEMMs of
+        the FFN are one fused launch (hftt_ffn_bwd_dx), the others hftt_strip_linear on transposed strip packs."""
+        d, p = self.d, self.p
+        b = ws['bufs']
+        sa, so, sh, sf = ws['sites'][tag]
+        GA, GB, GC, Gh, Gq, Gx = G
+        gam = self.P(pre + 'layer_norm.weight')
+        dgam, dbet = self.G(pre + 'layer_norm.weight'), self.G(pre + 'layer_norm.bias')
+        pf = pre + 'positionwise_feedforward.'
+        pa = pre + 'self_attention.'
+        use_drop = self.dropout > 0.0
+        dbr = GC if use_drop else GB
+        # LN2 -> FFN
+        self._lnb(plan, ws, S, GA, b[tag + '.r2'].data_ptr(), b[tag + '.m2'].data_ptr(), b[tag + '.s2'].data_ptr(), gam,
+                  GB, GC if use_drop else 0, sf, dgam, dbet, 0.0, dy_bf=True, dr_bf=True)
+        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True)
+        self._mlp(plan, ws, 1, S, dbr, key + '.ffn_t', GA, h_out=Gh, gate=b[tag + '.h'].data_ptr(), gate_scale=('inv_keep',), residual=GB)
+        self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=True)
+        # LN1 -> attention
+        self._lnb(plan, ws, S, GA, b[tag + '.r1'].data_ptr(), b[tag + '.m1'].data_ptr(), b[tag + '.s1'].data_ptr(), gam,
+                  GB, GC if use_drop else 0, so, dgam, dbet, 1.0, dy_bf=True, dr_bf=True)
+        self._tn(plan, ws, S, d, d, dbr, d, b[tag + '.ctx'].data_ptr(), d, [(0, d, self.G(pa + 'fc_o.weight'), self.G(pa + 'fc_o.bias'))], dy_bf=True, x_bf=True)
+        self._sl(plan, ws, S, d, d, dbr, d, key + '.sa.o_t', 0, Gx, d)
+        qkv = b[tag + '.qkv'].data_ptr()
+        self._attn(plan, ws, True, n_seq, H, L, L, qkv, L * 3 * d, 3 * d, qkv + 2 * d, L * 3 * d, 3 * d, qkv + 4 * d, L * 3 * d, 3 * d,
+                   b[tag + '.ctx'].data_ptr(), L * d, d, b[tag + '.lse'].data_ptr(), drop_site=sa, dout=Gx,
+                   dq=Gq, dqss=L * 3 * d, lddq=3 * d, dk=Gq + 2 * d, dkss=L * 3 * d, lddk=3 * d, dv=Gq + 4 * d, dvss=L * 3 * d, lddv=3 * d,
+                   flags=1 | 2 | 4 | 8 | 16)
+        self._tn(plan, ws, S, 3 * d, d, Gq, 3 * d, x_in, d,
+                 [(0, d, self.G(pa + 'fc_q.weight'), self.G(pa + 'fc_q.bias')), (d, d, self.G(pa + 'fc_k.weight'), self.G(pa + 'fc_k.bias')),
+                  (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))], dy_bf=True, x_bf=True)
+        self._sl(plan, ws, S, d, 3 * d, Gq, 3 * d, key + '.sa.qkv_t', 0, GA, d, residual=GB, ldr=d)
+
     def _ffn_bwd(self, plan, ws, tag, key, pre, S, x_in, G, ln_beta):
         """FFN + LN block of the decoder layers: grad of output in GA -> grad of x_in in GA."""
         d, p = self.d, self.p
@@ -787,6 +821,14 @@ class HfttEngine:
         dgam, dbet = self.G(pre + 'layer_norm.weight'), self.G(pre + 'layer_norm.bias')
         pf = pre + 'positionwise_feedforward.'
         use_drop = self.dropout > 0.0
+        if self.strip:
+            dbr = GC if use_drop else GB
+            self._lnb(plan, ws, S, GA, b[tag + '.fr'].data_ptr(), b[tag + '.fm'].data_ptr(), b[tag + '.fs'].data_ptr(), gam,
+                      GB, GC if use_drop else 0, sf, dgam, dbet, ln_beta, dy_bf=True, dr_bf=True)
+            self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True)
+            self._mlp(plan, ws, 1, S, dbr, key + '.ffn_t', GA, h_out=Gh, gate=b[tag + '.h'].data_ptr(), gate_scale=('inv_keep',), residual=GB)
+            self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=True)
+            return
         self._lnb(plan, ws, S, GA, b[tag + '.fr'].data_ptr(), b[tag + '.fm'].data_ptr(), b[tag + '.fs'].data_ptr(), gam,
                   GB, GC if use_drop else 0, sf, dgam, dbet, ln_beta)
         dbr, dbr_bf = (GC, True) if use_drop else (GB, False)
@@ -812,15 +854,17 @@ class HfttEngine:
         # (K=512: 253 -> 284 us, K=768: 324 -> 366 us) -- net zero, so it is OFF by default (HFTT_BF16_GRAD=1 enables) until the
         # row pass handles 8 columns per lane for bf16 residual / C.
         # (needs the A-stationary GEMM on every encoder dX: d % 256 == 0, K = ff and 3d <= 768, >= 256 bin tokens)
-        egb = (self.sb and os.environ.get('HFTT_BF16_GRAD', '0') == '1' and d % 256 == 0 and max(p, 3 * d) <= 768 and Se >= 256)
-        ws['bf16_grad'] = bool(egb)
+        st = self.strip                              # strip mode: the whole gradient stream is bf16
+        egb = (not st and self.sb and os.environ.get('HFTT_BF16_GRAD', '0') == '1' and d % 256 == 0 and max(p, 3 * d) <= 768 and Se >= 256)
+        ws['bf16_grad'] = bool(egb or st)
         # gradient scratch: note-token sized and bin-token sized sets
-        nGA = self._buf(ws, 'g.nA', Sn, d).data_ptr(); nGB = self._buf(ws, 'g.nB', Sn, d).data_ptr()
+        nGA = self._abuf(ws, 'g.nA', Sn, d).data_ptr(); nGB = self._abuf(ws, 'g.nB', Sn, d).data_ptr()
         hz = 2 if self.sb else 4
-        nGC = self._buf(ws, 'g.nC', Sn, d, half=True).data_ptr(); nGD = self._buf(ws, 'g.nD', Sn, d).data_ptr()
+        nGC = self._buf(ws, 'g.nC', Sn, d, half=True).data_ptr(); nGD = self._abuf(ws, 'g.nD', Sn, d).data_ptr()
         nGh = self._buf(ws, 'g.nh', Sn, p, half=True).data_ptr(); nGq = self._buf(ws, 'g.nq', Sn, 3 * d, half=True).data_ptr()
         nGx = self._buf(ws, 'g.nx', Sn, d, half=True).data_ptr()
-        eGA = self._buf(ws, 'g.eA', Se, d).data_ptr(); eGB = self._buf(ws, 'g.eB', Se, d).data_ptr()
+        q1f = self._buf(ws, 'g.q1f', Sn, d).data_ptr() if st else 0          # layer zero's per-sequence dq stays fp32 (summed over sequences)
+        eGA = self._abuf(ws, 'g.eA', Se, d).data_ptr(); eGB = self._abuf(ws, 'g.eB', Se, d).data_ptr()
         eGC = self._buf(ws, 'g.eC', Se, d, half=True).data_ptr()
         eGh = self._buf(ws, 'g.eh', Se, p, half=True).data_ptr(); eGq = self._buf(ws, 'g.eq', Se, 3 * d, half=True).data_ptr()
         eGx = self._buf(ws, 'g.ex', Se, d, half=True).data_ptr()
@@ -843,17 +887,20 @@ class HfttEngine:
         plan.append(('heads_bwd', ('B', dlog, 1), 'heads_split_bwd', None))
         y_last = ws['time_in'][-1]
         self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, y_last, d, head_segs('time'), x_bf=self.strip)
-        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_t_t'), 0, nGA, d)
+        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_t_t'), 0, nGA, d, c_bf=st)
         Gn = (nGA, nGB, nGC, nGh, nGq, nGx)
         for i in reversed(range(self.Ld)):
-            self._enc_layer_bwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, ws['time_in'][i], Gn)
+            if st:
+                self._enc_layer_bwd_strip(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, ws['time_in'][i], Gn)
+            else:
+                self._enc_layer_bwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, ws['time_in'][i], Gn)
         # ---- heads A, then the time-embedding transpose back onto the note-major gradient ----
         plan.append(('heads_bwd', ('A', dlog, 0), 'heads_split_bwd', None))
         f_last = ws['dec_out'][-1]
         self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, f_last, d, head_segs('freq'), x_bf=self.strip)
-        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_f_t'), 0, nGD, d)
-        plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed']), 'time_embed_bwd', None))
-        plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws), 'colsum', None))
+        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_f_t'), 0, nGD, d, c_bf=st)
+        plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed'], 7 if st else 0), 'time_embed_bwd', None))
+        plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws, 1 if st else 0), 'colsum', None))
         # gradient buckets in the order they become final (flat ranges are contiguous: state_dict order is encoder,
         # frequency decoder + heads A, time decoder + heads B): (plan length when final, flat lo, flat hi)
         o_dec, o_time, o_end = self.poff[dd + 'pos_embedding_freq.weight'], self.poff[dd + 'pos_embedding_time.weight'], self.flat_grads.numel()
@@ -862,7 +909,7 @@ class HfttEngine:
         #      the encoder-output gradient accumulates in eGA ----
         A, Bf, Cf, Q1 = nGD, nGB, nGC, nGA
         Gd = (A, Bf, Cf, nGh, nGq, nGx)
-        dbr, dbr_bf = (Cf, True) if use_drop else (Bf, False)
+        dbr, dbr_bf = (Cf, True) if use_drop else (Bf, st)
         first_enc_grad = True
         enc = ws['enc']
         for j in reversed(range(self.Ld)):
@@ -875,10 +922,13 @@ class HfttEngine:
             self._ffn_bwd(plan, ws, tag, tag, pre, Sn, b[tag + '.cx'].data_ptr(), Gd, 0.0)
             c_a, c_o = sites['cross']
             self._lnb(plan, ws, Sn, A, b[tag + '.cr'].data_ptr(), b[tag + '.cm'].data_ptr(), b[tag + '.cs'].data_ptr(), gam,
-                      Bf, Cf if use_drop else 0, c_o, dgam, dbet, 1.0)
+                      Bf, Cf if use_drop else 0, c_o, dgam, dbet, 1.0, dy_bf=st, dr_bf=st)
             self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.cctx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_o.weight'), self.G(pc + 'fc_o.bias'))],
                      dy_bf=dbr_bf, x_bf=True)
-            self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.ca.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
+            if st:
+                self._sl(plan, ws, Sn, d, d, dbr, d, tag + '.ca.o_t', 0, nGx, d)
+            else:
+                self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.ca.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
             kk = b[tag + '.ckv'].data_ptr()
             if j > 0:
                 qaddr, qss = b[tag + '.cq'].data_ptr(), N * d
@@ -886,30 +936,41 @@ class HfttEngine:
                 qaddr, qss = b['dec0.q0'].data_ptr(), 0
             # dq (per sequence) -> Q1 ; dk,dv -> eGq viewed as [Se, 2d]
             # per-sequence dq stays fp32 (layer zero sums it over sequences with the fp32 colsum); dk, dv are "half" tensors
+            # strip mode: dq of the layers with their own query projection is a GEMM operand only -> bf16; layer zero keeps fp32 (q1f)
+            dq_buf = Q1 if not st else (Q1 if j > 0 else q1f)
             self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
                        b[tag + '.cctx'].data_ptr(), N * d, d, b[tag + '.clse'].data_ptr(), drop_site=c_a, dout=nGx,
-                       dq=Q1, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + hz * d, dvss=F * 2 * d, lddv=2 * d,
-                       flags=1 | 2 | 4 | 16)
+                       dq=dq_buf, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + hz * d, dvss=F * 2 * d, lddv=2 * d,
+                       flags=1 | 2 | 4 | 16 | (8 if (st and j > 0) else 0))
             self._tn(plan, ws, Se, 2 * d, d, eGq, 2 * d, enc, d,
                      [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
-            if first_enc_grad:
+            if st:                                   # (in place: a lane reads exactly the residual elements it then overwrites)
+                self._sl(plan, ws, Se, d, 2 * d, eGq, 2 * d, tag + '.ca.kv_t', 0, eGA, d, residual=0 if first_enc_grad else eGA, ldr=d)
+                first_enc_grad = False
+            elif first_enc_grad:
                 self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, a_bf=True, c_bf=egb)
                 first_enc_grad = False
             else:
                 self._nt(plan, ws, Se, d, 2 * d, eGq, 2 * d, self.Wp(tag + '.ca.kv_t'), 0, eGA, d, residual=eGA, ldr=d, a_bf=True, res_bf=egb, c_bf=egb)
             if j > 0:
                 # q projection of the cross attention (input sx, which is also the residual of this block)
-                self._tn(plan, ws, Sn, d, d, Q1, d, b[tag + '.sx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))], x_bf=self.strip)
-                self._nt(plan, ws, Sn, d, d, Q1, d, self.Wp(tag + '.ca.q_t'), 0, A, d, residual=Bf, ldr=d)
+                self._tn(plan, ws, Sn, d, d, Q1, d, b[tag + '.sx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))], dy_bf=st, x_bf=st)
+                if st:
+                    self._sl(plan, ws, Sn, d, d, Q1, d, tag + '.ca.q_t', 0, A, d, residual=Bf, ldr=d)
+                else:
+                    self._nt(plan, ws, Sn, d, d, Q1, d, self.Wp(tag + '.ca.q_t'), 0, A, d, residual=Bf, ldr=d)
                 # self-attention block (input trg = previous layer output)
                 s_a, s_o = sites['self']
                 ps = pre + 'self_attention.'
                 trg = ws['dec_out'][j - 1]
                 self._lnb(plan, ws, Sn, A, b[tag + '.sr'].data_ptr(), b[tag + '.sm'].data_ptr(), b[tag + '.ss'].data_ptr(), gam,
-                          Bf, Cf if use_drop else 0, s_o, dgam, dbet, 1.0)
+                          Bf, Cf if use_drop else 0, s_o, dgam, dbet, 1.0, dy_bf=st, dr_bf=st)
                 self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.sctx'].data_ptr(), d, [(0, d, self.G(ps + 'fc_o.weight'), self.G(ps + 'fc_o.bias'))],
                          dy_bf=dbr_bf, x_bf=True)
-                self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.sa.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
+                if st:
+                    self._sl(plan, ws, Sn, d, d, dbr, d, tag + '.sa.o_t', 0, nGx, d)
+                else:
+                    self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.sa.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
                 q = b[tag + '.sqkv'].data_ptr()
                 self._attn(plan, ws, True, BT, H, N, N, q, N * 3 * d, 3 * d, q + hz * d, N * 3 * d, 3 * d, q + 2 * hz * d, N * 3 * d, 3 * d,
                            b[tag + '.sctx'].data_ptr(), N * d, d, b[tag + '.slse'].data_ptr(), drop_site=s_a, dout=nGx,
@@ -918,12 +979,15 @@ class HfttEngine:
                 self._tn(plan, ws, Sn, 3 * d, d, nGq, 3 * d, trg, d,
                          [(0, d, self.G(ps + 'fc_q.weight'), self.G(ps + 'fc_q.bias')), (d, d, self.G(ps + 'fc_k.weight'), self.G(ps + 'fc_k.bias')),
                           (2 * d, d, self.G(ps + 'fc_v.weight'), self.G(ps + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
-                self._nt(plan, ws, Sn, d, 3 * d, nGq, 3 * d, self.Wp(tag + '.sa.qkv_t'), 0, A, d, residual=Bf, ldr=d, a_bf=True)
+                if st:
+                    self._sl(plan, ws, Sn, d, 3 * d, nGq, 3 * d, tag + '.sa.qkv_t', 0, A, d, residual=Bf, ldr=d)
+                else:
+                    self._nt(plan, ws, Sn, d, 3 * d, nGq, 3 * d, self.Wp(tag + '.sa.qkv_t'), 0, A, d, residual=Bf, ldr=d, a_bf=True)
             else:
                 # layer zero: query = fc_q(pos_embedding_freq) shared by all sequences, residual = pos_embedding_freq
                 gpos = self.G(dd + 'pos_embedding_freq.weight')
-                plan.append(('colsum', (Bf, BT, N * d, N * d, gpos, 0.0, cs_ws), 'colsum', None))       # residual path (undropped dr)
-                plan.append(('colsum', (Q1, BT, N * d, N * d, dq0s, 0.0, cs_ws), 'colsum', None))       # sum of per-sequence dq
+                plan.append(('colsum', (Bf, BT, N * d, N * d, gpos, 0.0, cs_ws, 1 if st else 0), 'colsum', None))       # residual path (undropped dr)
+                plan.append(('colsum', (q1f if st else Q1, BT, N * d, N * d, dq0s, 0.0, cs_ws, 0), 'colsum', None))     # sum of per-sequence dq
                 self._tn(plan, ws, N, d, d, dq0s, d, self.P(dd + 'pos_embedding_freq.weight'), d,
                          [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
                 self._nt(plan, ws, N, d, d, dq0s, d, self.Wp(tag + '.ca.q_t'), 0, gpos, d, residual=gpos, ldr=d)
@@ -931,13 +995,16 @@ class HfttEngine:
         # ---- encoder layers ----
         Ge = (eGA, eGB, eGC, eGh, eGq, eGx)
         for i in reversed(range(self.Le)):
+            if st:
+                self._enc_layer_bwd_strip(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, ws['enc_in'][i], Ge)
+                continue
             self._enc_layer_bwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, ws['enc_in'][i], Ge,
                                 in_bf=egb, gbf=egb, out_bf=(egb and i > 0))     # the embedding stage below reads fp32
         # ---- embedding ----
-        plan.append(('dropout_bwd', (eGA, Se * d, ws['sites']['embed']), 'dropout_bwd', None))
-        plan.append(('colsum', (eGA, BT, F * d, F * d, self.G(e + 'pos_embedding_freq.weight'), 0.0, cs_ws), 'colsum', None))
+        plan.append(('dropout_bwd', (eGA, Se * d, ws['sites']['embed'], 1 if st else 0), 'dropout_bwd', None))
+        plan.append(('colsum', (eGA, BT, F * d, F * d, self.G(e + 'pos_embedding_freq.weight'), 0.0, cs_ws, 1 if st else 0), 'colsum', None))
         self._tn(plan, ws, Se, d, self.Kp, eGA, d, b['win'].data_ptr(), self.Kp, [(0, d, self.dweff.data_ptr(), self.dbeff.data_ptr())],
-                 out_scale=math.sqrt(d))
+                 out_scale=math.sqrt(d), dy_bf=st)
         plan.append((self.lib.hftt_embed_fold_bwd, (C.byref(self.fold),), 'embed_fold_bwd', None))
         marks.append((len(plan), 0, o_dec))
         ws['bwd'] = plan
@@ -972,14 +1039,14 @@ class HfttEngine:
                 x, pos, y, site, iof = args
                 rc = L.hftt_time_embed_fwd(x, pos, y, B, T, N, d, math.sqrt(d), p, site, seed, iof, stream)
             elif fn == 'time_embed_bwd':
-                dy, dx, dym, site = args
-                rc = L.hftt_time_embed_bwd(dy, dx, dym, B, T, N, d, math.sqrt(d), p, site, seed, 1, 0, stream)
+                dy, dx, dym, site, iof = args
+                rc = L.hftt_time_embed_bwd(dy, dx, dym, B, T, N, d, math.sqrt(d), p, site, seed, 1, iof, stream)
             elif fn == 'colsum':
-                x, rows, n, ld, out, beta, wsp = args
-                rc = L.hftt_colsum(x, rows, n, ld, out, beta, wsp, 0, stream)
+                x, rows, n, ld, out, beta, wsp, xbf = args
+                rc = L.hftt_colsum(x, rows, n, ld, out, beta, wsp, xbf, stream)
             elif fn == 'dropout_bwd':
-                g, n, site = args
-                rc = L.hftt_dropout_bwd(g, n, p, site, seed, 0, stream) if p > 0.0 else 0
+                g, n, site, gbf = args
+                rc = L.hftt_dropout_bwd(g, n, p, site, seed, gbf, stream) if p > 0.0 else 0
             else:
                 raise _capi.HfttError('unknown plan op %s' % fn)
             if prof is not None:

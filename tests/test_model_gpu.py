@@ -209,43 +209,47 @@ def test_dropout_training_mode(dev):
     assert all(max_err(p, q) == 0.0 for p, q in zip(a, b))
 
 
-def test_bf16_gradient_stream_option_matches_default_within_rounding(dev, monkeypatch):
-    """HFTT_BF16_GRAD=1 (opt-in, off by default because it measured net-zero): the encoder-side gradient stream stored as bf16.
-    Every gradient must stay within bf16 rounding of the default bf16-mode gradient (same seed, dropout on, same masks)."""
+def test_strip_kernels_match_the_round1_kernels_with_dropout_on(dev, monkeypatch):
+    """bf16 mode at the paper's width runs the strip kernels (bf16 activation + gradient streams, fused FFN); HFTT_STRIP=0 runs the
+    round-1 kernels (fp32 streams).  Same seed: every dropout site must regenerate the same masks in both builds, forward and backward.
+    Two bf16 roundings of this model differ visibly by themselves (first-layer attention logits ~1e4), so the
+    yardstick is the difference of the two builds with dropout OFF: turning dropout on must not make it materially larger (a site /
+    index mismatch anywhere would be an O(1) change of the masked activations)."""
     from hftt_hip.trainer import TrainStep
-    # the option needs the paper's width (d = 256, ff = 512: every encoder dX on the A-stationary GEMM); frames/bins/notes stay small
     cfg = O.HfttConfig(n_margin=4, n_frame=16, n_bin=48, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512,
                        enc_layer=2, dec_layer=2, enc_head=4, dec_head=4, n_note=12, n_velocity=16)
     B = 2
     x = (O.synth_spec(B, cfg, salt=21) * 0.5).to(dev)
     ld = _to_dev(O.synth_labels(B, cfg, salt=22), dev)
-    grads = {}
-    for flag in ('0', '1'):
-        monkeypatch.setenv('HFTT_BF16_GRAD', flag)
-        model = util.build_model(cfg, 7, dropout=0.1).to(dev)
-        model.hftt_precision = 'bf16'
-        model.train()
-        ts = TrainStep(model, lr=1e-3)
-        ts.forward_backward(x, *ld)
-        torch.cuda.synchronize()
-        eng = ts.engine
-        assert torch.isfinite(eng.flat_grads).all()
-        assert eng._ws[B]['bf16_grad'] == (flag == '1')          # the option engaged (and only when asked for)
-        grads[flag] = {name: eng.flat_grads[o:o + n].clone() for (name, _, o, n) in eng._bound}
-    worst = 0.0
-    for name, g0 in grads['0'].items():
-        g1 = grads['1'][name]
-        scale = g0.abs().max().item()
-        if name.endswith('fc_k.bias'):
-            # true gradient is identically zero (softmax ignores a constant added to every key's logit): what both runs hold is
-            # bf16-mode rounding noise (measured 3e-5 .. 3e-3 here), so a relative difference is noise / noise.  The option must
-            # not make that noise bigger.
-            assert g1.abs().max().item() <= 2.0 * scale + 1e-6, (name, scale, g1.abs().max().item())
-            continue
-        if scale < 1e-7:
-            continue
-        worst = max(worst, (g1 - g0).abs().max().item() / scale)
-    assert 0.0 < worst < 3e-2, worst          # measured 9e-3; > 0: the option really changed the arithmetic
+    diff = {}
+    for drop in (0.0, 0.1):
+        grads, outs, losses = {}, {}, {}
+        for flag in ('0', '1'):
+            monkeypatch.setenv('HFTT_STRIP', flag)
+            model = util.build_model(cfg, 7, dropout=drop).to(dev)
+            model.hftt_precision = 'bf16'
+            model.train()
+            ts = TrainStep(model, lr=1e-3)
+            loss = ts.forward_backward(x, *ld)
+            torch.cuda.synchronize()
+            eng = ts.engine
+            assert eng.strip == (flag == '1') and eng._ws[B]['bf16_grad'] == (flag == '1')
+            assert torch.isfinite(eng.flat_grads).all()
+            grads[flag] = torch.cat([eng.flat_grads[o:o + n] for (name, _, o, n) in eng._bound
+                                     if not name.endswith('fc_k.bias') and 'encoder_spec2midi.layers_freq.0.self_attention' not in name
+                                     and not any(t in name for t in ('conv', 'tok_embedding_freq', 'encoder_spec2midi.pos_embedding_freq'))]).double()
+            outs[flag] = [t.clone() for t in eng._ws[B]['outs']]
+            losses[flag] = loss[0].item()
+        diff[drop] = {'post': max(max_err(outs['1'][k], outs['0'][k]) for k in (0, 1, 2, 5, 6, 7)),
+                      'logit': max(max_err(outs['1'][k], outs['0'][k]) for k in (3, 8)),
+                      'loss': abs(losses['0'] - losses['1']),
+                      'gcos': float((grads['0'] @ grads['1']) / (grads['0'].norm() * grads['1'].norm()))}
+    print('strip vs round-1 kernels (bf16 mode):', json.dumps({str(k): v for k, v in diff.items()}))
+    assert diff[0.0]['post'] > 0.0                                     # the two builds really are different arithmetic
+    assert diff[0.1]['post'] < 2.5 * diff[0.0]['post'] + 0.02
+    assert diff[0.1]['logit'] < 2.5 * diff[0.0]['logit'] + 0.05
+    assert diff[0.1]['loss'] < 2.5 * diff[0.0]['loss'] + 0.02
+    assert diff[0.0]['gcos'] > 0.99 and diff[0.1]['gcos'] > 0.99
 
 
 def test_backward_reports_gradient_buckets_when_final(dev):
