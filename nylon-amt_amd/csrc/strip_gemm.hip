@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include "hftt_common.h"
 #include "hftt_host.h"
+#include "strip_internal.h"
 #include "../../include/hftt_hip.h"
 
 namespace {
@@ -24,6 +25,18 @@ constexpr int SLOT_BYTES = 16384;
 constexpr int NSLOT = 4;
 constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
 constexpr int FILL_AHEAD = NSLOT - 1;
+
+// Ablation build (tools/ablate_strip.sh compiles this file with -DHFTT_STRIP_ABLATE into its own library): the descriptor's pad
+// field switches single mechanisms off so their cost can be read from the timing difference (results are then garbage).
+//   1 no LDS-DMA fills / waits in the main loop   2 no fragment reads + MFMAs   4 no epilogue stores   8 no barriers
+#ifdef HFTT_STRIP_ABLATE
+#define ABL(g, bit) (((g).pad & (bit)) != 0)
+// bit 64: lane 0 of every wave writes shader-clock stamps to the (otherwise unused) ln_mean buffer: [wave id][16] uint64
+#define STAMP(g, k) do { if (ABL(g, 64) && lane == 0) reinterpret_cast<unsigned long long*>((g).ln_mean)[((long)blockIdx.x * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ABL(g, bit) false
+#define STAMP(g, k) do { } while (0)
+#endif
 
 // MFMA row i of a weight fragment <-> feature c(i) of the 32-wide tile; finv is the inverse
 __host__ __device__ inline int strip_c_of_i(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
@@ -82,6 +95,15 @@ __device__ __forceinline__ void wait_slot(int s, int S) {
   if (s + 2 < S) wait_vmcnt<8>();
   else if (s + 1 < S) wait_vmcnt<4>();
   else wait_vmcnt<0>();
+}
+// the same right after an epilogue that issued at least NST vector stores behind this slot's DMA (vmcnt retires in issue order: ops
+// younger than the awaited DMA may all stay in flight, so the previous pass's stores drain under this pass's MFMAs).  NST must be a
+// LOWER bound of the stores the compiler emitted: too small only waits longer, too large would read the slot early.
+template <int NST>
+__device__ __forceinline__ void wait_slot_after_stores(int s, int S) {
+  if (s + 2 < S) wait_vmcnt<8 + NST>();
+  else if (s + 1 < S) wait_vmcnt<4 + NST>();
+  else wait_vmcnt<NST>();
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -239,7 +261,23 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
   const bool res_bf = LN ? true : (bool)(g.flags & HFTT_SL_RES_BF16);       // the LayerNorm form is all-bf16 (host check)
   const long rrow = g.res_mod > 0 ? (long)((unsigned)tokc % (unsigned)g.res_mod) : tokc;
 
+#ifdef HFTT_STRIP_ABLATE
+  if (blockIdx.x >= 256 && blockIdx.x < 512 && (g.pad >> 8) > 0) {        // stagger experiment: the second workgroup of each CU starts late (first generation only)
+    for (int i = 0; i < (g.pad >> 8); i++) __builtin_amdgcn_s_sleep(16);      // ~1024 cycles per iteration
+  }
+#endif
+  STAMP(g, 0);
   bf16x8 xf[8][2];
+#ifdef HFTT_STRIP_ABLATE
+  if (ABL(g, 16)) {      // same bytes per wave, but every wave instruction reads 1 KB contiguous (wrong data: timing only)
+    const long wb = ((long)blockIdx.x * 128 + wave * 32) * g.ldx;
+#pragma unroll
+    for (int pt = 0; pt < 8; pt++) {
+      const bf16x8* p = reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(g.x) + wb + pt * 1024 + lane * 8);
+      xf[pt][0] = p[0]; xf[pt][1] = p[64];
+    }
+  } else
+#endif
   load_xfrags<XBF>(xf, g.x, tokc * g.ldx + 16 * h, kpc);
   for (int i = tid; i < g.N; i += 256) prm[i] = g.bias != nullptr ? g.bias[i] : 0.f;
   if (LN) {
@@ -254,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
   const unsigned char* abase = smem + lane * 16;
 
   int s = 0;
+  STAMP(g, 1);
   for (int pass = 0; pass < passes; pass++) {
     const int n0 = pass * 256;
     f32x16 acc[8];
@@ -262,10 +301,16 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
 #pragma unroll
       for (int pt = 0; pt < 8; pt++) {
         if (pt < kpc) {
-          wait_slot(s, S);
+          if (!ABL(g, 1)) {
+            // first three slots of a later pass: the 16 (bf16 C: two dwordx4 per tile) or 32 (fp32 C) stores of the previous pass's
+            // epilogue are younger than the slot's DMA (plain epilogue only: gate / residual loads would sit between them)
+            if (!LN && pass > 0 && kc == 0 && pt < FILL_AHEAD && g.gate == nullptr && g.residual == nullptr) wait_slot_after_stores<CBF ? 16 : 32>(s, S);
+            else wait_slot(s, S);
+          }
           if (s == 0) wait_lgkm0();                    // the parameter rows written to LDS above
-          __builtin_amdgcn_s_barrier();
-          ring_fill(g.w, s + FILL_AHEAD, S - 1, ring, wave, lane);
+          if (!ABL(g, 8)) __builtin_amdgcn_s_barrier();
+          if (s == 0) STAMP(g, 8);
+          if (!ABL(g, 1)) ring_fill(g.w, s + FILL_AHEAD, S - 1, ring, wave, lane);
           if (kc == 0 && pt == 0) {                    // accumulators start from the bias
 #pragma unroll
             for (int ot = 0; ot < 8; ot++) {
@@ -276,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
             }
           }
           const unsigned char* slot = abase + (pt & (NSLOT - 1)) * SLOT_BYTES;
+          if (!ABL(g, 2)) {
 #pragma unroll
           for (int u = 0; u < 2; u++)
 #pragma unroll
@@ -283,11 +329,13 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
               const bf16x8 a = *reinterpret_cast<const bf16x8*>(slot + (u * 8 + ot) * 1024);
               acc[ot] = mfma32(a, xf[pt][u], acc[ot]);
             }
+          }
           s++;
         }
       }
     }
     // ---------------- epilogue of this pass ----------------
+    if (!LN) { if (pass == 0) STAMP(g, 2); else if (pass == 1) STAMP(g, 4); else STAMP(g, 6); }
     const bool relu = g.flags & HFTT_SL_RELU;
     const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 1;        // pair index of (row, col 0); N is even
     if (LN) {
@@ -309,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
         __builtin_amdgcn_sched_barrier(0);             // one tile at a time: hoisting all 64 hashes of the row spills
       }
       LnArgs la{prm + g.N, prm + g.N + 256, g.pre_ln_out, g.ln_mean, g.ln_rstd, g.C, (long)g.ldc, c_bf};
-      ln_epilogue(acc, la, tok, tok_ok, h);
+      ln_epilogue(acc, la, tok, tok_ok && !ABL(g, 4), h);
     } else {
 #pragma unroll
       for (int ot = 0; ot < 8; ot++) {
@@ -334,9 +382,16 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
 #pragma unroll
           for (int q = 0; q < 16; q++) v[q] += r[q];
         }
-        if (tok_ok) store16(g.C, c_bf, tok * g.ldc + col0, v);
+#ifdef HFTT_STRIP_ABLATE
+        if (ABL(g, 32)) {    // same bytes, 1 KB contiguous per wave instruction (wrong placement: timing only)
+          const long wb = ((long)blockIdx.x * 128 + wave * 32) * g.ldc + (long)pass * 256 * 32;
+          store16(g.C, c_bf, wb + ot * 1024 + lane * 16, v);
+        } else
+#endif
+        if (tok_ok && !ABL(g, 4)) store16(g.C, c_bf, tok * g.ldc + col0, v);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (pass == 0) STAMP(g, 3); else if (pass == 1) STAMP(g, 5); else STAMP(g, 7);
     }
   }
 }
@@ -360,6 +415,11 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
   float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // b1[p] | b2[256] | gamma[256] | beta[256]
   constexpr bool c_bf = true, res_bf = true;
 
+#ifdef HFTT_STRIP_ABLATE
+  if (blockIdx.x >= 256 && blockIdx.x < 512 && (g.pad >> 8) > 0) {
+    for (int i = 0; i < (g.pad >> 8); i++) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   bf16x8 xf[8][2];
   load_xfrags<XBF>(xf, g.x, tokc * g.ldx + 16 * h, 8);
   for (int i = tid; i < g.p; i += 256) prm[i] = (MODE == 0 && g.b1 != nullptr) ? g.b1[i] : 0.f;
@@ -389,10 +449,10 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
       const int t = t0 + tt;
       const int sA = 2 * t, sB = 2 * t + 1;
       // ---- first GEMM, hidden tile t: 16 k-steps over the resident strip ----
-      wait_slot(sA, S);
+      if (!ABL(g, 1)) wait_slot(sA, S);
       if (t == 0) wait_lgkm0();
-      __builtin_amdgcn_s_barrier();
-      ring_fill(g.w, sA + FILL_AHEAD, S - 1, ring, wave, lane);
+      if (!ABL(g, 8)) __builtin_amdgcn_s_barrier();
+      if (!ABL(g, 1)) ring_fill(g.w, sA + FILL_AHEAD, S - 1, ring, wave, lane);
       if (t == 0) {
 #pragma unroll
         for (int ot = 0; ot < 8; ot++) {
@@ -416,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
 #pragma unroll
         for (int q = 0; q < 16; q++) hacc[q] = b[q];
       }
-      {
+      if (!ABL(g, 2)) {
         const unsigned char* slot = abase + (2 * tt) * SLOT_BYTES;
 #pragma unroll
         for (int pt = 0; pt < 8; pt++)
@@ -441,15 +501,15 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
       }
       bf16x8 hf[2];
       hf[0] = pack8(v); hf[1] = pack8(v + 8);
-      if (g.h_out != nullptr && tok_ok) {
+      if (g.h_out != nullptr && tok_ok && !ABL(g, 4)) {
         bf16x8* hp = reinterpret_cast<bf16x8*>(g.h_out + tok * g.ldh + hcol0);
         hp[0] = hf[0]; hp[1] = hf[1];
       }
       // ---- second GEMM, K-slice t ----
-      wait_slot(sB, S);
-      __builtin_amdgcn_s_barrier();
-      ring_fill(g.w, sB + FILL_AHEAD, S - 1, ring, wave, lane);
-      {
+      if (!ABL(g, 1)) wait_slot(sB, S);
+      if (!ABL(g, 8)) __builtin_amdgcn_s_barrier();
+      if (!ABL(g, 1)) ring_fill(g.w, sB + FILL_AHEAD, S - 1, ring, wave, lane);
+      if (!ABL(g, 2)) {
         const unsigned char* slot = abase + (2 * tt + 1) * SLOT_BYTES;
 #pragma unroll
         for (int u = 0; u < 2; u++)
@@ -486,14 +546,14 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
     if (MODE == 0) {
 #pragma unroll
       for (int q = 0; q < 16; q++) yacc[ot][q] = v[q];
-    } else if (tok_ok) {
+    } else if (tok_ok && !ABL(g, 4)) {
       store16(g.y, c_bf, tok * g.ldy + col0, v);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   if (MODE == 0) {
     LnArgs la{prm + g.p + 256, prm + g.p + 512, g.pre_ln_out, g.ln_mean, g.ln_rstd, g.y, (long)g.ldy, c_bf};
-    ln_epilogue(yacc, la, tok, tok_ok, h);
+    ln_epilogue(yacc, la, tok, tok_ok && !ABL(g, 4), h);
   }
 }
 
@@ -504,8 +564,16 @@ int set_lds(K kernel, int lds, const char* what) {
   return 0;
 }
 
+#ifdef HFTT_STRIP_ABLATE
+int ablate_bits() { const char* e = getenv("HFTT_STRIP_ABLATE"); return e ? atoi(e) : 0; }
+#endif
+
 template <bool XBF, bool CBF, bool LN>
-int launch_linear(const hftt_strip_desc& d, hipStream_t st) {
+int launch_linear(const hftt_strip_desc& d0, hipStream_t st) {
+  hftt_strip_desc d = d0;
+#ifdef HFTT_STRIP_ABLATE
+  d.pad = ablate_bits();
+#endif
   const int lds = RING_BYTES + 4 * (d.N + 512);
   static int attr = 0;
   if (lds > attr) { if (int rc = set_lds(strip_linear_kernel<XBF, CBF, LN>, lds, "strip_linear")) return rc; attr = lds; }
@@ -514,7 +582,11 @@ int launch_linear(const hftt_strip_desc& d, hipStream_t st) {
   return 0;
 }
 template <int MODE>
-int launch_mlp(const hftt_ffn_desc& d, hipStream_t st) {
+int launch_mlp(const hftt_ffn_desc& d0, hipStream_t st) {
+  hftt_ffn_desc d = d0;
+#ifdef HFTT_STRIP_ABLATE
+  d.pad = ablate_bits();
+#endif
   const int lds = RING_BYTES + 4 * (d.p + 768);
   static int attr = 0;
   if (lds > attr) { if (int rc = set_lds(strip_mlp_kernel<MODE>, lds, "strip_mlp")) return rc; attr = lds; }
@@ -574,6 +646,12 @@ extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
     HFTT_REQUIRE(d->N == 256 && d->ln_beta != nullptr && d->ldc == 256, "strip_linear: LayerNorm needs N == 256 == ldc and beta");
     HFTT_REQUIRE(d->gate == nullptr && !(d->flags & HFTT_SL_RELU), "strip_linear: gate / ReLU cannot be combined with LayerNorm");
     HFTT_REQUIRE(d->pre_ln_out == nullptr || ((uintptr_t)d->pre_ln_out & 15) == 0, "strip_linear: pre_ln_out alignment");
+  }
+  {                                                   // persistent software-pipelined form where it applies (strip_gemm2.hip)
+    const int rc = hftt_strip_linear2_try(*d, st);
+    if (rc >= 0) return rc;
+  }
+  if (d->ln_gamma != nullptr) {
     return launch_linear<true, true, true>(*d, st);
   }
   if (cbf) return xbf ? launch_linear<true, true, false>(*d, st) : launch_linear<false, true, false>(*d, st);
@@ -584,6 +662,8 @@ extern "C" int hftt_ffn_res_ln_fwd(const hftt_ffn_desc* d, void* stream) {
   if (int rc = check_ffn(d, 0, "ffn_res_ln_fwd")) return rc;
   HFTT_REQUIRE(d->ln_gamma != nullptr && d->ln_beta != nullptr && d->ldy == 256, "ffn_res_ln_fwd: needs gamma, beta and ldy == 256");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rc2 = hftt_strip_mlp2_try(*d, st);
+  if (rc2 >= 0) return rc2;
   return launch_mlp<0>(*d, st);
 }
 
@@ -591,5 +671,7 @@ extern "C" int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream) {
   if (int rc = check_ffn(d, 1, "ffn_bwd_dx")) return rc;
   HFTT_REQUIRE(d->gate != nullptr && d->ldg % 8 == 0 && ((uintptr_t)d->gate & 15) == 0, "ffn_bwd_dx: needs the stored hidden (bf16, 16-byte aligned rows)");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rc2 = hftt_strip_mlp2_try(*d, st);
+  if (rc2 >= 0) return rc2;
   return launch_mlp<1>(*d, st);
 }

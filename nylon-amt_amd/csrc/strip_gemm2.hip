@@ -1,0 +1,677 @@
+// Strip kernels, persistent software-pipelined form ("v2").  Same contract, operand layouts and arithmetic as csrc/strip_gemm.hip
+// (which stays as the general form: fp32 storage, gates, K = 128, ragged M); what changes is WHEN memory moves.
+//
+// Why.  In the one-block-per-workgroup form every workgroup runs load -> MFMA -> store, all workgroups of the chip do so in lockstep
+// (in-kernel clock stamps, tools/stamp_strip.py: x-load burst 16k cycles at the HBM limit, MFMA 16k cycles with HBM idle, store burst
+// 10k cycles at the HBM limit, per pass), and contention re-synchronises any stagger: HBM is busy 46 % of the time, the matrix pipe
+// 24 %.  Here one workgroup per CU (4 waves, one per SIMD, up to 512 registers) walks many 128-token blocks and keeps memory traffic
+// flat: while block b is multiplied, the activations of block b+1 are prefetched into a second register set and the results of the
+// previous pass are stored -- a fixed few loads and stores per ring slot, in between the MFMAs.
+//
+// Bookkeeping.  The ring fills (LDS-DMA) and the stores are issued from inline asm, the prefetch loads are ordinary 16-byte loads (one
+// global_load_dwordx4 each).  `issued` counts all of them, a mark is taken for each ring fill, and s_waitcnt vmcnt(issued - mark)
+// retires that fill (vmcnt retires in issue order).  Only the wait + barrier at the top of a slot carries a memory clobber: inside
+// a slot the fill pieces and stores carry none, so the LDS fragment reads are free to be scheduled across them -- and so are the
+// slot's prefetch loads, which is why a fill's mark is taken at the END of its slot's region (everything in the region counts as
+// older than the fill: stricter, never weaker).  An instruction the kernel does not count (the two statistics stores, a scratch
+// access) can likewise only make a wait stricter.  The prefetch loads are NOT asm: a register with an asm load in flight is just a register to the
+// allocator, and under pressure it copied / reused such registers before the data had landed (garbage operands, and a memory fault
+// where the reused register held an address).  hipcc's own wait for them is coarser than needed (it cannot see the asm operations
+// in flight and waits for those too), which costs about one DMA latency per block.
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+#include "hftt_common.h"
+#include "hftt_host.h"
+#include "strip_internal.h"
+#include "../../include/hftt_hip.h"
+
+namespace {
+
+constexpr int SLOT_BYTES = 16384;
+constexpr int NSLOT = 4;
+constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
+constexpr int FILL_AHEAD = NSLOT - 1;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a compile-time constant in every iteration.
+// (#pragma unroll on the slot loops was only honoured by a factor of four here -- the prefetch register arrays then had a run-time
+// index and went to scratch memory.)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// 16 bytes in four VGPRs as a native vector (HIP's uint4 is a struct: inline-asm operands of struct type go through memory)
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+// four LDS-DMA instructions (16 B per lane each): sources gsrc + {0, 1, 2, 3} KiB, LDS destinations lds_dst + {0, 1, 2, 3} KiB (+ 16 * lane).
+// The instruction offset advances BOTH addresses (LDS address = M0 + offset + 16 * lane; measured: adding it to M0 as well put the
+// fragments 1 KiB too far).  M0 (compiler-reserved) is saved once and restored once in the same statement.
+__device__ __forceinline__ void glds16x4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst));
+}
+// prefetch load: an ordinary 16-byte load (exactly one global_load_dwordx4), counted by the caller
+__device__ __forceinline__ void pload16(u4v& dst, const void* p) { dst = *reinterpret_cast<const u4v*>(p); }
+// store from asm (no destination registers: nothing the allocator could get wrong), counted by the caller
+__device__ __forceinline__ void astore16(void* p, const u4v& v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v)); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// s_waitcnt vmcnt(k) for a wave-uniform run-time n, with k = the largest value of a 16-entry grid that is <= n (waiting for a few
+// more operations than necessary is always safe).  The immediate must be static, so this is a depth-4 branch tree; the plain
+// 64-way switch it replaces was lowered to a chain of 64 compare-and-branch pairs, ~1,000 cycles per slot.
+#define HFTT_WAITVM(k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  if (n < 16) {
+    if (n < 8) {
+      if (n < 4) { if (n < 2) HFTT_WAITVM(0); else HFTT_WAITVM(2); }
+      else { if (n < 6) HFTT_WAITVM(4); else HFTT_WAITVM(6); }
+    } else {
+      if (n < 12) { if (n < 10) HFTT_WAITVM(8); else HFTT_WAITVM(10); }
+      else { if (n < 14) HFTT_WAITVM(12); else HFTT_WAITVM(14); }
+    }
+  } else {
+    if (n < 32) {
+      if (n < 24) { if (n < 20) HFTT_WAITVM(16); else HFTT_WAITVM(20); }
+      else { if (n < 28) HFTT_WAITVM(24); else HFTT_WAITVM(28); }
+    } else {
+      if (n < 48) { if (n < 40) HFTT_WAITVM(32); else HFTT_WAITVM(40); }
+      else { if (n < 63) HFTT_WAITVM(48); else HFTT_WAITVM(63); }
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  const f2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2_t));
+}
+__device__ __forceinline__ u4v pack8u(const float* v) {
+  u4v o;
+  o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+  return o;
+}
+__device__ __forceinline__ void unpack8(u4v q, float* v) {
+  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xFFFF0000u);
+  v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xFFFF0000u);
+  v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ void lds16f(const float* p, float* v) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const float4 t = reinterpret_cast<const float4*>(p)[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+}
+__device__ __forceinline__ void drop16(float* v, uint64_t seed, uint32_t site, uint64_t q0, uint32_t thr, float inv_keep) {
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const uint32_t w = hftt_hash(seed, site, q0 + e);
+    uint32_t m0, m1;                                  // sign of (field - thr) as a mask (see strip_gemm.hip: no SGPR pair per decision)
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m0) : "v"((w & 0xFFFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m1) : "v"((w >> 16) - thr));
+    v[2 * e] = __uint_as_float(__float_as_uint(v[2 * e] * inv_keep) & m0);
+    v[2 * e + 1] = __uint_as_float(__float_as_uint(v[2 * e + 1] * inv_keep) & m1);
+  }
+}
+__device__ __forceinline__ bf16x8 as_frag(const u4v& u) { return __builtin_bit_cast(bf16x8, u); }
+
+// per-wave pipeline state: the ring and the count of vector-memory instructions issued from asm
+struct Pipe {
+  const unsigned short* w;      // strip-packed weight stream of ONE block (S slots)
+  int S;                        // slots per block
+  long fill_left;               // slots this workgroup still has to fetch (its blocks x S at the start)
+  int fill_pos;                 // stream position (0 .. S-1) of the next slot to fetch
+  unsigned ring;
+  int wave, lane;
+  int issued;                   // asm-issued vector-memory instructions so far
+  int fill_mark[NSLOT];
+
+  // fetch the next slot of the stream into ring buffer BUF (static: slot number % NSLOT); wave w moves fragments 4w .. 4w+3
+  template <int BUF>
+  __device__ __forceinline__ void fill() {
+    if (fill_left <= 0) return;
+    const unsigned short* src = w + ((long)fill_pos * 16 + wave * 4) * 512 + lane * 8;
+    const unsigned dst = ring + (unsigned)BUF * SLOT_BYTES + (unsigned)wave * 4096u;
+    glds16x4(src, dst);
+    issued += 4;
+    fill_mark[BUF] = issued;
+    fill_left--;
+    fill_pos = (fill_pos + 1 == S) ? 0 : fill_pos + 1;
+  }
+  // top of slot BUF: its DMA has landed in every wave and the buffer consumed one slot ago is free; the refill of that buffer is then
+  // issued in four pieces between the slot's MFMA groups (fill_piece), and fill_close takes the mark
+  bool filling, closing;
+  bool nobar;                   // timing experiments only (HFTT_STRIP2_DEBUG bit 1; bit 0 drops the ring fills): results are garbage
+  const unsigned short* fsrc;
+  template <int BUF>
+  __device__ __forceinline__ void begin_slot() {
+    // The refill issued during the previous slot gets its mark HERE, at the end of that slot's region: every operation of the region
+    // (prefetch loads float inside it, between the memory-clobbering waits) then counts as older than the refill -- the wait can only
+    // be stricter than necessary, never weaker.
+    if (closing) {
+      fill_mark[(BUF + FILL_AHEAD - 1) & (NSLOT - 1)] = issued;      // previous slot = BUF - 1, its refill went to (BUF - 1 + 3) % 4
+      closing = false;
+    }
+    // steady state: the two regions since the mark issued at least a 4-piece refill each, so vmcnt(8) is never weaker than
+    // vmcnt(n); the branch tree is for the tail of the stream only (no more refills, n shrinks)
+    const int n = issued - fill_mark[BUF];
+    if (n >= 8) HFTT_WAITVM(8); else wait_vmcnt_dyn(n > 0 ? n : 0);
+    if (!nobar) __builtin_amdgcn_s_barrier();
+    filling = fill_left > 0;
+    fsrc = w + ((long)fill_pos * 16 + wave * 4) * 512 + lane * 8;
+  }
+  template <int BUF, int I>
+  __device__ __forceinline__ void fill_piece() {      // BUF: the slot being consumed; the refill goes to (BUF + 3) % 4 (all four pieces at I == 0)
+    if (I == 0 && filling) {
+      glds16x4(fsrc, ring + (unsigned)((BUF + FILL_AHEAD) & (NSLOT - 1)) * SLOT_BYTES + (unsigned)wave * 4096u);
+      issued += 4;
+    }
+  }
+  template <int BUF>
+  __device__ __forceinline__ void fill_close() {
+    if (filling) {
+      closing = true;
+      fill_left--;
+      fill_pos = (fill_pos + 1 == S) ? 0 : fill_pos + 1;
+    }
+  }
+};
+
+// The 16 weight fragments of a slot -> 16 MFMAs.  With ONE wave per SIMD nobody else covers an LDS round trip, and left alone hipcc
+// keeps only one or two ds_read_b128 in flight (~120 cycles per MFMA instead of 32).  The group barriers pin the shape: six reads
+// up front, then one read behind every MFMA, so each fragment is requested ~6 MFMAs (~190 cycles) before it is consumed.
+template <typename F>
+__device__ __forceinline__ void slot_mfmas(const unsigned char* slot, F&& mfma_i) {
+  bf16x8 fr[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) fr[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
+#pragma unroll
+  for (int i = 0; i < 16; i++) mfma_i(i, fr[i]);
+  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+}
+
+// element offset (inside the lane's 16-feature-per-tile row view) of load / store piece i = 0..15: tile (i >> 1), 8-element half (i & 1)
+__device__ __forceinline__ long piece_off(int i) { return (long)(i >> 1) * 32 + (i & 1) * 8; }
+
+// LayerNorm over the 256 features of the lane's token (lane: 128 of them in acc, partner lane ^ 32 the rest); the normalised row goes to
+// emit(tile, first half, second half) (deferred or immediate stores), the pre-LayerNorm sum (training) is stored at once
+template <typename F, typename E>
+__device__ __forceinline__ void ln_rows(f32x16 (&acc)[8], const float* gamma_lds, const float* beta_lds, int h,
+                                        float* mean_out, float* rstd_out, long tok, bool wave_ok, bool has_pre, unsigned short* pre_row, F&& count_issue, E&& emit) {
+  float s = 0.f;
+#pragma unroll
+  for (int ot = 0; ot < 8; ot++)
+#pragma unroll
+    for (int q = 0; q < 16; q++) s += acc[ot][q];
+  const float mean = xor32_sum(s) * (1.0f / 256.0f);
+  float qs = 0.f;
+#pragma unroll
+  for (int ot = 0; ot < 8; ot++)
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const float dlt = acc[ot][q] - mean; qs += dlt * dlt; }
+  const float rstd = 1.0f / sqrtf(xor32_sum(qs) * (1.0f / 256.0f) + 1e-5f);
+  if (wave_ok && h == 0) {
+    if (mean_out != nullptr) mean_out[tok] = mean;
+    if (rstd_out != nullptr) rstd_out[tok] = rstd;
+  }
+#pragma unroll
+  for (int ot = 0; ot < 8; ot++) {
+    float v[16], ga[16], be[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = acc[ot][q];
+    if (has_pre && wave_ok) {                       // (both wave-uniform: the issue count stays a scalar)
+      const u4v a = pack8u(v), b = pack8u(v + 8);
+      astore16(pre_row + piece_off(2 * ot), a);
+      astore16(pre_row + piece_off(2 * ot + 1), b);
+      count_issue(2);
+    }
+    lds16f(gamma_lds + ot * 32 + 16 * h, ga);
+    lds16f(beta_lds + ot * 32 + 16 * h, be);
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = (v[q] - mean) * rstd * ga[q] + be[q];
+    emit(ot, pack8u(v), pack8u(v + 8));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C = epi(x . Wl^T + bias), all tensors bf16, K % 256 == 0, N % 256 == 0; LN: N == 256 with dropout / residual / LayerNorm
+// ---------------------------------------------------------------------------------------------------------------------
+// PASSES = N / 256, KCH = K / 256 are template parameters: with run-time trip counts the allocator shuffled whole register sets
+// through scratch at the step boundaries (152 spilled registers in the plain form).
+template <bool LN, int PASSES, int KCH>
+__global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_desc g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  constexpr int passes = PASSES;
+  constexpr int steps = passes * KCH;               // 8-slot steps per block
+  const long nblk = ((long)g.M + 127) / 128;
+  const long my_blocks = (nblk - (long)blockIdx.x + gridDim.x - 1) / gridDim.x;
+  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // bias[N] | gamma[256] | beta[256]
+  const unsigned short* xb = reinterpret_cast<const unsigned short*>(g.x);
+  unsigned short* cb = reinterpret_cast<unsigned short*>(g.C);
+  unsigned short* preb = reinterpret_cast<unsigned short*>(g.pre_ln_out);
+  const unsigned short* rb = reinterpret_cast<const unsigned short*>(g.residual);
+  const bool relu = g.flags & HFTT_SL_RELU;
+  const bool has_res = g.residual != nullptr;
+
+  Pipe P;
+  P.w = g.w; P.S = steps * 8; P.fill_left = (g.pad & 1) ? 0 : my_blocks * P.S; P.fill_pos = 0; P.nobar = g.pad & 2; P.closing = false;
+  P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
+  P.wave = wave; P.lane = lane; P.issued = 0;
+#pragma unroll
+  for (int i = 0; i < NSLOT; i++) P.fill_mark[i] = 0;
+
+  auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
+
+  // ---- prologue: parameters to LDS (compiler loads), first block's activations, first ring slots
+  for (int i = tid; i < g.N; i += 256) prm[i] = g.bias != nullptr ? g.bias[i] : 0.f;
+  if (LN) { prm[g.N + tid] = g.ln_gamma[tid]; prm[g.N + 256 + tid] = g.ln_beta[tid]; }
+  // xf: this step's activations.  xn: the next step's, in flight.  pend: results of the last finished pass waiting to be stored, two
+  // pieces per slot; once a piece is on its way its registers receive the residual rows the NEXT epilogue needs (one set for both).
+  u4v xf[16], xn[16], pend[16];
+  {
+    const unsigned short* p0 = xb + tok_of(blockIdx.x) * g.ldx + 16 * h;
+#pragma unroll
+    for (int i = 0; i < 16; i++) pload16(xn[i], p0 + piece_off(i));
+    P.issued += 16;
+  }
+  P.fill<0>(); P.fill<1>(); P.fill<2>();
+  static_assert(FILL_AHEAD == 3, "prologue fills");
+  wait_lgkm0();
+
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const unsigned char* abase = smem + lane * 16;
+  unsigned short* pend_ptr = cb;                    // where the deferred results go (meaningful while pend_valid)
+  bool pend_valid = false;
+
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int hb = h;                                       // opaque per iteration: column arithmetic that only depends on (h, tile) is
+    asm volatile("" : "+v"(hb));                      // otherwise hoisted out of this loop and kept live in dozens of registers
+    const long tok = blk * 128 + wave * 32 + j;
+    const bool wave_ok = (blk * 128 + wave * 32) < g.M;          // M % 32 == 0 (host check): a wave is all-valid or all-invalid
+    const long tokc = tok_of(blk);
+    const long nxt = blk + gridDim.x;
+    const bool has_next = nxt < nblk;
+    const unsigned short* xrow_next = xb + (has_next ? tok_of(nxt) : tokc) * g.ldx + 16 * hb;
+    const long rrow = g.res_mod > 0 ? (long)((unsigned)tokc % (unsigned)g.res_mod) : tokc;
+    // The parameter rows in LDS do not change from block to block, so LICM would hoist every read of them out of this loop and keep
+    // hundreds of values live across it (spills).  An opaque zero added to the address pins the reads inside the iteration.
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    const float* prm_b = prm + zero;
+    for (int pass = 0; pass < passes; pass++) {
+      f32x16 acc[8];
+#pragma unroll
+      for (int ot = 0; ot < 8; ot++) {                // accumulators start from the bias
+        float b[16];
+        lds16f(prm_b + pass * 256 + ot * 32 + 16 * hb, b);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[ot][q] = b[q];
+      }
+      for (int kc = 0; kc < KCH; kc++) {
+        if (KCH > 1 || pass == 0) {                   // this step's activations: prefetched during the previous step (or the prologue)
+#pragma unroll
+          for (int i = 0; i < 16; i++) xf[i] = xn[i];
+        }
+        const bool last_step = (pass == passes - 1) && (kc == KCH - 1);
+        const bool pf_x = (KCH > 1) ? (!last_step || has_next) : (last_step && has_next);
+        const unsigned short* pf_src = (KCH > 1 && !last_step) ? (xb + tokc * g.ldx + (kc + 1 == KCH ? 0 : kc + 1) * 256 + 16 * hb) : xrow_next;
+        const bool pf_res = has_res && (kc == KCH - 1);
+        const unsigned short* res_src = rb + (has_res ? rrow * g.ldr + pass * 256 + 16 * hb : 0);
+        static_for<8>([&](auto pt_c) __attribute__((always_inline)) {
+          constexpr int pt = decltype(pt_c)::value;
+          constexpr int BUF = pt & 3;
+          P.template begin_slot<BUF>();
+          const unsigned char* slot = abase + BUF * SLOT_BYTES;
+          // fragment i = u * 8 + tile; the ring refill (four pieces) and the slot's share of the block's memory traffic ride along
+          slot_mfmas(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { acc[i & 7] = mfma32(a, as_frag(xf[2 * pt + (i >> 3)]), acc[i & 7]); });
+          static_for<4>([&](auto q_c) __attribute__((always_inline)) {
+            constexpr int q = decltype(q_c)::value;
+            P.template fill_piece<BUF, q>();
+            if (q < 2) {
+              if (pf_x) { pload16(xn[2 * pt + q], pf_src + piece_off(2 * pt + q)); P.issued += 1; }
+            } else {
+              constexpr int i = 2 * pt + (q - 2);
+              if (pend_valid) { astore16(pend_ptr + piece_off(i), pend[i]); P.issued += 1; }
+              if (pf_res) { pload16(pend[i], res_src + piece_off(i)); P.issued += 1; }      // (behind the store of the same registers)
+            }
+          });
+          P.template fill_close<BUF>();
+          if (pt == 7) pend_valid = false;
+        });
+      }
+      // ---------------- epilogue of this pass: results into the pending registers ----------------
+            const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 1;
+#pragma unroll
+      for (int ot = 0; ot < 8; ot++) {
+        const int col0 = pass * 256 + ot * 32 + 16 * hb;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          float t = acc[ot][q];
+          if (!LN && relu) t = fmaxf(t, 0.f);
+          v[q] = t * g.out_scale;
+        }
+        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 1), thr, inv_keep);
+        if (has_res) {
+          float r[16];
+          unpack8(pend[2 * ot], r); unpack8(pend[2 * ot + 1], r + 8);
+#pragma unroll
+          for (int q = 0; q < 16; q++) v[q] += r[q];
+        }
+        if (LN) {
+#pragma unroll
+          for (int q = 0; q < 16; q++) acc[ot][q] = v[q];
+        } else {
+          pend[2 * ot] = pack8u(v);
+          pend[2 * ot + 1] = pack8u(v + 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (LN) {
+        ln_rows(acc, prm_b + g.N, prm_b + g.N + 256, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, g.pre_ln_out != nullptr,
+                preb + tok * g.ldc + 16 * hb, [&](int n) { P.issued += n; },
+                [&](int ot, u4v a, u4v b) __attribute__((always_inline)) { pend[2 * ot] = a; pend[2 * ot + 1] = b; });
+      }
+      pend_ptr = cb + tok * g.ldc + pass * 256 + 16 * hb;
+      pend_valid = wave_ok;
+    }
+  }
+  if (pend_valid) {                                   // drain: the last pass's results
+#pragma unroll
+    for (int i = 0; i < 16; i++) astore16(pend_ptr + piece_off(i), pend[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fused two-GEMM block, d = 256, p = 32 * PT: mode 0 = FFN forward + residual + LayerNorm, mode 1 = dX half of its backward
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE, int PT>
+__global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc g) {
+  static_assert(PT % 4 == 0, "the gate prefetch ring and the slot buffers assume PT % 4 == 0");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  constexpr int p = PT * 32;
+  const long nblk = ((long)g.M + 127) / 128;
+  const long my_blocks = (nblk - (long)blockIdx.x + gridDim.x - 1) / gridDim.x;
+  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // b1[p] | b2[256] | gamma[256] | beta[256]
+  const unsigned short* xb = reinterpret_cast<const unsigned short*>(g.x);
+  unsigned short* yb = reinterpret_cast<unsigned short*>(g.y);
+  unsigned short* preb = reinterpret_cast<unsigned short*>(g.pre_ln_out);
+  const unsigned short* rb = reinterpret_cast<const unsigned short*>(g.residual);
+  const bool has_res = (MODE == 1) && g.residual != nullptr;
+
+  Pipe P;
+  P.w = g.w; P.S = 2 * PT; P.fill_left = (g.pad & 1) ? 0 : my_blocks * P.S; P.fill_pos = 0; P.nobar = g.pad & 2; P.closing = false;
+  P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
+  P.wave = wave; P.lane = lane; P.issued = 0;
+#pragma unroll
+  for (int i = 0; i < NSLOT; i++) P.fill_mark[i] = 0;
+
+  auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
+
+  for (int i = tid; i < p; i += 256) prm[i] = (MODE == 0 && g.b1 != nullptr) ? g.b1[i] : 0.f;
+  prm[p + tid] = (MODE == 0 && g.b2 != nullptr) ? g.b2[tid] : 0.f;
+  if (MODE == 0) { prm[p + 256 + tid] = g.ln_gamma[tid]; prm[p + 512 + tid] = g.ln_beta[tid]; }
+
+  // xf: the block's activations; after the last first-GEMM of the block (mode 1) its registers receive the residual rows of the final
+  // epilogue.  xn: the next block's activations, one piece per hidden tile.  Results are stored from the epilogue directly: with 16
+  // hidden-tile stores already spread over the block, a deferred set on top overflowed the register file (73-95 spills, and a spill
+  // of a register with a load in flight is a wrong answer, not a slow one).
+  u4v xf[16], xn[16];
+  u4v gt[4][2];                                     // mode 1: stored hidden (the gate) of tiles t .. t+2, ring of four
+  {
+    const long t0 = tok_of(blockIdx.x);
+    const unsigned short* p0 = xb + t0 * g.ldx + 16 * h;
+#pragma unroll
+    for (int i = 0; i < 16; i++) pload16(xn[i], p0 + piece_off(i));
+    P.issued += 16;
+    if (MODE == 1) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const unsigned short* gp = g.gate + t0 * g.ldg + t * 32 + 16 * h;
+        pload16(gt[t][0], gp); pload16(gt[t][1], gp + 8);
+        P.issued += 2;
+      }
+    }
+  }
+  P.fill<0>(); P.fill<1>(); P.fill<2>();
+  static_assert(FILL_AHEAD == 3, "prologue fills");
+  wait_lgkm0();
+
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const unsigned char* abase = smem + lane * 16;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int hb = h;                                       // (opaque per iteration: see strip_linear2_kernel)
+    asm volatile("" : "+v"(hb));
+    const long tok = blk * 128 + wave * 32 + j;
+    const bool wave_ok = (blk * 128 + wave * 32) < g.M;
+    const long tokc = tok_of(blk);
+    const long nxt = blk + gridDim.x;
+    const bool has_next = nxt < nblk;
+    const long tokn = has_next ? tok_of(nxt) : tokc;
+    const unsigned short* xrow_next = xb + tokn * g.ldx + 16 * hb;
+    const unsigned short* res_src = rb + (has_res ? tokc * g.ldr + 16 * hb : 0);
+    const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)p) >> 1;
+    int zero = 0;                                     // (keeps the LDS parameter reads inside the iteration: see strip_linear2_kernel)
+    asm volatile("" : "+s"(zero));
+    const float* prm_b = prm + zero;
+#pragma unroll
+    for (int i = 0; i < 16; i++) xf[i] = xn[i];
+
+    f32x16 yacc[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ot++) {
+      float b[16];
+      lds16f(prm_b + p + ot * 32 + 16 * hb, b);
+#pragma unroll
+      for (int q = 0; q < 16; q++) yacc[ot][q] = b[q];
+    }
+
+    static_for<PT>([&](auto t_c) __attribute__((always_inline)) {
+      constexpr int t = decltype(t_c)::value;
+      // ---- first GEMM, hidden tile t ----
+      constexpr int BA = (2 * t) & 3, BB = (2 * t + 1) & 3;
+      const bool stamp = MODE == 0 && (g.pad & 4) && (t == 4 || t == 5) && blk == (long)blockIdx.x + gridDim.x && tid == 0;
+      unsigned long long* sb = reinterpret_cast<unsigned long long*>(const_cast<unsigned short*>(g.gate)) + (long)blockIdx.x * 16 + (t - 4) * 8;
+      if (stamp) sb[0] = __builtin_amdgcn_s_memtime();
+      P.template begin_slot<BA>();
+      if (stamp) sb[1] = __builtin_amdgcn_s_memtime();
+      f32x16 hacc;
+      {
+        float b[16];
+        lds16f(prm_b + t * 32 + 16 * hb, b);
+#pragma unroll
+        for (int q = 0; q < 16; q++) hacc[q] = b[q];
+      }
+      {
+        const unsigned char* slot = abase + BA * SLOT_BYTES;
+        const bool in_blk = (t + 2) < PT;             // mode 1: gate of tile t + 2 (of the next block past the end)
+        const unsigned short* gp = (MODE == 1) ? g.gate + (in_blk ? tokc : tokn) * g.ldg + ((t + 2) % PT) * 32 + 16 * hb : nullptr;
+        slot_mfmas(slot, [&](int f, bf16x8 a) __attribute__((always_inline)) { hacc = mfma32(a, as_frag(xf[f]), hacc); });    // fragment f = 2 * pt + u
+        static_for<4>([&](auto q_c) __attribute__((always_inline)) {
+          constexpr int q = decltype(q_c)::value;
+          P.template fill_piece<BA, q>();
+          if (q == 0) {
+            if (has_next) { pload16(xn[t], xrow_next + piece_off(t)); P.issued += 1; }      // one piece of the next block's activations per tile
+          } else if (q < 3) {
+            if (MODE == 1 && (in_blk || has_next)) { pload16(gt[(t + 2) & 3][q - 1], gp + 8 * (q - 1)); P.issued += 1; }
+          }
+        });
+        P.template fill_close<BA>();
+      }
+      if (stamp) sb[2] = __builtin_amdgcn_s_memtime();
+      if (t == PT - 1 && has_res) {                   // xf has fed its last MFMA of the block: fetch the residual rows into it
+#pragma unroll
+        for (int i = 0; i < 16; i++) pload16(xf[i], res_src + piece_off(i));
+        P.issued += 16;
+      }
+      // ---- middle epilogue: the lane's 16 hidden features of tile t become the B operand of the second GEMM ----
+      float v[16];
+      const int hcol0 = t * 32 + 16 * hb;
+      if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = fmaxf(hacc[q], 0.f);
+        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 1), thr, inv_keep);
+      } else {
+        float gv[16];
+        unpack8(gt[t & 3][0], gv); unpack8(gt[t & 3][1], gv + 8);
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = gv[q] > 0.f ? hacc[q] * g.gate_scale : 0.f;
+      }
+      u4v hf[2];
+      hf[0] = pack8u(v); hf[1] = pack8u(v + 8);
+      // ---- second GEMM, K-slice t; the hidden tile's two stores ride behind its first two MFMA groups ----
+      if (stamp) sb[3] = __builtin_amdgcn_s_memtime();
+      P.template begin_slot<BB>();
+      if (stamp) sb[4] = __builtin_amdgcn_s_memtime();
+      {
+        const unsigned char* slot = abase + BB * SLOT_BYTES;
+        const bool st_h = g.h_out != nullptr && wave_ok;
+        unsigned short* hp = g.h_out + tok * g.ldh + hcol0;
+        slot_mfmas(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { yacc[i & 7] = mfma32(a, as_frag(hf[i >> 3]), yacc[i & 7]); });
+        static_for<4>([&](auto q_c) __attribute__((always_inline)) {
+          constexpr int q = decltype(q_c)::value;
+          P.template fill_piece<BB, q>();
+          if (q < 2 && st_h) { astore16(hp + 8 * q, hf[q]); P.issued += 1; }
+        });
+        P.template fill_close<BB>();
+      }
+      if (stamp) sb[5] = __builtin_amdgcn_s_memtime();
+    });
+
+    // ---------------- final epilogue of the block ----------------
+        const uint64_t rowq = ((uint64_t)tok * 256ull) >> 1;
+    unsigned short* yrow = yb + tok * g.ldy + 16 * hb;
+#pragma unroll
+    for (int ot = 0; ot < 8; ot++) {
+      const int col0 = ot * 32 + 16 * hb;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) v[q] = yacc[ot][q];
+      if (MODE == 0 && g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_o, rowq + (col0 >> 1), thr, inv_keep);
+      float r[16];
+      if (MODE == 0 || has_res) {                     // mode 0: residual = the block input, still in xf; mode 1: just fetched into xf
+        unpack8(xf[2 * ot], r); unpack8(xf[2 * ot + 1], r + 8);
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] += r[q];
+      }
+      if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) yacc[ot][q] = v[q];
+      } else if (wave_ok) {
+        astore16(yrow + piece_off(2 * ot), pack8u(v));
+        astore16(yrow + piece_off(2 * ot + 1), pack8u(v + 8));
+        P.issued += 2;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 0) {
+      ln_rows(yacc, prm_b + p + 256, prm_b + p + 512, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, g.pre_ln_out != nullptr,
+              preb + tok * g.ldy + 16 * hb, [&](int n) { P.issued += n; },
+              [&](int ot, u4v a, u4v b) __attribute__((always_inline)) {
+                if (wave_ok) { astore16(yrow + piece_off(2 * ot), a); astore16(yrow + piece_off(2 * ot + 1), b); P.issued += 2; }
+              });
+    }
+  }
+}
+
+int n_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    n = prop.multiProcessorCount;
+  }
+  return n;
+}
+bool v2_enabled() {
+  const char* e = getenv("HFTT_STRIP_V2");
+  return !(e && e[0] == '0');
+}
+template <typename K>
+int set_lds(K kernel, int lds, const char* what) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) { hftt_set_error("%s: hipFuncSetAttribute(%d B LDS) failed: %s", what, lds, hipGetErrorString(e)); return 2; }
+  return 0;
+}
+template <bool LN, int PASSES, int KCH>
+int launch_linear2(const hftt_strip_desc& d, hipStream_t st) {
+  const int lds = RING_BYTES + 4 * (d.N + 512);
+  static int attr = 0;
+  if (lds > attr) { if (int rc = set_lds(strip_linear2_kernel<LN, PASSES, KCH>, lds, "strip_linear2")) return rc; attr = lds; }
+  const int cus = n_cus();
+  if (cus <= 0) { hftt_set_error("strip_linear2: device query failed"); return 2; }
+  const long nblk = ((long)d.M + 127) / 128;
+  hipLaunchKernelGGL((strip_linear2_kernel<LN, PASSES, KCH>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  HFTT_CHECK_LAUNCH("strip_linear2");
+  return 0;
+}
+template <int MODE>
+int launch_mlp2(const hftt_ffn_desc& d, hipStream_t st) {
+  const int lds = RING_BYTES + 4 * (d.p + 768);
+  static int attr = 0;
+  if (lds > attr) { if (int rc = set_lds(strip_mlp2_kernel<MODE, 16>, lds, "strip_mlp2")) return rc; attr = lds; }
+  const int cus = n_cus();
+  if (cus <= 0) { hftt_set_error("strip_mlp2: device query failed"); return 2; }
+  const long nblk = ((long)d.M + 127) / 128;
+  hipLaunchKernelGGL((strip_mlp2_kernel<MODE, 16>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  HFTT_CHECK_LAUNCH("strip_mlp2");
+  return 0;
+}
+
+}  // namespace
+
+// -1: this shape / storage is not covered by the pipelined form (the caller launches the general kernel); otherwise the launch status
+static int strip2_debug() { const char* e = getenv("HFTT_STRIP2_DEBUG"); return e ? atoi(e) : 0; }
+
+int hftt_strip_linear2_try(const hftt_strip_desc& d0, hipStream_t st) {
+  hftt_strip_desc d = d0;
+  d.pad = strip2_debug();
+  const uint32_t bf = HFTT_SL_X_BF16 | HFTT_SL_C_BF16;
+  if (!v2_enabled() || (d.flags & bf) != bf || d.K % 256 != 0 || d.M % 32 != 0 || d.gate != nullptr) return -1;
+  if (d.residual != nullptr && !(d.flags & HFTT_SL_RES_BF16)) return -1;
+  const int passes = d.N / 256, kch = d.K / 256;
+  if (d.ln_gamma != nullptr) {
+    if (kch == 1) return launch_linear2<true, 1, 1>(d, st);
+    if (kch == 2) return launch_linear2<true, 1, 2>(d, st);
+    if (kch == 3) return launch_linear2<true, 1, 3>(d, st);
+    return -1;
+  }
+  // the shapes of the model: QKV (3 passes), cross K/V (2), single projections and the dX forms with K = 256 / 512 / 768
+  if (kch == 1 && passes == 1) return launch_linear2<false, 1, 1>(d, st);
+  if (kch == 1 && passes == 2) return launch_linear2<false, 2, 1>(d, st);
+  if (kch == 1 && passes == 3) return launch_linear2<false, 3, 1>(d, st);
+  if (kch == 2 && passes == 1) return launch_linear2<false, 1, 2>(d, st);
+  if (kch == 3 && passes == 1) return launch_linear2<false, 1, 3>(d, st);
+  return -1;
+}
+int hftt_strip_mlp2_try(const hftt_ffn_desc& d0, hipStream_t st) {
+  hftt_ffn_desc d = d0;
+  d.pad = strip2_debug();
+  if (!v2_enabled() || d.p != 512 || d.M % 32 != 0) return -1;
+  if (d.mode == 0 && d.residual != nullptr) return -1;
+  return d.mode == 0 ? launch_mlp2<0>(d, st) : launch_mlp2<1>(d, st);
+}

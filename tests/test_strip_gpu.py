@@ -182,3 +182,66 @@ def test_fused_ffn_backward_dx(dev, M, pf):
     assert rel_err(dh, dh_ref) < 6e-3
     dx_ref = bfr(dh_ref) @ bfr(W1) + bfr(res)
     assert rel_err(dx, dx_ref) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# persistent software-pipelined form (csrc/strip_gemm2.hip): taken automatically for all-bf16 descriptors with M % 32 == 0 and
+# K % 256 == 0; HFTT_STRIP_V2=0 forces the one-block-per-workgroup kernels.  Same operand order, same epilogue arithmetic ->
+# the two forms must agree BIT FOR BIT, also when a workgroup walks several blocks and when the last block is ragged.
+# ---------------------------------------------------------------------------------------------------------------------
+def _both_forms(monkeypatch, fn):
+    monkeypatch.setenv('HFTT_STRIP_V2', '0')
+    a = fn()
+    monkeypatch.setenv('HFTT_STRIP_V2', '1')
+    b = fn()
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize('M', [128, 4096, 38432, 70016])
+def test_pipelined_linear_is_bit_identical(dev, monkeypatch, M):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M)
+    d = 256
+    x = torch.randn(M, d, generator=g).to(dev).to(BF)
+    Wq = (torch.randn(3 * d, d, generator=g) / 16).to(dev); bq = torch.randn(3 * d, generator=g).to(dev)
+    res = torch.randn(M, d, generator=g).to(dev).to(BF)
+    gam = (1 + 0.3 * torch.randn(d, generator=g)).to(dev); bet = torch.randn(d, generator=g).to(dev)
+    wq = ops.strip_pack(Wq); wqt = ops.strip_pack(Wq, transpose=True); wo = ops.strip_pack(Wq[:d].contiguous())
+    dq = torch.randn(M, 3 * d, generator=g).to(dev).to(BF)
+    # QKV projection (three passes), its dX (K = 768 in three chunks, + residual), fc_o + dropout + residual + LayerNorm
+    a, b = _both_forms(monkeypatch, lambda: ops.strip_linear(x, wq, 3 * d, bias=bq))
+    assert torch.equal(a, b)
+    ref = bfr(x.cpu().float()) @ bfr(Wq.cpu()).T + bq.cpu().double()
+    assert rel_err(b, ref) < 6e-3
+    a, b = _both_forms(monkeypatch, lambda: ops.strip_linear(dq, wqt, d, residual=res))
+    assert torch.equal(a, b)
+    a, b = _both_forms(monkeypatch, lambda: ops.strip_linear(x, wo, d, bias=bq[:d].contiguous(), drop_p=0.1, drop_site=3, drop_seed=11, residual=res,
+                                                             ln=(gam, bet)))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    a, b = _both_forms(monkeypatch, lambda: ops.strip_linear(x, wo, d, bias=bq[:d].contiguous(), residual=res, ln=(gam, bet), save_pre=False))
+    assert torch.equal(a[0], b[0])
+
+
+@pytest.mark.parametrize('M', [128, 4096, 38432])
+def test_pipelined_ffn_is_bit_identical(dev, monkeypatch, M):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + 1)
+    d, pf = 256, 512
+    x = torch.randn(M, d, generator=g).to(dev).to(BF)
+    W1 = (torch.randn(pf, d, generator=g) / 16).to(dev); b1 = (0.5 * torch.randn(pf, generator=g)).to(dev)
+    W2 = (torch.randn(d, pf, generator=g) / 22).to(dev); b2 = (0.5 * torch.randn(d, generator=g)).to(dev)
+    gam = (1 + 0.3 * torch.randn(d, generator=g)).to(dev); bet = torch.randn(d, generator=g).to(dev)
+    wf = ops.ffn_pack(W1, W2); wfb = ops.ffn_pack(W1, W2, backward=True)
+    for p_, save in ((0.1, True), (0.0, False)):
+        a, b = _both_forms(monkeypatch, lambda: ops.ffn_res_ln_fwd(x, wf, pf, b1, b2, gam, bet, drop_p=p_, site_h=4, site_o=5, seed=7,
+                                                                   save_hidden=save, save_pre=save))
+        for u, v in zip(a, b):
+            assert (u is None and v is None) or torch.equal(u, v)
+    hid = torch.relu(torch.randn(M, pf, generator=g)).to(dev).to(BF)
+    res = torch.randn(M, d, generator=g).to(dev).to(BF)
+    a, b = _both_forms(monkeypatch, lambda: ops.ffn_bwd_dx(x, wfb, pf, hid, gate_scale=1.0 / 0.9, residual=res))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a, b = _both_forms(monkeypatch, lambda: ops.ffn_bwd_dx(x, wfb, pf, hid, gate_scale=1.0))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -33,6 +33,7 @@ def line(name, us, flops, nbytes):
 
 
 def main():
+    only_strip = len(sys.argv) > 1 and sys.argv[1] == 'strip'
     M = int(os.environ.get('M', 262144))
     d, p = 256, 512
     g = torch.Generator().manual_seed(1)
@@ -48,14 +49,14 @@ def main():
     # ---- QKV projection ----
     wq_s = ops.strip_pack(Wq); wq_o = ops.prepare_weight(Wq, 1)
     fl = 2.0 * M * 3 * d * d
-    line('qkv  old (x fp32 -> bf16)', timeit(lambda: ops.gemm_nt(x, Wq, bq, npass=1, planes=wq_o, out_dtype=BF)), fl, M * d * 4 + M * 3 * d * 2)
-    line('qkv  old (x bf16 -> bf16)', timeit(lambda: ops.gemm_nt(xb, Wq, bq, npass=1, planes=wq_o, out_dtype=BF)), fl, M * d * 2 + M * 3 * d * 2)
+    only_strip or line('qkv  old (x fp32 -> bf16)', timeit(lambda: ops.gemm_nt(x, Wq, bq, npass=1, planes=wq_o, out_dtype=BF)), fl, M * d * 4 + M * 3 * d * 2)
+    only_strip or line('qkv  old (x bf16 -> bf16)', timeit(lambda: ops.gemm_nt(xb, Wq, bq, npass=1, planes=wq_o, out_dtype=BF)), fl, M * d * 2 + M * 3 * d * 2)
     line('qkv  strip (x bf16 -> bf16)', timeit(lambda: ops.strip_linear(xb, wq_s, 3 * d, bias=bq)), fl, M * d * 2 + M * 3 * d * 2)
-    line('qkv  strip (x fp32 -> bf16)', timeit(lambda: ops.strip_linear(x, wq_s, 3 * d, bias=bq)), fl, M * d * 4 + M * 3 * d * 2)
+    only_strip or line('qkv  strip (x fp32 -> bf16)', timeit(lambda: ops.strip_linear(x, wq_s, 3 * d, bias=bq)), fl, M * d * 4 + M * 3 * d * 2)
     # ---- fc_o + dropout + residual + LayerNorm ----
     wo_s = ops.strip_pack(Wo); wo_o = ops.prepare_weight(Wo, 1)
     fl = 2.0 * M * d * d
-    line('o+LN old (ctx bf16, res/out/pre fp32)', timeit(lambda: ops.gemm_nt(xb, Wo, bo, npass=1, planes=wo_o, drop_p=0.1, drop_site=3, drop_seed=7, residual=res,
+    only_strip or line('o+LN old (ctx bf16, res/out/pre fp32)', timeit(lambda: ops.gemm_nt(xb, Wo, bo, npass=1, planes=wo_o, drop_p=0.1, drop_site=3, drop_seed=7, residual=res,
                                                                              ln=(gam, bet))), fl, M * d * (2 + 4 + 4 + 4))
     line('o+LN strip (all bf16, pre saved)', timeit(lambda: ops.strip_linear(xb, wo_s, d, bias=bo, drop_p=0.1, drop_site=3, drop_seed=7, residual=resb,
                                                                             ln=(gam, bet))), fl, M * d * 2 * 4)
@@ -68,7 +69,7 @@ def main():
     def old_ffn():
         h = ops.gemm_nt(x, W1, b1, npass=1, planes=w1_o, act=1, drop_p=0.1, drop_site=4, drop_seed=7, out_dtype=BF)
         return ops.gemm_nt(h, W2, b2, npass=1, planes=w2_o, drop_p=0.1, drop_site=5, drop_seed=7, residual=x, ln=(gam, bet))
-    line('ffn  old (2 launches, fp32 stream)', timeit(old_ffn), fl, M * d * 4 + M * p * 2 * 2 + M * d * 4 * 3)
+    only_strip or line('ffn  old (2 launches, fp32 stream)', timeit(old_ffn), fl, M * d * 4 + M * p * 2 * 2 + M * d * 4 * 3)
     line('ffn  fused training (h + pre saved, p=0.1)', timeit(lambda: ops.ffn_res_ln_fwd(xb, wf, p, b1, b2, gam, bet, drop_p=0.1, site_h=4, site_o=5, seed=7)),
          fl, M * d * 2 * 3 + M * p * 2)
     line('ffn  fused training (p=0)', timeit(lambda: ops.ffn_res_ln_fwd(xb, wf, p, b1, b2, gam, bet)), fl, M * d * 2 * 3 + M * p * 2)
@@ -83,7 +84,7 @@ def main():
     wqt_s = ops.strip_pack(Wq, transpose=True); wqt_o = ops.prepare_weight(Wq, 1, transposed=True)
     fl = 2.0 * M * 3 * d * d
     WqT = Wq.T.contiguous()
-    line('dqkv old (K=768, fp32 res/out)', timeit(lambda: ops.gemm_nt(dq, WqT, None, npass=1, planes=wqt_o, residual=res)), fl, M * 3 * d * 2 + M * d * 8)
+    only_strip or line('dqkv old (K=768, fp32 res/out)', timeit(lambda: ops.gemm_nt(dq, WqT, None, npass=1, planes=wqt_o, residual=res)), fl, M * 3 * d * 2 + M * d * 8)
     line('dqkv strip (K=768, bf16 res/out)', timeit(lambda: ops.strip_linear(dq, wqt_s, d, residual=resb)), fl, M * 3 * d * 2 + M * d * 4)
 
 
