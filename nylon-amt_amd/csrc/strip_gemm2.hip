@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   P.fill<0>(); P.fill<1>(); P.fill<2>();
   static_assert(FILL_AHEAD == 3, "prologue fills");
   wait_lgkm0();
+  __builtin_amdgcn_s_barrier();                       // the parameter rows in LDS are read (by every wave) before the first slot's barrier
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
   P.fill<0>(); P.fill<1>(); P.fill<2>();
   static_assert(FILL_AHEAD == 3, "prologue fills");
   wait_lgkm0();
+  __builtin_amdgcn_s_barrier();                       // the parameter rows in LDS are read (by every wave) before the first slot's barrier
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;

@@ -211,45 +211,47 @@ def test_dropout_training_mode(dev):
 
 def test_strip_kernels_match_the_round1_kernels_with_dropout_on(dev, monkeypatch):
     """bf16 mode at the paper's width runs the strip kernels (bf16 activation + gradient streams, fused FFN); HFTT_STRIP=0 runs the
-    round-1 kernels (fp32 streams).  Same seed: every dropout site must regenerate the same masks in both builds, forward and backward.
-    Two bf16 roundings of this model differ visibly by themselves (first-layer attention logits ~1e4), so the
-    yardstick is the difference of the two builds with dropout OFF: turning dropout on must not make it materially larger (a site /
-    index mismatch anywhere would be an O(1) change of the masked activations)."""
+    round-1 kernels (fp32 streams).  Every dropout site must regenerate the same masks in both builds, forward and backward, as the
+    exact-fp32 parity mode does (same plan, same sites, same seed).  Yardstick: each bf16 build's deviation from the parity mode.  Two
+    bf16 roundings of this model differ visibly by themselves (first-layer attention logits ~1e4), so the strip
+    build must simply not be further from the parity mode than the round-1 build is -- with dropout off AND on (a site / index
+    mismatch anywhere would be an O(1) change of the masked activations and of every gradient behind them)."""
     from hftt_hip.trainer import TrainStep
     cfg = O.HfttConfig(n_margin=4, n_frame=16, n_bin=48, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512,
                        enc_layer=2, dec_layer=2, enc_head=4, dec_head=4, n_note=12, n_velocity=16)
     B = 2
     x = (O.synth_spec(B, cfg, salt=21) * 0.5).to(dev)
     ld = _to_dev(O.synth_labels(B, cfg, salt=22), dev)
-    diff = {}
+    skip = ('conv', 'tok_embedding_freq', 'encoder_spec2midi.pos_embedding_freq', 'encoder_spec2midi.layers_freq.0.self_attention')
+    rep = {}
     for drop in (0.0, 0.1):
-        grads, outs, losses = {}, {}, {}
-        for flag in ('0', '1'):
-            monkeypatch.setenv('HFTT_STRIP', flag)
+        res = {}
+        for build in ('parity', 'round1', 'strip'):
+            monkeypatch.setenv('HFTT_STRIP', '1' if build == 'strip' else '0')
             model = util.build_model(cfg, 7, dropout=drop).to(dev)
-            model.hftt_precision = 'bf16'
+            model.hftt_precision = 'parity' if build == 'parity' else 'bf16'
             model.train()
             ts = TrainStep(model, lr=1e-3)
             loss = ts.forward_backward(x, *ld)
             torch.cuda.synchronize()
             eng = ts.engine
-            assert eng.strip == (flag == '1') and eng._ws[B]['bf16_grad'] == (flag == '1')
-            assert torch.isfinite(eng.flat_grads).all()
-            grads[flag] = torch.cat([eng.flat_grads[o:o + n] for (name, _, o, n) in eng._bound
-                                     if not name.endswith('fc_k.bias') and 'encoder_spec2midi.layers_freq.0.self_attention' not in name
-                                     and not any(t in name for t in ('conv', 'tok_embedding_freq', 'encoder_spec2midi.pos_embedding_freq'))]).double()
-            outs[flag] = [t.clone() for t in eng._ws[B]['outs']]
-            losses[flag] = loss[0].item()
-        diff[drop] = {'post': max(max_err(outs['1'][k], outs['0'][k]) for k in (0, 1, 2, 5, 6, 7)),
-                      'logit': max(max_err(outs['1'][k], outs['0'][k]) for k in (3, 8)),
-                      'loss': abs(losses['0'] - losses['1']),
-                      'gcos': float((grads['0'] @ grads['1']) / (grads['0'].norm() * grads['1'].norm()))}
-    print('strip vs round-1 kernels (bf16 mode):', json.dumps({str(k): v for k, v in diff.items()}))
-    assert diff[0.0]['post'] > 0.0                                     # the two builds really are different arithmetic
-    assert diff[0.1]['post'] < 2.5 * diff[0.0]['post'] + 0.02
-    assert diff[0.1]['logit'] < 2.5 * diff[0.0]['logit'] + 0.05
-    assert diff[0.1]['loss'] < 2.5 * diff[0.0]['loss'] + 0.02
-    assert diff[0.0]['gcos'] > 0.99 and diff[0.1]['gcos'] > 0.99
+            assert eng.strip == (build == 'strip') and torch.isfinite(eng.flat_grads).all()
+            grads = torch.cat([eng.flat_grads[o:o + n] for (name, _, o, n) in eng._bound
+                               if not name.endswith('fc_k.bias') and not any(t in name for t in skip)]).double()
+            res[build] = ([t.clone() for t in eng._ws[B]['outs']], loss[0].item(), grads)
+        for build in ('round1', 'strip'):
+            o, l, gr = res[build]
+            po, pl, pg = res['parity']
+            rep['%s p=%.1f' % (build, drop)] = {
+                'post': max(max_err(o[k], po[k]) for k in (0, 1, 2, 5, 6, 7)), 'logit': max(max_err(o[k], po[k]) for k in (3, 8)),
+                'loss': abs(l - pl), 'gcos': float((gr @ pg) / (gr.norm() * pg.norm()))}
+    print('bf16 builds vs parity mode:', json.dumps(rep))
+    for drop in ('0.0', '0.1'):
+        r1, st = rep['round1 p=' + drop], rep['strip p=' + drop]
+        assert st['post'] < 1.6 * r1['post'] + 0.02, (drop, st, r1)
+        assert st['logit'] < 1.6 * r1['logit'] + 0.05, (drop, st, r1)
+        assert st['loss'] < 1.6 * r1['loss'] + 0.02, (drop, st, r1)
+        assert st['gcos'] > r1['gcos'] - 0.03, (drop, st, r1)
 
 
 def test_backward_reports_gradient_buckets_when_final(dev):

@@ -189,10 +189,34 @@ def test_fused_ffn_backward_dx(dev, M, pf):
 # K % 256 == 0; HFTT_STRIP_V2=0 forces the one-block-per-workgroup kernels.  Same operand order, same epilogue arithmetic ->
 # the two forms must agree BIT FOR BIT, also when a workgroup walks several blocks and when the last block is ragged.
 # ---------------------------------------------------------------------------------------------------------------------
+_SCRUB = {}
+
+
+def _scrub_lds(dev):
+    """LDS keeps its contents from launch to launch.  A kernel that reads a ring slot or a parameter row before it is (re)written would
+    find exactly the right bytes there if the previous launch used the same weights -- which is what a v1-then-v2 comparison does.
+    (That masked a missing barrier once: the model-level test caught it, these did not.)  So every CU's LDS is overwritten with
+    unrelated fragments and parameters first: both kernel families, different random weights."""
+    ops = _ops()
+    if not _SCRUB:
+        g = torch.Generator().manual_seed(999)
+        _SCRUB['x'] = torch.randn(256 * 128, 256, generator=g).to(dev).to(BF)
+        _SCRUB['w'] = ops.strip_pack((torch.randn(768, 256, generator=g) * 3).to(dev))
+        _SCRUB['b'] = (torch.randn(768, generator=g) * 7).to(dev)
+        _SCRUB['wf'] = ops.ffn_pack((torch.randn(512, 256, generator=g) * 3).to(dev), (torch.randn(256, 512, generator=g) * 3).to(dev))
+        _SCRUB['v'] = (torch.randn(512, generator=g) * 7).to(dev)
+    ops.strip_linear(_SCRUB['x'], _SCRUB['w'], 768, bias=_SCRUB['b'])
+    ops.ffn_res_ln_fwd(_SCRUB['x'], _SCRUB['wf'], 512, _SCRUB['v'], _SCRUB['v'][:256].contiguous(), _SCRUB['v'][:256].contiguous(),
+                       _SCRUB['v'][256:].contiguous(), save_hidden=False, save_pre=False)
+
+
 def _both_forms(monkeypatch, fn):
+    dev = torch.device('cuda:0')
     monkeypatch.setenv('HFTT_STRIP_V2', '0')
+    _scrub_lds(dev)
     a = fn()
     monkeypatch.setenv('HFTT_STRIP_V2', '1')
+    _scrub_lds(dev)                 # (the scrub itself runs in the form under test, on all 256 CUs)
     b = fn()
     torch.cuda.synchronize()
     return a, b
