@@ -321,9 +321,10 @@ int hftt_loss(const hftt_loss_desc* d, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * Fused Adam over one flat parameter buffer (torch.optim.Adam defaults, m_training.py:146):
  *   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * Hyper-parameters are doubles (python floats): 1-b1, 1-b2 and the bias corrections are formed in double and rounded once, like torch.
  * --------------------------------------------------------------------------------------------- */
 int hftt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
-                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+                   double lr, double beta1, double beta2, double eps, double grad_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Log-mel front end (model/amt.py:55-63 after resampling): frames of n_fft with hop, centred,

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const hftt_loss_desc g
 
 // ------------------------------------------------------------------ fused Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                            float lr_c, float beta1, float beta2, float eps, float inv_sqrt_bc2, float grad_scale) {
+                            float lr_c, float beta1, float beta2, float omb1, float omb2, float eps, float inv_sqrt_bc2, float grad_scale) {
   const long n4 = n / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -462,8 +462,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const float gr = ge[e] * grad_scale;
-      me[e] = beta1 * me[e] + (1.f - beta1) * gr;
-      ve[e] = beta2 * ve[e] + (1.f - beta2) * gr * gr;
+      me[e] = beta1 * me[e] + omb1 * gr;
+      ve[e] = beta2 * ve[e] + omb2 * gr * gr;
       pe[e] -= lr_c * me[e] / (sqrtf(ve[e]) * inv_sqrt_bc2 + eps);
     }
     reinterpret_cast<float4*>(p)[i] = pp;
@@ -473,8 +473,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   const long tail = n4 * 4;
   for (long i = tail + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gr = g[i] * grad_scale;
-    m[i] = beta1 * m[i] + (1.f - beta1) * gr;
-    v[i] = beta2 * v[i] + (1.f - beta2) * gr * gr;
+    m[i] = beta1 * m[i] + omb1 * gr;
+    v[i] = beta2 * v[i] + omb2 * gr * gr;
     p[i] -= lr_c * m[i] / (sqrtf(v[i]) * inv_sqrt_bc2 + eps);
   }
 }
@@ -609,15 +609,17 @@ extern "C" int hftt_loss(const hftt_loss_desc* d, void* stream) {
 }
 
 extern "C" int hftt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
-                              float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                              double lr, double beta1, double beta2, double eps, double grad_scale, void* stream) {
   HFTT_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
   HFTT_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float lr_c = (float)((double)lr / bc1);
+  // hyper-parameters arrive as doubles (python floats) and 1-beta is formed BEFORE rounding to fp32, as torch.optim.Adam does: 1.f - 0.999f is
+  // off by 1.3e-5 relative and would show in exp_avg_sq of every step
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float lr_c = (float)(lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
-                     lr_c, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+                     lr_c, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, inv_sqrt_bc2, (float)grad_scale);
   HFTT_CHECK_LAUNCH("adam_step");
   return 0;
 }

@@ -167,7 +167,7 @@ SIGNATURES = {
     'hftt_loss_ws_bytes': (C.c_int64, [C.c_int64]),
     'hftt_loss': (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
     'hftt_adam_step': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,
-                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     'hftt_logmel': (C.c_int, [C.POINTER(LogmelDesc), C.c_void_p]),
 }
 

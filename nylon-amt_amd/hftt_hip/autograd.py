@@ -13,6 +13,7 @@ class HfttModelFunction(torch.autograd.Function):
     def forward(ctx, spec, engine, training, *params):
         outs = engine.forward(spec, training=training, save=True)
         ctx.engine = engine
+        ctx.params = params
         ctx.B = spec.shape[0]
         ctx.generation = engine.generation
         ctx.mark_non_differentiable(outs[4])     # attention map: returned for inspection, never part of the loss
@@ -31,5 +32,9 @@ class HfttModelFunction(torch.autograd.Function):
             else:
                 buf.copy_(g.reshape(buf.shape))
         eng.backward(ctx.B, ctx.generation)
-        grads = eng.grad_views(eng.flat_grads.clone())   # private copy: autograd may keep references
+        # The reference loop calls optimizer.zero_grad() every step (train.py:89; set_to_none since torch 2.0), so p.grad is None here
+        # and autograd simply adopts what it is handed: views of the flat gradient buffer, no 22 MB copy per step.  If a caller keeps
+        # gradients across backward passes (accumulation), the views would be summed into themselves -- then, and only then, copy.
+        alias_ok = all(p.grad is None for p in ctx.params)
+        grads = eng.grad_views(None if alias_ok else eng.flat_grads.clone())
         return (None, None, None) + tuple(grads)

@@ -9,6 +9,20 @@ import torch
 import torch.distributed as dist
 
 
+def _host_transport():
+    """gloo moves host memory: device tensors are staged through the host (the RCCL backend, 'nccl', takes them as they are)"""
+    return dist.get_backend() == 'gloo'
+
+
+def _all_reduce_sum(t):
+    if t.is_cuda and _host_transport():
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 class FlatGradSync:
     """all-reduce the engine's flat gradient buffer on a side stream, bucket by bucket, overlapped with the backward.
 
@@ -22,9 +36,15 @@ class FlatGradSync:
     Without ``bucket_ready`` calls (plain ``sync(flat_grads)``) the whole buffer is reduced after the backward in
     ``buckets`` equal slices -- the path the CPU/gloo tests and non-engine callers use."""
 
-    def __init__(self, engine, world, buckets=1):
+    def __init__(self, engine, world, buckets=1, rank=None):
         self.engine = engine
         self.world = world
+        # every rank must draw its own dropout masks: fold the rank into the engine's seed (bench.py used to be the only caller that did)
+        if rank is None:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if not getattr(engine, '_seed_has_rank', False):
+            engine.base_seed = int(engine.base_seed) + 7919 * int(rank)
+            engine._seed_has_rank = True
         self.cuda = engine.flat_grads.is_cuda
         self.stream = torch.cuda.Stream(device=engine.flat_grads.device) if self.cuda else None
         n = engine.flat_grads.numel()
@@ -33,6 +53,11 @@ class FlatGradSync:
         self.slices = [(i, min(n, i + step)) for i in range(0, n, step)]
         self.scale = 1.0 / world
         self.launched = []                     # flat ranges already reduced (or in flight) for the current step
+
+    def begin_step(self):
+        """called before every backward: ranges reported by a backward that was never followed by __call__ (gradient accumulation,
+        an exception) must not be mistaken for this step's"""
+        self.launched = []
 
     def bucket_ready(self, lo, hi):
         """flat_grads[lo:hi] is final on the current stream: start its all-reduce now."""
@@ -44,12 +69,14 @@ class FlatGradSync:
         else:
             self.stream.wait_stream(torch.cuda.current_stream(g.device))
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
+                _all_reduce_sum(g[lo:hi])
         self.launched.append((lo, hi))
 
     def __call__(self, flat_grads):
         if self.launched:                      # overlapped mode: every range was handed over by bucket_ready
             done, self.launched = sorted(self.launched), []
+            if self.cuda:                           # join the side stream first: also on the error paths below
+                torch.cuda.current_stream(flat_grads.device).wait_stream(self.stream)
             pos = 0
             for lo, hi in done:
                 if lo != pos:
@@ -57,8 +84,6 @@ class FlatGradSync:
                 pos = hi
             if pos != flat_grads.numel():
                 raise RuntimeError('FlatGradSync: gradient range [%d, %d) was never reported ready' % (pos, flat_grads.numel()))
-            if self.cuda:
-                torch.cuda.current_stream(flat_grads.device).wait_stream(self.stream)
             return self.scale
         if not self.cuda:                      # gloo / CPU tensors (tests): same bucketing, no streams
             for a, b in self.slices:
@@ -68,6 +93,52 @@ class FlatGradSync:
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             for a, b in self.slices:
-                dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM)
+                _all_reduce_sum(flat_grads[a:b])
         cur.wait_stream(self.stream)
         return self.scale
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Host-side helpers of the data-parallel job (one process per GPU).  The reference has no multi-device code at all: these are what a
+# launcher around training/m_training.py and the training.train / model.amt mirrors use when WORLD_SIZE > 1.
+def rank_world():
+    """(rank, world) of the running job; (0, 1) outside torch.distributed."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def is_main():
+    """rank 0 writes checkpoints / logs (m_training.py:372-392 runs on every rank otherwise)"""
+    return rank_world()[0] == 0
+
+
+def shard_indices(n, rank=None, world=None):
+    """clip ids of this rank: r, r+world, r+2*world, ... (files differ in length; striding keeps the ranks balanced), truncated so that every
+    rank holds the SAME number of clips -- ranks must make the same number of steps or the gradient all-reduce deadlocks."""
+    if rank is None or world is None:
+        rank, world = rank_world()
+    per = n // world
+    return list(range(rank, per * world, world))
+
+
+def broadcast_parameters(engine, src=0):
+    """every rank starts from rank `src`'s parameters (m_training.py:141 initialises per process): one broadcast of the flat buffer"""
+    if rank_world()[1] > 1:                              # (the engine re-packs its GEMM operands from flat_params at every forward)
+        if engine.flat_params.is_cuda and _host_transport():
+            h = engine.flat_params.cpu()
+            dist.broadcast(h, src)
+            engine.flat_params.copy_(h)
+        else:
+            dist.broadcast(engine.flat_params, src)
+
+
+def allreduce_sums(*values, device=None):
+    """sum python scalars / 0-d tensors over the ranks in ONE collective; returns floats (the epoch-loss exchange of train / valid)"""
+    rank, world = rank_world()
+    if world > 1 and _host_transport():
+        device = 'cpu'
+    t = torch.stack([torch.as_tensor(v, dtype=torch.float64, device=device).reshape(()) for v in values])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]

@@ -118,6 +118,8 @@ class HfttEngine:
         self.poff = {n: o for (n, _), o in zip(named, offs)}
         self.pshape = {n: tuple(p.shape) for n, p in named}
         self._bound = [(n, p, o, p.numel()) for (n, p), o in zip(named, offs)]
+        from .trainer import register_binding     # lets FusedAdam(model.parameters()) built before this bind find the engine
+        register_binding(self, [p for _, p in named])
         self._build_prep()
         self._ws = {}
 
@@ -1069,6 +1071,10 @@ class HfttEngine:
         if not self.is_bound():
             raise _capi.HfttError('engine parameters are not bound (call bind first)')
         B = spec.shape[0]
+        with torch.cuda.device(self.device):         # launches, stream lookup and device queries all refer to the engine's GPU
+            return self._forward(spec, B, training, outputs, save)
+
+    def _forward(self, spec, B, training, outputs, save):
         ws = self.workspace(B)
         self._cur_ws = ws
         ws['bufs']['spec'].copy_(spec)
@@ -1112,16 +1118,17 @@ class HfttEngine:
         if generation is not None and generation != ws['generation']:
             raise _capi.HfttError('backward called for a stale forward (activations were overwritten by a later forward)')
         self._cur_ws = ws
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._patch(ws, ws['p'], ws['seed'])
-        if on_ready is None:
-            self._run(ws, ws['bwd'], stream, outs=ws['outs'], seed=ws['seed'], p=ws['p'])
-            return
-        start = 0
-        for end, lo, hi in ws['bwd_marks']:
-            self._run(ws, ws['bwd'][start:end], stream, outs=ws['outs'], seed=ws['seed'], p=ws['p'])
-            on_ready(lo, hi)
-            start = end
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._patch(ws, ws['p'], ws['seed'])
+            if on_ready is None:
+                self._run(ws, ws['bwd'], stream, outs=ws['outs'], seed=ws['seed'], p=ws['p'])
+                return
+            start = 0
+            for end, lo, hi in ws['bwd_marks']:
+                self._run(ws, ws['bwd'][start:end], stream, outs=ws['outs'], seed=ws['seed'], p=ws['p'])
+                on_ready(lo, hi)
+                start = end
 
     # ------------------------------------------------------------------ fused loss (training/train.py:141-153)
     def loss(self, B, labels, weight_A=1.0, weight_B=1.0, with_grad=True):
@@ -1150,6 +1157,7 @@ class HfttEngine:
                 dsc.d_prob[i] = b['d.' + nm].data_ptr()
             dsc.d_vel[0], dsc.d_vel[1] = b['d.velocity_A'].data_ptr(), b['d.velocity_B'].data_ptr()
         dsc.loss_out, dsc.ws = b['loss_out'].data_ptr(), b['loss_ws'].data_ptr()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.lib.hftt_loss(C.byref(dsc), stream), 'loss')
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            check(self.lib.hftt_loss(C.byref(dsc), stream), 'loss')
         return b['loss_out'][:9]

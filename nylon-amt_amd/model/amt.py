@@ -25,12 +25,21 @@ from hftt_hip._capi import HfttError   # noqa: E402
 
 
 class AMT():
-    def __init__(self, config, model_path, batch_size=1, verbose_flag=False):
+    def __init__(self, config, model_path, batch_size=1, verbose_flag=False, rank=None, world=None, device=None):
+        """rank / world (default: those of torch.distributed when it is initialised, else 0 / 1): the clip batches of a file are dealt
+        to the ranks round-robin, each rank runs its share on ITS GPU and the results are all-gathered, so every rank returns the whole
+        transcription (the reference runs one clip at a time on one device, amt.py:88)."""
         if verbose_flag is True:
             print('torch version: ' + torch.__version__)
             print('torch cuda   : ' + str(torch.cuda.is_available()))
-        if torch.cuda.is_available():
-            self.device = 'cuda'
+        if rank is None or world is None:
+            from hftt_hip.ddp import rank_world
+            rank, world = rank_world()
+        self.rank, self.world = int(rank), int(world)
+        if device is not None:
+            self.device = device
+        elif torch.cuda.is_available():
+            self.device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', 0)) if self.world > 1 and 'LOCAL_RANK' in os.environ else 'cuda'
         else:
             self.device = 'cpu'      # the model itself will refuse to run there (no CPU fallback)
 
@@ -58,7 +67,7 @@ class AMT():
         """wave [channels, n] or [n] float tensor at sample rate sr -> log-mel [n_frames, n_mels] (CPU tensor like the reference)."""
         from hftt_hip import ops
         fe = self.config['feature']
-        if self.device != 'cuda':
+        if not str(self.device).startswith('cuda'):
             raise HfttError('wav2feature runs the HIP log-mel kernel: a ROCm device is required')
         wave = wave.float()
         wave_mono = wave.mean(dim=0) if wave.dim() == 2 else wave        # torch.mean(wave, dim=0), amt.py:56
@@ -79,21 +88,46 @@ class AMT():
             raise HfttError("only mode='combination' without ablation is built (the 1-F-D-T model of model_spec2midi.py)")
         cin = self.config['input']
         width = cin['margin_b'] + cin['num_frame'] + cin['margin_f']
-        x = torch.from_numpy(a_input)
-        outs = None
+        x = torch.from_numpy(a_input).to(self.device)                          # the whole file's features: one host->device copy
         self.model.eval()
-        for b0 in range(0, len(starts), self.batch_size):
-            idx = starts[b0:b0 + self.batch_size]
-            spec = torch.stack([x[i:i + width].T for i in idx], dim=0)          # [b, n_bins, width] (amt.py:89)
+        batches = [starts[b0:b0 + self.batch_size] for b0 in range(0, len(starts), self.batch_size)]
+        mine = list(range(self.rank, len(batches), self.world))                 # this rank's batches (round-robin)
+        parts = [[] for _ in range(8)]
+        for bi in mine:
+            spec = torch.stack([x[i:i + width].T for i in batches[bi]], dim=0)  # [b, n_bins, width] (amt.py:89)
             with torch.no_grad():
-                o = self.model(spec.to(self.device))
-            sel = [o[0], o[1], o[2], o[3].argmax(3), o[5], o[6], o[7], o[8].argmax(3)]   # velocity argmax (amt.py:107,113)
-            sel = [t.to('cpu').numpy() for t in sel]
-            if outs is None:
-                outs = [[] for _ in sel]
-            for lst, t in zip(outs, sel):
-                lst.append(t)
-        return [np.concatenate(l, axis=0) for l in outs]      # each [n_clips, num_frame, num_note]
+                o = self.model(spec)
+            sel = (o[0], o[1], o[2], o[3].argmax(3), o[5], o[6], o[7], o[8].argmax(3))   # velocity argmax (amt.py:107,113)
+            for lst, t in zip(parts, sel):
+                lst.append(t)                                                   # stays on the device: one copy back per file, not per batch
+        return self._collect(parts, batches, mine)
+
+    def _collect(self, parts, batches, mine):
+        """per-rank device results -> 8 numpy arrays [n_clips, num_frame, num_note] in clip order, on every rank"""
+        cin, cm = self.config['input'], self.config['midi']
+        T, N = cin['num_frame'], cm['num_note']
+        n_clips = sum(len(b) for b in batches)
+        if self.world == 1:
+            return [torch.cat(l, dim=0).to('cpu').numpy() for l in parts]
+        import torch.distributed as dist
+        gdev = 'cpu' if dist.get_backend() == 'gloo' else self.device          # gloo moves host memory; RCCL ('nccl') device memory
+        per = -(-len(batches) // self.world) * self.batch_size                # clips per rank, padded: equal-sized all_gather
+        res = []
+        order = [i for r in range(self.world) for bi in range(r, len(batches), self.world) for i in range(bi * self.batch_size, bi * self.batch_size + len(batches[bi]))]
+        counts = [sum(len(batches[bi]) for bi in range(r, len(batches), self.world)) for r in range(self.world)]
+        for k, l in enumerate(parts):
+            dt = torch.int64 if k % 4 == 3 else torch.float32
+            local = torch.zeros(per, T, N, dtype=dt, device=gdev)
+            if l:
+                cat = torch.cat(l, dim=0)
+                local[:cat.shape[0]] = cat
+            gathered = [torch.empty_like(local) for _ in range(self.world)]
+            dist.all_gather(gathered, local)
+            flat = torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)
+            full = torch.empty(n_clips, T, N, dtype=dt, device=gdev)
+            full[torch.tensor(order, device=gdev)] = flat
+            res.append(full.to('cpu').numpy())
+        return res
 
     def transcript(self, a_feature, mode='combination', ablation_flag=False):
         # a_feature: [num_frame, n_mels]

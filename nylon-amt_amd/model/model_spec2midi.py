@@ -39,15 +39,29 @@ class Model_SPEC2MIDI(nn.Module):
         self.hftt_precision = os.environ.get('HFTT_PRECISION', 'parity')   # 'parity' (exact-fp32 MFMA, <= 1e-3 of the reference) or 'bf16' (throughput mode)
         self.hftt_seed = 1234
 
+    def __setstate__(self, state):
+        """A checkpoint written by the REFERENCE (pickle.dump(model), m_training.py:372-373; amt.py:24-25 loads it) unpickles into these
+        classes by module path; it carries the reference's attributes only, so the engine settings get their defaults here."""
+        super().__setstate__(state)
+        self.__dict__.setdefault('hftt_precision', os.environ.get('HFTT_PRECISION', 'parity'))
+        self.__dict__.setdefault('hftt_seed', 1234)
+
     # ---- engine management -------------------------------------------------------------------
     def hftt_config(self):
+        """Constructor arguments of the reference classes, read back from the submodules (not from bookkeeping attributes of this
+        file: a reference-made pickle has none of those)."""
         e, d = self.encoder_spec2midi, self.decoder_spec2midi
+        e_pf = e.layers_freq[0].positionwise_feedforward.fc_1.out_features
+        d_pf = d.layer_zero_freq.positionwise_feedforward.fc_1.out_features
         if e.hid_dim != d.hid_dim or e.n_frame != d.n_frame or e.n_bin != d.n_bin:
             raise HfttError('encoder/decoder shapes disagree')
+        if e_pf != d_pf or float(e.dropout.p) != float(d.dropout.p):
+            raise HfttError('the fused engine runs ONE feed-forward width and ONE dropout rate: encoder (%d, %g) and decoder (%d, %g) disagree'
+                            % (e_pf, e.dropout.p, d_pf, d.dropout.p))
         return dict(n_margin=(e.n_proc - 1) // 2, n_frame=e.n_frame, n_bin=e.n_bin, cnn_channel=e.cnn_channel,
-                    cnn_kernel=e.cnn_kernel, hid_dim=e.hid_dim, pf_dim=e.pf_dim, enc_layer=len(e.layers_freq),
-                    dec_layer=len(d.layers_time), enc_head=e.n_heads, dec_head=d.n_heads, n_note=d.n_note,
-                    n_velocity=d.n_velocity)
+                    cnn_kernel=e.cnn_kernel, hid_dim=e.hid_dim, pf_dim=e_pf, enc_layer=len(e.layers_freq),
+                    dec_layer=len(d.layers_time), enc_head=e.layers_freq[0].self_attention.n_heads,
+                    dec_head=d.layer_zero_freq.encoder_attention.n_heads, n_note=d.n_note, n_velocity=d.n_velocity)
 
     def hftt_engine(self):
         """Return the HIP engine bound to this module's parameters (built / rebound lazily)."""
@@ -70,6 +84,7 @@ class Model_SPEC2MIDI(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop('_hftt', None)
+        state.pop('_hftt_sync', None)
         # parameters are views into the engine's flat buffer: clone them out so each pickles its own storage
         state['_modules'] = copy.deepcopy(state['_modules'])
         return state
@@ -77,6 +92,7 @@ class Model_SPEC2MIDI(nn.Module):
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)
         self.__dict__.pop('_hftt', None)     # .to()/.cuda()/.float() replace parameter storage: rebind on next use
+        self.__dict__.pop('_hftt_sync', None)
         return r
 
     def forward(self, input_spec):

@@ -9,6 +9,12 @@ Two execution paths, same kernels underneath:
     exactly as training/train.py:89-160 does.
 The mir_eval metrics branch of ``valid`` (train.py:9-57,193-200: SURVEY section 2 #15, a metric artefact) is out of scope:
 ``metrics=True`` raises.
+
+Data parallel (the reference is single-device): when torch.distributed is initialised with world > 1, every process runs these same
+functions on ITS shard of the clips (``hftt_hip.ddp.shard_indices`` / ``DeviceClipStore.loader(rank=, world=)``: r::world, equal counts);
+``train`` all-reduces the flat gradient inside the step (FlatGradSync, overlapped with the backward) and both functions exchange ONE
+pair of scalars per epoch, so every rank returns the loss of the whole job: ``train`` -> global mean, ``valid`` -> (global sum, global
+number of batches).  Checkpoints are written by rank 0 only (``hftt_hip.ddp.is_main``).
 """
 import os
 import sys
@@ -22,6 +28,7 @@ if _PKG not in sys.path:
 
 from hftt_hip._capi import HfttError           # noqa: E402
 from hftt_hip.trainer import FusedAdam, TrainStep   # noqa: E402
+from hftt_hip import ddp                        # noqa: E402
 
 try:
     from tqdm import tqdm
@@ -46,13 +53,22 @@ def train(model, iterator, optimizer,
     crits = (criterion_onset_A, criterion_offset_A, criterion_mpe_A, criterion_velocity_A,
              criterion_onset_B, criterion_offset_B, criterion_mpe_B, criterion_velocity_B)
     fast = isinstance(optimizer, FusedAdam) and _reference_criteria(crits)
+    rank, world = ddp.rank_world()
+    sync = None
+    if world > 1:
+        eng = model.hftt_engine()
+        sync = model.__dict__.get('_hftt_sync')
+        if sync is None or sync.engine is not eng:
+            ddp.broadcast_parameters(eng)            # every rank starts from rank 0's parameters
+            sync = ddp.FlatGradSync(eng, world, rank=rank)
+            model.__dict__['_hftt_sync'] = sync
     step = None
     if fast:
         step = getattr(optimizer, '_train_step', None)
-        if step is None or step.model is not model:
-            step = TrainStep(model, weight_A=weight_A, weight_B=weight_B, optimizer=optimizer)
+        if step is None or step.model is not model or step.engine is not model.hftt_engine():
+            step = TrainStep(model, weight_A=weight_A, weight_B=weight_B, optimizer=optimizer, grad_sync=sync)
             optimizer._train_step = step
-        step.weight_A, step.weight_B = weight_A, weight_B
+        step.weight_A, step.weight_B, step.grad_sync = weight_A, weight_B, sync
     epoch_loss = torch.zeros((), device=device, dtype=torch.float64) if fast else 0
     n = 0
     for i, (input_spec, label_onset, label_offset, label_mpe, label_velocity) in tqdm(enumerate(iterator), total=len(iterator)):
@@ -85,10 +101,17 @@ def train(model, iterator, optimizer,
             print('(5) loss:' + str(loss.size()))
             print(loss)
         loss.backward()
+        if sync is not None:                       # p.grad are views of the flat gradient buffer: one all-reduce, then the mean
+            flat = model.hftt_engine().flat_grads
+            sync.begin_step()
+            flat.mul_(sync(flat))
         optimizer.step()
         epoch_loss += loss.item()
     if fast:
         epoch_loss = float(epoch_loss.item())
+    if world > 1:
+        epoch_loss, n_batches = ddp.allreduce_sums(epoch_loss, len(iterator), device=device)
+        return epoch_loss / n_batches
     return epoch_loss / len(iterator)
 
 
@@ -104,7 +127,7 @@ def valid(model, iterator,
     crits = (criterion_onset_A, criterion_offset_A, criterion_mpe_A, criterion_velocity_A,
              criterion_onset_B, criterion_offset_B, criterion_mpe_B, criterion_velocity_B)
     fast = _reference_criteria(crits)
-    epoch_loss = 0
+    epoch_loss = torch.zeros((), device=device, dtype=torch.float64) if fast else 0
     with torch.no_grad():
         for i, (input_spec, label_onset, label_offset, label_mpe, label_velocity) in enumerate(tqdm(iterator)):
             input_spec = input_spec.to(device, non_blocking=True)
@@ -118,7 +141,7 @@ def valid(model, iterator,
                 loss9 = eng.loss(input_spec.shape[0], (label_onset.float().contiguous(), label_offset.float().contiguous(),
                                                        label_mpe.float().contiguous(), label_velocity.long().contiguous()),
                                  weight_A, weight_B, with_grad=False)
-                epoch_loss += loss9[0].item()
+                epoch_loss += loss9[0].double()          # one host sync per epoch (train.py:252 syncs per batch)
                 continue
             oa, fa, ma, va, _att, ob, fb, mb, vb = out
             lo, lf, lm, lv = (t.contiguous().view(-1) for t in (label_onset, label_offset, label_mpe, label_velocity))
@@ -127,4 +150,9 @@ def valid(model, iterator,
             loss_B = (criterion_onset_B(ob.contiguous().view(-1), lo) + criterion_offset_B(fb.contiguous().view(-1), lf)
                       + criterion_mpe_B(mb.contiguous().view(-1), lm) + criterion_velocity_B(vb.contiguous().view(-1, vb.shape[-1]), lv))
             epoch_loss += (weight_A * loss_A + weight_B * loss_B).item()
+    if fast:
+        epoch_loss = float(epoch_loss.item())
+    if ddp.rank_world()[1] > 1:
+        epoch_loss, n_batches = ddp.allreduce_sums(epoch_loss, len(iterator), device=device)
+        return epoch_loss, int(n_batches)
     return epoch_loss, len(iterator)

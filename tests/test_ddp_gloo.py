@@ -19,6 +19,7 @@ class _FakeEngine:
     def __init__(self, n):
         self.flat_grads = torch.zeros(n)
         self.device = torch.device('cpu')
+        self.base_seed = 1234
 
 
 def _worker(rank, world, port, tmp):
@@ -46,6 +47,9 @@ def _worker(rank, world, port, tmp):
     eng = _FakeEngine(flat.numel())
     eng.flat_grads.copy_(torch.cat([sd[n_].grad.reshape(-1) for n_ in names]))
     sync = FlatGradSync(eng, world, buckets=3)
+    assert eng.base_seed == 1234 + 7919 * rank          # every rank draws its own dropout masks
+    FlatGradSync(eng, world)
+    assert eng.base_seed == 1234 + 7919 * rank          # ... folded in once per engine
     scale = sync(eng.flat_grads)
     avg = eng.flat_grads * scale
     # overlapped mode: the engine hands over three ranges as they become final (here: after the fact, any order)
@@ -56,7 +60,10 @@ def _worker(rank, world, port, tmp):
     for lo, hi in ((n_all // 2, n_all), (n_all // 5, n_all // 2), (0, n_all // 5)):
         sync2.bucket_ready(lo, hi)
     assert sync2(eng2.flat_grads) == scale and torch.equal(eng2.flat_grads * scale, avg)
-    sync2.bucket_ready(0, 10)                            # a step that forgot a range must not pass silently
+    sync2.bucket_ready(0, 10)                            # ranges of an abandoned backward (accumulation, exception) are dropped ...
+    sync2.begin_step()
+    assert sync2.launched == []
+    sync2.bucket_ready(0, 10)                            # ... and a step that forgot a range must not pass silently
     try:
         sync2(eng2.flat_grads)
         raise AssertionError('missing range not detected')
@@ -80,3 +87,47 @@ def test_world2_flat_gradient_allreduce_equals_global_batch_gradient(tmp_path):
     err, scale, n_buckets = np.load(tmp_path / 'result.npy')
     assert scale == 0.5 and n_buckets == 3
     assert err < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# inference scatter (model/amt.py) and the epoch-loss exchange of training/train.py under world 2
+def _amt_worker(rank, world, port, tmp):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import test_amt_host as H
+    from model.amt import AMT
+    from hftt_hip import ddp
+    g = util.golden('amt')
+    assert ddp.rank_world() == (rank, world) and ddp.is_main() == (rank == 0)
+    for bs in (1, 3):
+        amt = AMT(H.CFG, None, batch_size=bs, device='cpu')        # rank / world picked up from torch.distributed
+        assert (amt.rank, amt.world) == (rank, world)
+        calls = []
+        echo = H.EchoModel(H.CFG)
+        amt.model = type('Counting', (), {'eval': lambda s: s, '__call__': lambda s, x: (calls.append(x.shape[0]), echo(x))[1]})()
+        for n in (8, 21, 30):
+            feat = g[f'tr.{n}.feature']
+            calls.clear()
+            outs = amt.transcript(feat)
+            n_clips = -(-n // 8)
+            n_batches = -(-n_clips // bs)
+            assert len(calls) == len(range(rank, n_batches, world))      # this rank ran only its share of the batches ...
+            for i, o in enumerate(outs):                                  # ... and holds the whole file's result, equal to the reference's
+                ref = g[f'tr.{n}.out{i}']
+                assert o.dtype == ref.dtype and o.shape == ref.shape
+                np.testing.assert_array_equal(o, ref)
+            for i, o in enumerate(amt.transcript_stride(feat, 2)):
+                np.testing.assert_array_equal(o, g[f'trs.{n}.2.out{i}'])
+    # clip sharding: disjoint, equal-sized, covering all but the n % world tail
+    ids = [ddp.shard_indices(11, r, world) for r in range(world)]
+    assert ids == [[0, 2, 4, 6, 8], [1, 3, 5, 7, 9]] and ddp.shard_indices(11) == ids[rank]
+    # epoch-loss exchange: every rank ends with the global sums
+    tot, cnt = ddp.allreduce_sums(1.5 + rank, 3)
+    assert (tot, cnt) == (4.0, 6.0)
+    dist.destroy_process_group()
+
+
+def test_world2_inference_scatter_and_loss_exchange(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_amt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
