@@ -426,8 +426,13 @@ class HfttEngine:
         tf = lambda v: 'true' if v else 'false'
         nbytes = (2 if x_bf else 4) * M * K + (2 if c_bf else 4) * M * N * (2 if pre_saved else 1) + 2 * N * K \
             + ((2 if res_bf else 4) * M * N if residual else 0) + (2 * M * N if gate else 0)
-        meta = {'kernel': 'strip_linear_kernel<%s, %s, %s>' % (tf(x_bf), tf(c_bf), tf(ln is not None)), 'flops': 2.0 * M * N * K, 'bytes': float(nbytes),
-                'shape': (M, N, K)}
+        # kernel symbol as rocprofv3 prints it (the C side picks the pipelined form by the rule mirrored here: strip_gemm2.hip hftt_strip_linear2_try)
+        passes, kch = N // 256, K // 256
+        v2 = (os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and x_bf and c_bf and K % 256 == 0 and M % 32 == 0 and not gate and (not residual or res_bf)
+              and ((ln is not None and kch <= 3) or (ln is None and (kch, passes) in ((1, 1), (1, 2), (1, 3), (2, 1), (3, 1)))))
+        kname = ('strip_linear2_kernel<%s, %d, %d>' % (tf(ln is not None), 1 if ln is not None else passes, kch)) if v2 \
+            else 'strip_linear_kernel<%s, %s, %s>' % (tf(x_bf), tf(c_bf), tf(ln is not None))
+        meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_strip_linear, (C.byref(dsc),), 'strip_linear', meta))
         return dsc
 
@@ -456,7 +461,9 @@ class HfttEngine:
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
         nbytes = 2.0 * M * d * (2 + (1 if pre_saved else 0) + (1 if residual else 0)) + (2.0 * M * p if h_out else 0) + (2.0 * M * p if gate else 0) + 4.0 * d * p
-        meta = {'kernel': 'strip_mlp_kernel<%d>' % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes, 'shape': (M, d, p)}
+        v2 = os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and p == 512 and M % 32 == 0 and not (mode == 0 and residual)
+        meta = {'kernel': ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>') % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
+                'shape': (M, d, p), 'saves': bool(h_out or pre_saved)}
         plan.append((self.lib.hftt_ffn_res_ln_fwd if mode == 0 else self.lib.hftt_ffn_bwd_dx, (C.byref(dsc),), 'ffn_fwd' if mode == 0 else 'ffn_bwd_dx', meta))
         return dsc
 

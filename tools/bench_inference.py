@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Inference plan only (model.eval() forward of the paper-size model, batch 8, bf16 mode): the command the inference-side rocprofv3 passes
+of tools/profile_bench.sh wrap.  Prints clips/s."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'nylon-amt_amd')]
+import torch   # noqa: E402
+import bench   # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--steps', type=int, default=10)
+ap.add_argument('--batch', type=int, default=8)
+args = ap.parse_args()
+dev = torch.device('cuda', 0)
+cfg = bench.CONFIGS['paper']
+model = bench.build_model(cfg, 1234, 0.1, dev)
+model.hftt_precision = 'bf16'
+model.eval()
+x, _ = bench.synthetic_batch(cfg, args.batch, 1234, dev)
+with torch.no_grad():
+    for _ in range(2):
+        model(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model(x)
+    torch.cuda.synchronize()
+print('inference clips/s %.1f' % (args.batch * args.steps / (time.perf_counter() - t0)))

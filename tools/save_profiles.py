@@ -1,29 +1,82 @@
 #!/usr/bin/env python3
-"""Copy a rocprofv3 run out of gpurun_out/ into profiles/ (tracked).
-Usage: python tools/save_profiles.py <tag> <stats_dir> <bench_json> <pmc_fetch_dir> <pmc_write_dir>"""
-import csv, collections, json, re, shutil, sys
-tag, stats_dir, bench_json, fdir, wdir = sys.argv[1:6]
-shutil.copy(f'{stats_dir}/bench_kernel_stats.csv', f'profiles/{tag}_bench_kernel_stats.csv')
-shutil.copy(bench_json, f'profiles/{tag}_bench.json')
+"""Copy a tools/profile_bench.sh run out of gpurun_out/ into profiles/ (tracked).   Usage: python tools/save_profiles.py <tag>
+Writes profiles/<tag>_bench.json (the bench line), _bench_kernel_stats.csv, _bench_pmc_traffic.json, _bench_pmc_busy.json and the same
+three for the inference plan (<tag>_inference_*)."""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1]
+G = 'gpurun_out/' + tag
+
+
+def key_of(n):
+    m = re.search(r'::([a-z_0-9]+(?:<[^>]*>)?)\(', n)
+    return m.group(1) if m else n
+
+
 def load(path):
-    d = collections.defaultdict(list)
+    """-> {kernel symbol: {counter: [values per launch]}} (rocprofv3 counter_collection.csv, one row per dispatch and counter)"""
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not os.path.exists(path):
+        return d
     for r in csv.DictReader(open(path)):
-        d[r['Kernel_Name']].append(float(r['Counter_Value']))
+        n = r['Kernel_Name']
+        if 'namespace)::' in n and 'at::' not in n:
+            d[key_of(n)][r['Counter_Name']].append(float(r['Counter_Value']))
     return d
-f = load(f'{fdir}/b_counter_collection.csv'); w = load(f'{wdir}/b_counter_collection.csv')
-out = {}
-for n in sorted(set(f) | set(w)):
-    if 'namespace)::' in n and 'at::' not in n:
-        m = re.search(r'::([a-z_0-9]+(?:<[^>]*>)?)\(', n)
-        key = m.group(1) if m else n
-        fl = f.get(n, [0]); wl = w.get(n, [0])
-        out[key] = {'launches': len(fl), 'fetch_MB_per_launch_x2_corrected': round(2 * sum(fl) / len(fl) * 1024 / 1e6, 2),
-                    'write_MB_per_launch': round(sum(wl) / max(1, len(wl)) * 1024 / 1e6, 2)}
-json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) around `python3 bench.py --steps 2 --warmup 1 '
-                   '--no-cpu-baseline --no-profile` (paper size, B=8, bf16 mode); counter values are KB; FETCH_SIZE doubled as '
-                   'MI355X_MICROARCH.md prescribes for gfx950 (calibrated on a 268 MB copy: profiles/r01_kernel_pmc_traffic.json); '
-                   'per-launch averages over all launches of a kernel symbol', 'kernels': out},
-          open(f'profiles/{tag}_bench_pmc_traffic.json', 'w'), indent=1)
-rows = list(csv.DictReader(open(f'profiles/{tag}_bench_kernel_stats.csv')))
-for r in rows[:10]:
-    print('%-84s calls=%6s avg_us=%9.1f pct=%5s' % (r['Name'][:84], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
+
+
+def traffic(fdir, wdir, out, what):
+    f, w = load(f'{fdir}/b_counter_collection.csv'), load(f'{wdir}/b_counter_collection.csv')
+    k = {}
+    for n in sorted(set(f) | set(w)):
+        fl, wl = f[n].get('FETCH_SIZE', [0]), w[n].get('WRITE_SIZE', [0])
+        k[n] = {'launches': len(fl), 'fetch_MB_per_launch_x2_corrected': round(2 * sum(fl) / len(fl) * 1024 / 1e6, 2),
+                'write_MB_per_launch': round(sum(wl) / max(1, len(wl)) * 1024 / 1e6, 2)}
+    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) around `%s` (paper size, B=8, bf16 mode); counter '
+                       'values are KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated on a 268 MB copy: '
+                       'profiles/r01_kernel_pmc_traffic.json); per-launch averages over all launches of a kernel symbol' % what, 'kernels': k},
+              open(out, 'w'), indent=1)
+
+
+def busy(dirs, out, what):
+    d = collections.defaultdict(dict)
+    for p in dirs:
+        for n, c in load(f'{p}/b_counter_collection.csv').items():
+            for name, vals in c.items():
+                d[n][name] = sum(vals) / len(vals)
+                d[n]['launches'] = len(vals)
+    k = {}
+    for n, c in sorted(d.items()):
+        e = {'launches': c.get('launches')}
+        e.update({name: round(v, 1) for name, v in c.items() if name != 'launches'})
+        if c.get('SQ_BUSY_CYCLES'):
+            # SQ_VALU_MFMA_BUSY_CYCLES counts, summed over the SQs like SQ_BUSY_CYCLES, the cycles the MFMA pipe was busy
+            e['mfma_busy'] = round(c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / c['SQ_BUSY_CYCLES'], 4)
+        k[n] = e
+    json.dump({'note': 'rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES (one pass) and SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES '
+                       '(another) around `%s`; per-launch averages per kernel symbol; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES' % what,
+               'kernels': k}, open(out, 'w'), indent=1)
+
+
+cmd = 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras'
+shutil.copy(f'{G}_stats/bench_kernel_stats.csv', f'profiles/{tag}_bench_kernel_stats.csv')
+if os.path.exists(f'{G}_bench.json'):
+    shutil.copy(f'{G}_bench.json', f'profiles/{tag}_bench.json')
+traffic(f'{G}_fetch', f'{G}_write', f'profiles/{tag}_bench_pmc_traffic.json', cmd)
+busy([f'{G}_busy', f'{G}_busy2'], f'profiles/{tag}_bench_pmc_busy.json', cmd)
+if os.path.exists(f'{G}_inf_stats/bench_kernel_stats.csv'):
+    cmd = 'python3 tools/bench_inference.py --steps 2'
+    shutil.copy(f'{G}_inf_stats/bench_kernel_stats.csv', f'profiles/{tag}_inference_kernel_stats.csv')
+    traffic(f'{G}_inf_fetch', f'{G}_inf_write', f'profiles/{tag}_inference_pmc_traffic.json', cmd)
+    busy([f'{G}_inf_busy'], f'profiles/{tag}_inference_pmc_busy.json', cmd)
+for name in (f'profiles/{tag}_bench_kernel_stats.csv', f'profiles/{tag}_inference_kernel_stats.csv'):
+    if os.path.exists(name):
+        print(name)
+        for r in list(csv.DictReader(open(name)))[:12]:
+            print('  %-84s calls=%6s avg_us=%9.1f pct=%5s' % (r['Name'][:84], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
