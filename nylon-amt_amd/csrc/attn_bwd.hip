@@ -16,6 +16,15 @@
 
 int hftt_attn_check(const hftt_attn_desc* d, bool bwd);
 
+// Ablation build (tools/ablate_attn.sh, -DHFTT_ATTN_ABLATE): descriptor pad bits switch mechanisms off (timing only, results garbage):
+//   1 no Q/dO/O block loads (registers keep the first block)   2 no S / dP MFMAs   4 no softmax-backward arithmetic   8 no dropout
+//   16 no dV / dK MFMAs   32 no dS -> LDS and no dQ product / stores   64 no dK / dV stores
+#ifdef HFTT_ATTN_ABLATE
+#define ABL(g, bit) (((g).pad & (bit)) != 0)
+#else
+#define ABL(g, bit) false
+#endif
+
 namespace {
 
 // npass == 1: bf16 planes as described above.  npass == 3 (parity): every tile stays fp32 in LDS / registers and all
@@ -63,8 +72,13 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
   const int Lq = g.Lq, Lk = g.Lk;
   const float scale = 1.0f / sqrtf((float)DH);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float c2 = scale * LOG2E;
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  // one hash per four elements needs Lk % 4 == 0 and quad indices below 2^32 for the whole launch (attn_fwd.hip makes the same choice;
+  // either way the decisions are those of hftt_keep)
+  const bool pair_ok = (Lk & 3) == 0 && (((uint64_t)g.n_seq * (uint64_t)g.n_heads * (uint64_t)g.Lq * (uint64_t)Lk) >> 34) == 0;
 
   auto pack4 = [&](const float4& f) {
     uint2 ph;
@@ -245,13 +259,13 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         dot = group_sum<QSLOT>(dot);
         if (cs == 0) {
           delta_s[row] = dot;
-          lse_s[row] = pl[u].x;
+          lse_s[row] = HB ? pl[u].x * LOG2E : pl[u].x;      // HB: the forward's m2 = max * log2e (same rounding as attn_fwd.hip)
           inv_s[row] = pl[u].y;
         }
       }
     }
     __syncthreads();   // (b)
-    if (qb + 1 < nqb) qload(qb + 1);
+    if (qb + 1 < nqb && !ABL(g, 1)) qload(qb + 1);
 
     // ---- (c) S tile and (d) dP tile: rows = queries (registers), column = this lane's key ----
     f32x16 sacc, pacc;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         sacc = mfma32_f32(Qs32[lr * RSQ + HD * lh + t], kf32[t], sacc);
         pacc = mfma32_f32(Os32[lr * RSQ + HD * lh + t], vf32[t], pacc);
       }
-    } else {
+    } else if (!ABL(g, 2)) {
 #pragma unroll
       for (int s = 0; s < KS; s++) {
         const int off = lr * RSQ + 16 * s + 8 * lh;
@@ -272,27 +286,65 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       }
     }
     const bool key_ok = mykey < Lk;
-    // the (wave-uniform) dropout test is hoisted out of the register loop: 16 branches in it kept hipcc from interleaving the rows
-    auto softmax_bwd = [&](auto drop_c) {
-      constexpr bool DROP = decltype(drop_c)::value;
-      const uint64_t ebase = (uint64_t)((sh * Lq + (long)qb * 32 + 4 * lh) * (long)Lk + mykey);
+    // The 16 registers of a lane are 16 query rows: rows 8j + 4*lh + {0,1,2,3} for j = r >> 2 -> one 16-byte LDS read per statistic and j.
+    // The (wave-uniform) dropout test is hoisted out of the register loop: 16 branches in it kept hipcc from interleaving the rows.
+    auto softmax_bwd = [&](auto drop_c, auto pair_c) {
+      constexpr bool DROP = decltype(drop_c)::value, PAIR = decltype(pair_c)::value;
+      const long row0 = sh * Lq + (long)qb * 32 + 4 * lh;                  // element row of register 0
+      const uint64_t ebase = (uint64_t)(row0 * (long)Lk + mykey);
+      // PAIR (quad form): lanes 4i .. 4i+3 hold the four keys of one hash quad and registers 4j .. 4j+3 four adjacent rows.  Lane 4i+a hashes
+      // the quad of row(4j + a); a DPP quad broadcast hands every lane each row's word, of which it takes its own key's byte: one hash per
+      // FOUR elements.
+      const int sub = lane & 3;
+      const uint32_t fsh = 8u * (uint32_t)sub;
+      const uint64_t hk = hftt_hash_key(g.drop_seed, g.drop_site);
+      const uint32_t quarter = (uint32_t)(Lk >> 2);
+      const uint32_t qlo = (uint32_t)(row0 + sub) * quarter + (uint32_t)(mykey >> 2);          // quad index of (row(0) + sub, my key quad): < 2^32 (pair_ok)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int ql_ = acc_row32(r, lh);
-        const float arg = sacc[r] * scale - lse_s[ql_];
-        float p = (F32 ? expf(arg) : __expf(arg)) * inv_s[ql_];
-        if (!key_ok) p = 0.f;
-        float pd = p, dp = pacc[r];
-        if (DROP) {
-          const bool keep = hftt_keep(g.drop_seed, g.drop_site, ebase + (uint64_t)(((r & 3) + 8 * (r >> 2)) * Lk), thr);
-          pd = keep ? p * inv_keep : 0.f;
-          dp = keep ? dp * inv_keep : 0.f;
+      for (int j4 = 0; j4 < 4; j4++) {
+        const float4 m4 = *reinterpret_cast<const float4*>(lse_s + 8 * j4 + 4 * lh);
+        const float4 i4 = *reinterpret_cast<const float4*>(inv_s + 8 * j4 + 4 * lh);
+        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 8 * j4 + 4 * lh);
+        const float rs_m[4] = {m4.x, m4.y, m4.z, m4.w}, rs_i[4] = {i4.x, i4.y, i4.z, i4.w}, rs_d[4] = {d4.x, d4.y, d4.z, d4.w};
+        float m_[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP && PAIR) {
+          const uint32_t w = hftt_hash_mix(hk, qlo + (uint32_t)(8 * j4) * quarter, 0u);      // row(4*j4) - row(0) = 8*j4 rows
+          const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x00, 0xF, 0xF, true);   // quad_perm [0,0,0,0]: row(4j+0)'s word
+          const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x55, 0xF, 0xF, true);   // [1,1,1,1]
+          const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xAA, 0xF, 0xF, true);   // [2,2,2,2]
+          const uint32_t w3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xFF, 0xF, 0xF, true);   // [3,3,3,3]
+          m_[0] = ((w0 >> fsh) & 0xFFu) < thr ? inv_keep : 0.f;
+          m_[1] = ((w1 >> fsh) & 0xFFu) < thr ? inv_keep : 0.f;
+          m_[2] = ((w2 >> fsh) & 0xFFu) < thr ? inv_keep : 0.f;
+          m_[3] = ((w3 >> fsh) & 0xFFu) < thr ? inv_keep : 0.f;
         }
-        sacc[r] = pd;                                        // dropped probabilities (for dV)
-        pacc[r] = p * (dp - delta_s[ql_]) * scale;           // dS (scaled): for dK, dQ
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = 4 * j4 + e;
+          float p;
+          if (HB) p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -rs_m[e])) * rs_i[e];
+          else {
+            const float arg = sacc[r] * scale - rs_m[e];
+            p = (F32 ? expf(arg) : __expf(arg)) * rs_i[e];
+          }
+          if (!key_ok) p = 0.f;
+          float pd = p, dp = pacc[r];
+          if (DROP) {
+            float m;
+            if (PAIR) m = m_[e];
+            else m = hftt_keep(g.drop_seed, g.drop_site, ebase + (uint64_t)((e + 8 * j4) * Lk), thr) ? inv_keep : 0.f;
+            pd = p * m;
+            dp = dp * m;
+          }
+          sacc[r] = pd;                                        // dropped probabilities (for dV)
+          pacc[r] = p * (dp - rs_d[e]) * scale;                // dS (scaled): for dK, dQ
+        }
       }
     };
-    if (g.drop_p > 0.f) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
+    if (ABL(g, 4)) {
+    } else if (g.drop_p > 0.f && !ABL(g, 8)) {
+      if (pair_ok) softmax_bwd(std::true_type{}, std::true_type{}); else softmax_bwd(std::true_type{}, std::false_type{});
+    } else softmax_bwd(std::false_type{}, std::false_type{});
     // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS ----
     if (F32) {
 #pragma unroll
@@ -304,7 +356,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
           dKT[n] = mfma32_f32(Qs32[qrow * RSQ + n * 32 + lr], pacc[r], dKT[n]);
         }
       }
-    } else {
+    } else if (!ABL(g, 16)) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++) {
         bf16x8 ph, sh_;
@@ -322,7 +374,8 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       }
     }
     // ---- (g) dS -> LDS [query][key] ----
-    if (F32) {
+    if (ABL(g, 32)) {
+    } else if (F32) {
 #pragma unroll
       for (int r = 0; r < 16; r++) Ss32[acc_row32(r, lh) * RSS + wave * 32 + lr] = pacc[r];
     } else {
@@ -338,7 +391,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
 
     // ---- (i) dQ block = dS . K with 16x16 tiles spread over the waves ----
     constexpr int CT = DH / 16;
-    for (int t = wave; t < 2 * CT; t += KT) {
+    for (int t = wave; t < 2 * CT && !ABL(g, 32); t += KT) {
       const int qh2 = t / CT, ct = t % CT;
       f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
       if (F32) {
@@ -378,7 +431,46 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   }
 
   // ---- epilogue: dK, dV (this wave's 32 keys) ----
-  if (mykey < Lk) {
+  if (!F32 && dkv_bf) {
+    // bf16 gradients leave through LDS: the accumulators hold, per lane, 4 consecutive head-dim elements of ONE key row, so a direct store
+    // is 8 bytes per lane into 32 different rows per instruction.  Written row-major into the wave's own LDS patch and read back as 16 bytes
+    // per lane, eight lanes cover the 128-byte row segment of this head: whole sectors per instruction (the scattered form wrote up to 2.7x
+    // the bytes to HBM on the [S, 2d] cross-attention layout, whose 1 KB row pitch defeats the L2's write combining).
+    constexpr int RSE = DH + 8;
+    __syncthreads();                                           // every wave is done with the K / Q / dO / dS images
+    unsigned short* ek = reinterpret_cast<unsigned short*>(smem) + wave * (2 * 32 * RSE);
+    unsigned short* ev = ek + 32 * RSE;
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int dh0 = n * 32 + 8 * c + 4 * lh;
+        *reinterpret_cast<uint2*>(ek + lr * RSE + dh0) = pack4(make_float4(dKT[n][4 * c], dKT[n][4 * c + 1], dKT[n][4 * c + 2], dKT[n][4 * c + 3]));
+        *reinterpret_cast<uint2*>(ev + lr * RSE + dh0) = pack4(make_float4(dVT[n][4 * c], dVT[n][4 * c + 1], dVT[n][4 * c + 2], dVT[n][4 * c + 3]));
+      }
+    __syncthreads();
+    constexpr int CPR = DH / 8;                                // 16-byte chunks per row
+    constexpr int RPP = 64 / CPR;                              // rows per pass of the wave
+    unsigned short* dkp = reinterpret_cast<unsigned short*>(g.dk) + (long)seq * g.dk_seq_stride + head * DH;
+    unsigned short* dvp = reinterpret_cast<unsigned short*>(g.dv) + (long)seq * g.dv_seq_stride + head * DH;
+    const bool wide_ok = !ABL(g, 64) && (g.lddk % 8 == 0) && (g.lddv % 8 == 0) && (g.dk_seq_stride % 8 == 0) && (g.dv_seq_stride % 8 == 0) &&
+                         ((((uintptr_t)g.dk | (uintptr_t)g.dv) & 15) == 0);
+#pragma unroll
+    for (int ps = 0; ps < 32 / RPP; ps++) {
+      const int row = ps * RPP + lane / CPR, ch = lane % CPR;
+      const int key = wave * 32 + row;
+      if (key < Lk && wide_ok) {
+        *reinterpret_cast<uint4*>(dkp + (long)key * g.lddk + ch * 8) = *reinterpret_cast<const uint4*>(ek + row * RSE + ch * 8);
+        *reinterpret_cast<uint4*>(dvp + (long)key * g.lddv + ch * 8) = *reinterpret_cast<const uint4*>(ev + row * RSE + ch * 8);
+      } else if (key < Lk && !ABL(g, 64)) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          dkp[(long)key * g.lddk + ch * 8 + e] = ek[row * RSE + ch * 8 + e];
+          dvp[(long)key * g.lddv + ch * 8 + e] = ev[row * RSE + ch * 8 + e];
+        }
+      }
+    }
+  } else if (mykey < Lk && !ABL(g, 64)) {
     const long dkofs = (long)seq * g.dk_seq_stride + (long)mykey * g.lddk + head * DH;
     const long dvofs = (long)seq * g.dv_seq_stride + (long)mykey * g.lddv + head * DH;
 #pragma unroll
@@ -419,9 +511,15 @@ int dispatch_ab(const hftt_attn_desc& d, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int hftt_attn_bwd(const hftt_attn_desc* d, void* stream) {
-  int rc = hftt_attn_check(d, true);
+extern "C" int hftt_attn_bwd(const hftt_attn_desc* d0, void* stream) {
+  int rc = hftt_attn_check(d0, true);
   if (rc) return rc;
+  hftt_attn_desc dd = *d0;
+  dd.pad = 0;
+#ifdef HFTT_ATTN_ABLATE
+  if (const char* e = getenv("HFTT_ATTN_ABLATE")) dd.pad = (uint32_t)atoi(e);
+#endif
+  const hftt_attn_desc* d = &dd;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
   const bool hb = (d->io_flags & all_half) == all_half && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 8 == 0 &&

@@ -12,6 +12,16 @@
 #include "../../include/hftt_hip.h"
 #include <math.h>
 
+// Ablation build (tools/ablate_attn.sh compiles this file with -DHFTT_ATTN_ABLATE into its own library): the descriptor's pad field
+// (from HFTT_ATTN_ABLATE in the environment) switches single mechanisms off, so that their cost can be read from the timing difference
+// (results are then garbage).   1 no K/V staging loads   2 no QK^T MFMAs   4 no softmax arithmetic   8 no dropout   16 no PV MFMAs
+// 32 no output / statistics stores
+#ifdef HFTT_ATTN_ABLATE
+#define ABL(g, bit) (((g).pad & (bit)) != 0)
+#else
+#define ABL(g, bit) false
+#endif
+
 namespace {
 
 // npass == 1: K/V as bf16 planes (layout notes below).  npass == 3 (parity): K/V stay fp32 in LDS and every product runs on
@@ -52,11 +62,25 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
   const int Lq = g.Lq, Lk = g.Lk;
   const bool q_bf = !F32 && (g.io_flags & HFTT_ATTN_Q_BF16), kv_bf = !F32 && (g.io_flags & HFTT_ATTN_KV_BF16), o_bf = !F32 && (g.io_flags & HFTT_ATTN_O_BF16);
 
+  // HB: the Q fragments of a wave's NEXT query block are fetched while the current one is computed (the first block's before the K/V staging):
+  // a workgroup lives for two blocks per wave, so a load waited for at its point of use is exposed in full every time
+  bf16x8 qn[HB ? DH / 16 : 1];
+  auto q_prefetch = [&](int qb) {
+    if (HB) {
+      const int qr = qb * 32 + lr;
+      const int qc = qr < Lq ? qr : Lq - 1;            // clamped: the loads are unconditional (a block past the end re-reads the last row)
+      const unsigned short* p = reinterpret_cast<const unsigned short*>(g.q) + (long)seq * g.q_seq_stride + (long)qc * g.ldq + head * DH + 8 * lh;
+#pragma unroll
+      for (int s = 0; s < DH / 16; s++) qn[s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+    }
+  };
+  q_prefetch(wave);
   // ---- stage K and V of this (seq, head) into LDS: 8 + 8 x 16 B loads in flight per thread, then convert + store ----
   {
     const long kofs = (long)seq * g.k_seq_stride + head * DH;      // element offsets (the tensors may be fp32 or bf16)
     const long vofs = (long)seq * g.v_seq_stride + head * DH;
-    if (HB) {
+    if (ABL(g, 1)) {
+    } else if (HB) {
       constexpr int S8R = DH / 8;                    // 16-byte slots (8 bf16) per key row
       constexpr int TOTAL8 = LKP * S8R;
       constexpr int UB8 = (TOTAL8 / 256) < 8 ? ((TOTAL8 / 256) < 1 ? 1 : (TOTAL8 / 256)) : 8;
@@ -126,6 +150,8 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
   const int nqb = (Lq + 31) / 32;
   const bool vec_probs = (Lk % 4) == 0;
+  const uint64_t hk = hftt_hash_key(g.drop_seed, g.drop_site);
+  const bool quad_ok = (Lk & 3) == 0 && (((uint64_t)g.n_seq * (uint64_t)g.n_heads * (uint64_t)Lq * (uint64_t)Lk) >> 34) == 0;
 
   for (int qb = wave; qb < nqb; qb += 4) {
     const int qrow = qb * 32 + lr;                     // this lane's query (as the B-operand column)
@@ -154,8 +180,8 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
       bf16x8 qh[KS];
       if (HB) {
 #pragma unroll
-        for (int s = 0; s < KS; s++)
-          qh[s] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(g.q) + qofs + 16 * s + 8 * lh);   // unscaled: scores are scaled below
+        for (int s = 0; s < KS; s++) qh[s] = qn[s];      // unscaled: the scale is folded into the exponent below
+        q_prefetch(qb + 4);
       } else
 #pragma unroll
       for (int s = 0; s < KS; s++) {
@@ -165,6 +191,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
 #pragma unroll
         for (int e = 0; e < 8; e++) qh[s][e] = (short)f2bf(v[e] * scale);
       }
+      if (!ABL(g, 2))
 #pragma unroll
       for (int kt = 0; kt < KT; kt++)
 #pragma unroll
@@ -172,58 +199,95 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
           sacc[kt] = mfma32(lds_read_b128(Ks16 + (kt * 32 + lr) * RSK + 16 * s + 8 * lh), qh[s], sacc[kt]);
     }
     // ---- softmax over keys (register-local + one cross-half exchange) ----
+    // HB: the maximum is taken over the RAW scores (scale > 0 keeps the order) and the scale is folded with log2(e) into the one FMA
+    // in front of v_exp_f32:  p = 2^(s*c2 - m2), c2 = scale*log2e, m2 = (max*scale)*log2e.  The backward forms m2 from the stored max with
+    // the same two roundings, so it recomputes bitwise the same P.
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c2 = scale * LOG2E;
+    // 4*lh as a value the optimiser cannot see through: every per-register key number below is then (compile-time constant + lh4) formed
+    // where it is used.  Left visible, LICM hoists all KT*16 of them (and their 64-bit forms) out of the query-block loop and spills them.
+    int lh4 = 4 * lh;
+    asm volatile("" : "+v"(lh4));
     float mx = -INFINITY;
+    if (!ABL(g, 4)) {
+    if (Lk < LKP) {                                   // (wave-uniform) key padding of the last tile
+      const int lkm = Lk - lh4;
+#pragma unroll
+      for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (kt * 32 + (r & 3) + 8 * (r >> 2) >= lkm) sacc[kt][r] = -INFINITY;
+    }
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = kt * 32 + acc_row32(r, lh);
-        if (HB) sacc[kt][r] *= scale;
-        if (key >= Lk) sacc[kt][r] = -INFINITY;
-        mx = fmaxf(mx, sacc[kt][r]);
-      }
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
     mx = xor32_max(mx);
+    if (HB) mx *= scale;                              // the row maximum in natural units (what lse[0] holds in every mode)
+    }
     float sum = 0.f;
+    if (!ABL(g, 4)) {
+    const float m2 = mx * LOG2E;
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const float p = F32 ? expf(sacc[kt][r] - mx) : __expf(sacc[kt][r] - mx);
+        const float p = HB ? __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c2, -m2)) : (F32 ? expf(sacc[kt][r] - mx) : __expf(sacc[kt][r] - mx));
         sacc[kt][r] = p;
         sum += p;
       }
     sum = xor32_sum(sum);
-    const float inv = 1.0f / sum;
-    if (lh == 0 && qrow < Lq) {      // row statistics for the backward recompute: P = exp(s - max) * inv  (bitwise the forward P)
+    }
+    const float inv = ABL(g, 4) ? 1.0f : 1.0f / sum;
+    if (lh == 0 && qrow < Lq && !ABL(g, 32)) {      // row statistics for the backward recompute: P = exp(s - max) * inv  (bitwise the forward P)
       float* st = g.lse + (((long)seq * g.n_heads + head) * Lq + qrow) * 2;
       st[0] = mx; st[1] = inv;
     }
 
     const long prow = (((long)seq * g.n_heads + head) * Lq + qrow) * (long)Lk;   // element index base of this query's row
+    // Normalisation and dropout in one multiply: kept elements are scaled by inv / (1 - p), dropped ones become zero.
+    // Registers 4c..4c+3 of a lane are four CONSECUTIVE keys of its row, starting at a multiple of 4; with Lk % 4 == 0 the row starts at such
+    // an element index too, so the four are one hash quad (hftt_keep: byte idx&3 of hash(idx>>2)).  `quad_ok` also asks that no quad index
+    // of this launch reaches 2^32 (the high word is then zero and is not mixed); otherwise every element takes the general form.
+    // (The branches stay inside the (kt, c) loop: arms that rewrite the whole tile make hipcc keep two copies of it and spill.)
+    const float nrm = (g.probs != nullptr) ? inv_keep : inv * inv_keep;
+    const uint32_t q0lo = (uint32_t)((uint64_t)prow >> 2) + (uint32_t)(lh4 >> 2);     // quad index of this lane's first key (register 0)
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
 #pragma unroll
       for (int c = 0; c < 4; c++) {
-        float p4[4];
+        const int key0 = kt * 32 + 8 * c + lh4;
+        if (g.probs != nullptr) {    // (wave-uniform) the attention map is an output: normalise, store, then drop
+          float p4[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) p4[e] = sacc[kt][4 * c + e] * inv;
-        const int key0 = kt * 32 + 8 * c + 4 * lh;
-        if (g.probs != nullptr && qrow < Lq) {
-          if (vec_probs && key0 + 3 < Lk) {
-            *reinterpret_cast<float4*>(g.probs + prow + key0) = make_float4(p4[0], p4[1], p4[2], p4[3]);
+          for (int e = 0; e < 4; e++) { p4[e] = sacc[kt][4 * c + e] * inv; sacc[kt][4 * c + e] = p4[e]; }
+          if (qrow < Lq) {
+            if (vec_probs && key0 + 3 < Lk) {
+              *reinterpret_cast<float4*>(g.probs + prow + key0) = make_float4(p4[0], p4[1], p4[2], p4[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; e++)
+                if (key0 + e < Lk) g.probs[prow + key0 + e] = p4[e];
+            }
+          }
+        }
+        if (g.drop_p > 0.f && !ABL(g, 8)) {        // (wave-uniform)
+          if (quad_ok) {
+            const uint32_t w = hftt_hash_mix(hk, q0lo + (uint32_t)(kt * 8 + 2 * c), 0u);      // keys kt*32 + 8c + 4lh + {0..3}
+            const float a0 = sacc[kt][4 * c], a1 = sacc[kt][4 * c + 1], a2 = sacc[kt][4 * c + 2], a3 = sacc[kt][4 * c + 3];
+            sacc[kt][4 * c] = (w & 0xFFu) < thr ? a0 * nrm : 0.f;
+            sacc[kt][4 * c + 1] = ((w >> 8) & 0xFFu) < thr ? a1 * nrm : 0.f;
+            sacc[kt][4 * c + 2] = ((w >> 16) & 0xFFu) < thr ? a2 * nrm : 0.f;
+            sacc[kt][4 * c + 3] = (w >> 24) < thr ? a3 * nrm : 0.f;
           } else {
 #pragma unroll
             for (int e = 0; e < 4; e++)
-              if (key0 + e < Lk) g.probs[prow + key0 + e] = p4[e];
+              sacc[kt][4 * c + e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(prow + key0 + e), thr) ? sacc[kt][4 * c + e] * nrm : 0.f;
           }
-        }
-        if (g.drop_p > 0.f) {        // (wave-uniform; hoisting it out of the loop lets hipcc overlap 128 hash chains and spill)
+        } else if (g.probs == nullptr) {
 #pragma unroll
-          for (int e = 0; e < 4; e++)
-            p4[e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(prow + key0 + e), thr) ? p4[e] * inv_keep : 0.f;
+          for (int e = 0; e < 4; e++) sacc[kt][4 * c + e] *= inv;
         }
-#pragma unroll
-        for (int e = 0; e < 4; e++) sacc[kt][4 * c + e] = p4[e];
       }
     }
     // ---- out = P . V  (probability tile reused as the A operand; keys are the reduction index) ----
@@ -250,6 +314,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
           bf16x8 xh;
 #pragma unroll
           for (int e = 0; e < 8; e++) xh[e] = (short)f2bf(sacc[kt][8 * s2 + e]);
+          if (!ABL(g, 16))
 #pragma unroll
           for (int n = 0; n < NT; n++) {
             const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
@@ -261,7 +326,8 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
       }
     }
     const long oofs = (long)seq * g.o_seq_stride + head * DH;
-    if (HB) {
+    if (ABL(g, 32)) {
+    } else if (HB) {
       // lanes 2i / 2i+1 hold adjacent columns: exchange so that each lane stores one packed pair (4 bytes) per register pair
       unsigned short* op = reinterpret_cast<unsigned short*>(g.out) + oofs;
       const bool odd = lane & 1;
@@ -333,9 +399,15 @@ int hftt_attn_check(const hftt_attn_desc* d, bool bwd) {
   return 0;
 }
 
-extern "C" int hftt_attn_fwd(const hftt_attn_desc* d, void* stream) {
-  int rc = hftt_attn_check(d, false);
+extern "C" int hftt_attn_fwd(const hftt_attn_desc* d0, void* stream) {
+  int rc = hftt_attn_check(d0, false);
   if (rc) return rc;
+  hftt_attn_desc dd = *d0;
+  dd.pad = 0;
+#ifdef HFTT_ATTN_ABLATE
+  if (const char* e = getenv("HFTT_ATTN_ABLATE")) dd.pad = (uint32_t)atoi(e);
+#endif
+  const hftt_attn_desc* d = &dd;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
   const bool hb = (d->io_flags & all_half) == all_half && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 2 == 0 &&

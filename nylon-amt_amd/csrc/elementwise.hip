@@ -276,16 +276,13 @@ __global__ void time_embed_bwd_kernel(const float* __restrict__ dy, float* __res
 __global__ void dropout_bwd_kernel(float* __restrict__ gbuf, long n, float drop_p, uint32_t site, uint64_t seed, uint32_t bf) {
   const uint32_t thr = hftt_keep_thr(drop_p);
   const float inv_keep = 1.0f / (1.0f - drop_p);
-  const long n4 = n >> 2;                          // n % 4 == 0 (host check): 4 consecutive elements = 2 hash pairs per thread
+  const long n4 = n >> 2;                          // n % 4 == 0 (host check): 4 consecutive elements = one hash quad per thread
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const float4 a = hftt_load4(gbuf, bf, i * 4);
     float v[4] = {a.x, a.y, a.z, a.w};
+    const uint32_t k4 = hftt_keep_quad(seed, site, (uint64_t)i, thr);
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-      const uint32_t k2 = hftt_keep_pair(seed, site, (uint64_t)(i * 2 + e), thr);
-      v[2 * e] = (k2 & 1u) ? v[2 * e] * inv_keep : 0.f;
-      v[2 * e + 1] = (k2 & 2u) ? v[2 * e + 1] * inv_keep : 0.f;
-    }
+    for (int e = 0; e < 4; e++) v[e] = ((k4 >> e) & 1u) ? v[e] * inv_keep : 0.f;
     hftt_store4(gbuf, bf, i * 4, v[0], v[1], v[2], v[3]);
   }
 }

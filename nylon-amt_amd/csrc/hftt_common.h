@@ -100,39 +100,49 @@ __device__ __forceinline__ void hftt_store1(float* base, bool bf, long off, floa
 }
 
 // ---- counter-based dropout RNG: keep(seed, site, element index) -- identical in forward and backward ----
-__device__ __forceinline__ uint32_t hftt_hash(uint64_t seed, uint32_t site, uint64_t idx) {
-  // key: one splitmix64 round over (seed, site) -- wave-uniform, so it runs on the scalar ALU once per kernel
+// key: one splitmix64 round over (seed, site) -- wave-uniform, so it runs on the scalar ALU once per kernel
+__device__ __forceinline__ uint64_t hftt_hash_key(uint64_t seed, uint32_t site) {
   uint64_t k = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1u);
   k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull;
   k ^= k >> 27; k *= 0x94D049BB133111EBull;
   k ^= k >> 31;
-  // per element: a 32-bit two-multiply mixer (64-bit multiplies cost ~4x on the vector ALU and the dropout sites hash
-  // ~2e9 elements per paper-size step); the high index word only matters beyond 2^32 elements per site
-  const uint32_t hi = (uint32_t)(idx >> 32);
-  uint32_t x = ((uint32_t)idx + (uint32_t)k) ^ (hi ^ (hi << 16));
+  return k;
+}
+// the high index word's contribution (it only matters beyond 2^32 hashed indices per site): hoistable when a loop walks the low word
+__device__ __forceinline__ uint32_t hftt_hash_himix(uint32_t hi) { return hi ^ (hi << 16); }
+// per index: a 32-bit two-multiply mixer (64-bit multiplies cost ~4x on the vector ALU and the dropout sites hash ~2e9 elements
+// per paper-size step; even v_mul_lo_u32 is a quarter-rate instruction, which is why kernels share one hash between two elements)
+__device__ __forceinline__ uint32_t hftt_hash_mix(uint64_t k, uint32_t lo, uint32_t himix) {
+  uint32_t x = (lo + (uint32_t)k) ^ himix;
   x ^= x >> 16; x *= 0x7FEB352Du;
   x ^= x >> 15; x ^= (uint32_t)(k >> 32); x *= 0x846CA68Bu;
   x ^= x >> 16;
   return x;
 }
-// One 32-bit hash serves TWO consecutive elements (2q, 2q+1): each gets a 16-bit field compared with a 16-bit threshold, so
-// the keep probability is quantised to 1/65536 (p = 0.1 -> 0.100006).  keep(idx) = field(idx & 1) of hash(idx >> 1) < thr.
-// Kernels whose lanes own adjacent elements hash once per pair (hftt_keep_pair); every other site calls hftt_keep per element
+__device__ __forceinline__ uint32_t hftt_hash(uint64_t seed, uint32_t site, uint64_t idx) {
+  return hftt_hash_mix(hftt_hash_key(seed, site), (uint32_t)idx, hftt_hash_himix((uint32_t)(idx >> 32)));
+}
+// One 32-bit hash serves FOUR consecutive elements (4q .. 4q+3): each takes one BYTE of the word, compared with an 8-bit threshold
+//   keep(idx) = byte (idx & 3) of hash(idx >> 2) < thr,   thr = round((1 - p) * 256)
+// so the keep probability is quantised to 1/256 (p = 0.1 -> thr 230, drop rate 0.1016).  Kept elements are still scaled by 1 / (1 - p), the
+// reference's nn.Dropout factor: the expected value of a dropped tensor is thr / 256 / (1 - p) of the input (0.9983 at p = 0.1; exact
+// whenever (1 - p) * 256 is an integer, e.g. p = 0.25, 0.5).  v_mul_lo_u32 issues at quarter rate, so the two multiplies of the mixer
+// are most of a hash: kernels whose lanes own adjacent elements hash once per quad; every other site calls hftt_keep per element
 // and gets the same decisions.
 __host__ __device__ inline uint32_t hftt_keep_thr(float p) {
-  double k = (1.0 - (double)p) * 65536.0;
-  if (k >= 65536.0) return 65536u;
+  double k = (1.0 - (double)p) * 256.0 + 0.5;
+  if (k >= 256.0) return 256u;
   if (k <= 0.0) return 0u;
   return (uint32_t)k;
 }
 __device__ __forceinline__ bool hftt_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr) {
-  const uint32_t w = hftt_hash(seed, site, idx >> 1);
-  return ((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) < thr;
+  const uint32_t w = hftt_hash(seed, site, idx >> 2);
+  return ((w >> (8u * ((uint32_t)idx & 3u))) & 0xFFu) < thr;
 }
-// both decisions of the pair (2q, 2q+1), q = pair index: bit 0 = keep(2q), bit 1 = keep(2q+1)
-__device__ __forceinline__ uint32_t hftt_keep_pair(uint64_t seed, uint32_t site, uint64_t q, uint32_t thr) {
+// the four decisions of the quad (4q .. 4q+3): bit e = keep(4q + e)
+__device__ __forceinline__ uint32_t hftt_keep_quad(uint64_t seed, uint32_t site, uint64_t q, uint32_t thr) {
   const uint32_t w = hftt_hash(seed, site, q);
-  return ((w & 0xFFFFu) < thr ? 1u : 0u) | ((w >> 16) < thr ? 2u : 0u);
+  return ((w & 0xFFu) < thr ? 1u : 0u) | (((w >> 8) & 0xFFu) < thr ? 2u : 0u) | (((w >> 16) & 0xFFu) < thr ? 4u : 0u) | ((w >> 24) < thr ? 8u : 0u);
 }
 
 // ---- cross-lane traffic without the LDS crossbar ----------------------------------------------------------------

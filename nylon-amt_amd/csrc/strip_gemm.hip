@@ -156,17 +156,20 @@ __device__ __forceinline__ void lds16f(const float* p, float* v) {
 }
 // dropout on 16 consecutive elements whose first element index is 2*q0 (even): one hash per pair
 __device__ __forceinline__ void drop16(float* v, uint64_t seed, uint32_t site, uint64_t q0, uint32_t thr, float inv_keep) {
+  // q0 = (index of the first element) / 4: the 16 elements are four hash quads (hftt_keep: byte idx&3 of hash(idx>>2) < thr)
 #pragma unroll
-  for (int e = 0; e < 8; e++) {
+  for (int e = 0; e < 4; e++) {
     const uint32_t w = hftt_hash(seed, site, q0 + e);
-    // field < thr as an arithmetic mask (sign of field - thr).  A compare + select per element parks one SGPR pair per decision
-    // and hipcc hoists all 64 pairs of an epilogue: the scalar file spilled (231 SGPRs).  The shift is inline asm because
-    // instcombine turns (x - thr) >> 31 back into that compare.
-    uint32_t m0, m1;
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m0) : "v"((w & 0xFFFFu) - thr));
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m1) : "v"((w >> 16) - thr));
-    v[2 * e] = __uint_as_float(__float_as_uint(v[2 * e] * inv_keep) & m0);
-    v[2 * e + 1] = __uint_as_float(__float_as_uint(v[2 * e + 1] * inv_keep) & m1);
+    // byte < thr as an arithmetic mask (sign of byte - thr).  A compare + select per element parks one SGPR pair per decision and hipcc
+    // hoists all 64 pairs of an epilogue: the scalar file spilled (231 SGPRs).  The shift is inline asm because instcombine turns
+    // (x - thr) >> 31 back into that compare.
+    uint32_t m[4];
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[0]) : "v"((w & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[1]) : "v"(((w >> 8) & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[2]) : "v"(((w >> 16) & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[3]) : "v"((w >> 24) - thr));
+#pragma unroll
+    for (int f = 0; f < 4; f++) v[4 * e + f] = __uint_as_float(__float_as_uint(v[4 * e + f] * inv_keep) & m[f]);
   }
 }
 
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
     // ---------------- epilogue of this pass ----------------
     if (!LN) { if (pass == 0) STAMP(g, 2); else if (pass == 1) STAMP(g, 4); else STAMP(g, 6); }
     const bool relu = g.flags & HFTT_SL_RELU;
-    const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 1;        // pair index of (row, col 0); N is even
+    const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;        // quad index of (row, col 0); N % 4 == 0
     if (LN) {
 #pragma unroll
       for (int ot = 0; ot < 8; ot++) {
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
         float v[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = acc[ot][q] * g.out_scale;
-        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 1), thr, inv_keep);
+        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 2), thr, inv_keep);
         if (g.residual != nullptr) {
           float r[16];
           load16(g.residual, res_bf, rrow * g.ldr + col0, r);
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
 #pragma unroll
           for (int q = 0; q < 16; q++) v[q] = gt[q] > 0.f ? v[q] * g.gate_scale : 0.f;
         }
-        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 1), thr, inv_keep);
+        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 2), thr, inv_keep);
         if (g.residual != nullptr) {
           float r[16];
           load16(g.residual, res_bf, rrow * g.ldr + col0, r);
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
   const unsigned char* abase = smem + lane * 16;
-  const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)g.p) >> 1;
+  const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)g.p) >> 2;
 
   f32x16 yacc[8];
   uint4 gnext[2];                                    // mode 1: stored hidden of the next tile (the ReLU / dropout gate)
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
       if (MODE == 0) {
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = fmaxf(hacc[q], 0.f);
-        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 1), thr, inv_keep);
+        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 2), thr, inv_keep);
       } else {
         float gt[16];
         unpack8(gcur[0], gt); unpack8(gcur[1], gt + 8);
@@ -523,14 +526,14 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
   }
 
   // ---------------- final epilogue ----------------
-  const uint64_t rowq = ((uint64_t)tok * 256ull) >> 1;
+  const uint64_t rowq = ((uint64_t)tok * 256ull) >> 2;
 #pragma unroll
   for (int ot = 0; ot < 8; ot++) {
     const int col0 = ot * 32 + 16 * h;
     float v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = yacc[ot][q];
-    if (MODE == 0 && g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_o, rowq + (col0 >> 1), thr, inv_keep);
+    if (MODE == 0 && g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_o, rowq + (col0 >> 2), thr, inv_keep);
     if (g.residual != nullptr) {
       float r[16];
       load16(g.residual, res_bf, tokc * g.ldr + col0, r);

@@ -111,14 +111,20 @@ __device__ __forceinline__ void lds16f(const float* p, float* v) {
   for (int q = 0; q < 4; q++) { const float4 t = reinterpret_cast<const float4*>(p)[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
 }
 __device__ __forceinline__ void drop16(float* v, uint64_t seed, uint32_t site, uint64_t q0, uint32_t thr, float inv_keep) {
+  // q0 = (index of the first element) / 4: the 16 elements are four hash quads (hftt_keep: byte idx&3 of hash(idx>>2) < thr)
 #pragma unroll
-  for (int e = 0; e < 8; e++) {
+  for (int e = 0; e < 4; e++) {
     const uint32_t w = hftt_hash(seed, site, q0 + e);
-    uint32_t m0, m1;                                  // sign of (field - thr) as a mask (see strip_gemm.hip: no SGPR pair per decision)
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m0) : "v"((w & 0xFFFFu) - thr));
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m1) : "v"((w >> 16) - thr));
-    v[2 * e] = __uint_as_float(__float_as_uint(v[2 * e] * inv_keep) & m0);
-    v[2 * e + 1] = __uint_as_float(__float_as_uint(v[2 * e + 1] * inv_keep) & m1);
+    // byte < thr as an arithmetic mask (sign of byte - thr).  A compare + select per element parks one SGPR pair per decision and hipcc
+    // hoists all 64 pairs of an epilogue: the scalar file spilled (231 SGPRs).  The shift is inline asm because instcombine turns
+    // (x - thr) >> 31 back into that compare.
+    uint32_t m[4];
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[0]) : "v"((w & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[1]) : "v"(((w >> 8) & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[2]) : "v"(((w >> 16) & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[3]) : "v"((w >> 24) - thr));
+#pragma unroll
+    for (int f = 0; f < 4; f++) v[4 * e + f] = __uint_as_float(__float_as_uint(v[4 * e + f] * inv_keep) & m[f]);
   }
 }
 __device__ __forceinline__ bf16x8 as_frag(const u4v& u) { return __builtin_bit_cast(bf16x8, u); }
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
         });
       }
       // ---------------- epilogue of this pass: results into the pending registers ----------------
-            const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 1;
+            const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;
 #pragma unroll
       for (int ot = 0; ot < 8; ot++) {
         const int col0 = pass * 256 + ot * 32 + 16 * hb;
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
           if (!LN && relu) t = fmaxf(t, 0.f);
           v[q] = t * g.out_scale;
         }
-        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 1), thr, inv_keep);
+        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 2), thr, inv_keep);
         if (has_res) {
           float r[16];
           unpack8(pend[2 * ot], r); unpack8(pend[2 * ot + 1], r + 8);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
     const long tokn = has_next ? tok_of(nxt) : tokc;
     const unsigned short* xrow_next = xb + tokn * g.ldx + 16 * hb;
     const unsigned short* res_src = rb + (has_res ? tokc * g.ldr + 16 * hb : 0);
-    const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)p) >> 1;
+    const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)p) >> 2;
     int zero = 0;                                     // (keeps the LDS parameter reads inside the iteration: see strip_linear2_kernel)
     asm volatile("" : "+s"(zero));
     const float* prm_b = prm + zero;
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
       if (MODE == 0) {
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = fmaxf(hacc[q], 0.f);
-        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 1), thr, inv_keep);
+        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 2), thr, inv_keep);
       } else {
         float gv[16];
         unpack8(gt[t & 3][0], gv); unpack8(gt[t & 3][1], gv + 8);
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
     });
 
     // ---------------- final epilogue of the block ----------------
-        const uint64_t rowq = ((uint64_t)tok * 256ull) >> 1;
+        const uint64_t rowq = ((uint64_t)tok * 256ull) >> 2;
     unsigned short* yrow = yb + tok * g.ldy + 16 * hb;
 #pragma unroll
     for (int ot = 0; ot < 8; ot++) {
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
       float v[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) v[q] = yacc[ot][q];
-      if (MODE == 0 && g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_o, rowq + (col0 >> 1), thr, inv_keep);
+      if (MODE == 0 && g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_o, rowq + (col0 >> 2), thr, inv_keep);
       float r[16];
       if (MODE == 0 || has_res) {                     // mode 0: residual = the block input, still in xf; mode 1: just fetched into xf
         unpack8(xf[2 * ot], r); unpack8(xf[2 * ot + 1], r + 8);

@@ -250,11 +250,17 @@ def attn_fwd(q, k, v, n_heads, npass=3, want_probs=False, drop_p=0.0, drop_site=
     return (out, lse, probs) if want_probs else (out, lse)
 
 
-def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0, drop_seed=0, dq_dtype=torch.float32, dkv_dtype=torch.float32):
+def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0, drop_seed=0, dq_dtype=torch.float32, dkv_dtype=torch.float32,
+             grads_out=None):
+    """grads_out = (dq, dk, dv): preallocated (possibly strided, e.g. interleaved [S, 3d]) gradient tensors to write into."""
     _need_cuda(q, k, v, out, dout)
-    dq = torch.empty(q.shape, device=q.device, dtype=dq_dtype)
-    dk = torch.empty(k.shape, device=q.device, dtype=dkv_dtype)
-    dv = torch.empty(v.shape, device=q.device, dtype=dkv_dtype)
+    if grads_out is not None:
+        dq, dk, dv = grads_out
+        dq_dtype, dkv_dtype = dq.dtype, dk.dtype
+    else:
+        dq = torch.empty(q.shape, device=q.device, dtype=dq_dtype)
+        dk = torch.empty(k.shape, device=q.device, dtype=dkv_dtype)
+        dv = torch.empty(v.shape, device=q.device, dtype=dkv_dtype)
     d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed)
     d.out, d.o_seq_stride, d.ldo = out.data_ptr(), out.stride(0), out.stride(1)
     d.lse = lse.data_ptr()

@@ -66,7 +66,7 @@ def sd_cpu(model):
 # ---- numpy emulation of the device dropout RNG (csrc/hftt_common.h: hftt_hash / hftt_keep_thr) ----
 def keep_mask(seed, site, idx, p):
     """numpy emulation of hftt_hash / hftt_keep (csrc/hftt_common.h): splitmix64 key over (seed, site), one 32-bit mixer per
-    PAIR of elements (idx >> 1); element idx takes the low (even) or high (odd) 16-bit field, compared with (1-p)*65536."""
+    QUAD of elements (idx >> 2); element idx takes byte (idx & 3) of the word, compared with round((1-p)*256)."""
     M64, M32 = np.uint64, np.uint32
     with np.errstate(over='ignore'):
         k = M64(seed) + M64(0x9E3779B97F4A7C15) * M64(site + 1)
@@ -74,15 +74,15 @@ def keep_mask(seed, site, idx, p):
         k ^= k >> M64(27); k *= M64(0x94D049BB133111EB)
         k ^= k >> M64(31)
         idx = idx.astype(np.uint64)
-        q = idx >> M64(1)
+        q = idx >> M64(2)
         lo = (q & M64(0xFFFFFFFF)).astype(np.uint32); hi = (q >> M64(32)).astype(np.uint32)
         x = (lo + M32(int(k) & 0xFFFFFFFF)) ^ (hi ^ (hi << M32(16)))
         x ^= x >> M32(16); x *= M32(0x7FEB352D)
         x ^= x >> M32(15); x ^= M32(int(k) >> 32); x *= M32(0x846CA68B)
         x ^= x >> M32(16)
-    field = np.where((idx & M64(1)).astype(bool), x >> M32(16), x & M32(0xFFFF)).astype(np.uint32)
-    kk = (1.0 - float(np.float32(p))) * 65536.0
-    thr = 65536 if kk >= 65536.0 else int(kk)
+    field = ((x >> (M32(8) * (idx & M64(3)).astype(np.uint32))) & M32(0xFF)).astype(np.uint32)
+    kk = (1.0 - float(np.float32(p))) * 256.0 + 0.5
+    thr = 256 if kk >= 256.0 else (0 if kk <= 0.0 else int(kk))
     return field < np.uint32(thr)
 
 

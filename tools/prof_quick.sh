@@ -3,7 +3,7 @@
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o bench --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile "$@" > $R/gpurun_out/${TAG}_stats.log 2>&1
+timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o bench --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-extras "$@" > $R/gpurun_out/${TAG}_stats.log 2>&1
 rc=$?
 grep '"metric"' $R/gpurun_out/${TAG}_stats.log | cut -c1-260
 f=$(find $R/gpurun_out/${TAG}_stats -name '*kernel_stats.csv' | sort | tail -n 1)

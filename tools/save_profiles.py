@@ -44,24 +44,49 @@ def traffic(fdir, wdir, out, what):
               open(out, 'w'), indent=1)
 
 
+def durations(path):
+    """kernel symbol -> mean duration (ns) of its dispatches in a pass's kernel trace"""
+    d = collections.defaultdict(list)
+    if os.path.exists(path):
+        for r in csv.DictReader(open(path)):
+            n = r['Kernel_Name']
+            if 'namespace)::' in n and 'at::' not in n:
+                d[key_of(n)].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+    return {k: sum(v) / len(v) for k, v in d.items()}
+
+
+N_SIMD = 256 * 4
+
+
 def busy(dirs, out, what):
     d = collections.defaultdict(dict)
     for p in dirs:
+        dur = durations(f'{p}/b_kernel_trace.csv')
         for n, c in load(f'{p}/b_counter_collection.csv').items():
             for name, vals in c.items():
                 d[n][name] = sum(vals) / len(vals)
                 d[n]['launches'] = len(vals)
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in c:
+                d[n]['duration_ns_in_this_pass'] = dur.get(n)
     k = {}
     for n, c in sorted(d.items()):
         e = {'launches': c.get('launches')}
-        e.update({name: round(v, 1) for name, v in c.items() if name != 'launches'})
-        if c.get('SQ_BUSY_CYCLES'):
-            # SQ_VALU_MFMA_BUSY_CYCLES counts, summed over the SQs like SQ_BUSY_CYCLES, the cycles the MFMA pipe was busy
-            e['mfma_busy'] = round(c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / c['SQ_BUSY_CYCLES'], 4)
+        e.update({name: round(v, 1) for name, v in c.items() if name != 'launches' and v is not None})
+        mf = c.get('SQ_VALU_MFMA_BUSY_CYCLES')
+        if mf is not None and c.get('GRBM_GUI_ACTIVE'):
+            # SQ_VALU_MFMA_BUSY_CYCLES: cycles the MFMA pipe was busy, summed over all 1024 SIMDs (= 32 per v_mfma_f32_32x32x16_bf16);
+            # GRBM_GUI_ACTIVE: active cycles summed over the 8 XCDs (MI355X_MICROARCH.md) -> per-SIMD busy fraction
+            e['mfma_busy'] = round(mf / (N_SIMD * c['GRBM_GUI_ACTIVE'] / 8.0), 4)
+            e['clock_GHz'] = round(c['GRBM_GUI_ACTIVE'] / 8.0 / c['duration_ns_in_this_pass'], 3) if c.get('duration_ns_in_this_pass') else None
+        elif mf is not None and c.get('duration_ns_in_this_pass'):
+            # no cycle count of the dispatch in this pass: price the duration at the 2.4 GHz peak clock (the chip runs ~1.9-2.0 GHz under a
+            # profiled load, so this UNDERSTATES the busy fraction by up to ~20 %)
+            e['mfma_busy'] = round(mf / (N_SIMD * c['duration_ns_in_this_pass'] * 2.4), 4)
+            e['mfma_busy_basis'] = 'duration x 2.4 GHz (lower bound)'
         k[n] = e
-    json.dump({'note': 'rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES (one pass) and SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES '
-                       '(another) around `%s`; per-launch averages per kernel symbol; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES' % what,
-               'kernels': k}, open(out, 'w'), indent=1)
+    json.dump({'note': 'rocprofv3 --pmc passes around `%s`; per-launch averages per kernel symbol. mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / '
+                       '(1024 SIMDs x cycles of the dispatch); cycles of the dispatch = GRBM_GUI_ACTIVE / 8 where that counter was collected in the '
+                       'same pass, else the traced duration at 2.4 GHz' % what, 'kernels': k}, open(out, 'w'), indent=1)
 
 
 cmd = 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras'
