@@ -195,6 +195,108 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
   }
 }
 
+// N = 256 with dy, r, dr (and the dropped copy) all stored as bf16 -- the bf16 gradient stream of the strip plans.  The row-per-wave form
+// above moves 8 bytes per lane and per tensor and goes through a 64-lane reduction for every row, one row at a time: it sat at 3.7 TB/s.
+// Here a wave takes FOUR rows per step (16 lanes x 16 elements per row: two 16-byte loads per lane and tensor, a 16-lane reduction) and the
+// next step's loads are issued before the current step is computed.
+__device__ __forceinline__ void unpack16(const uint4& a, const uint4& b, float* v) {
+  const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; e++) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+}
+__device__ __forceinline__ void pack16(const float* v, uint4& a, uint4& b) {
+  unsigned w[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) w[e] = f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+  a = make_uint4(w[0], w[1], w[2], w[3]); b = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__global__ __launch_bounds__(256) void ln_bwd256_bf16_kernel(const hftt_ln_bwd_desc g) {
+  constexpr int N = 256;
+  __shared__ float red[16][2][N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 4, cl = lane & 15;               // row within the group of four, 16-column chunk
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const bool drop = g.dr_drop != nullptr && g.drop_p > 0.f;
+  const unsigned short* dyp = reinterpret_cast<const unsigned short*>(g.dy);
+  const unsigned short* rp = reinterpret_cast<const unsigned short*>(g.r);
+  unsigned short* drp = reinterpret_cast<unsigned short*>(g.dr);
+  unsigned short* ddp = reinterpret_cast<unsigned short*>(g.dr_drop);
+  float gam[16], dg[16], db[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) { gam[e] = g.gamma[cl * 16 + e]; dg[e] = 0.f; db[e] = 0.f; }
+  const long ngrp = ((long)g.M + 3) / 4;
+  const long stride = (long)gridDim.x * 4;
+  long grp = (long)blockIdx.x * 4 + wave;
+  uint4 y0, y1, r0, r1;
+  float mean, rstd;
+  auto load = [&](long gq) {
+    const long row = gq * 4 + sub;
+    const long rc = row < g.M ? row : (long)g.M - 1;       // clamped: loads stay unconditional
+    const uint4* py = reinterpret_cast<const uint4*>(dyp + rc * N + cl * 16);
+    const uint4* pr = reinterpret_cast<const uint4*>(rp + rc * N + cl * 16);
+    y0 = py[0]; y1 = py[1]; r0 = pr[0]; r1 = pr[1];
+    mean = g.mean[rc]; rstd = g.rstd[rc];
+  };
+  if (grp < ngrp) load(grp);
+  for (; grp < ngrp; grp += stride) {
+    float dy[16], xh[16];
+    unpack16(y0, y1, dy);
+    unpack16(r0, r1, xh);
+    const float mu = mean, rs = rstd;
+    const long row = grp * 4 + sub;
+    const long nxt = grp + stride;
+    load(nxt < ngrp ? nxt : ngrp - 1);                     // the next step's rows are in flight while this step is computed
+    const bool valid = row < g.M;
+    float gg[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      if (!valid) dy[e] = 0.f;
+      xh[e] = (xh[e] - mu) * rs;
+      gg[e] = dy[e] * gam[e];
+      s1 += gg[e];
+      s2 += gg[e] * xh[e];
+      dg[e] += dy[e] * xh[e];
+      db[e] += dy[e];
+    }
+    s1 = group_sum<16>(s1) * (1.0f / N);
+    s2 = group_sum<16>(s2) * (1.0f / N);
+    float o[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) o[e] = rs * (gg[e] - s1 - xh[e] * s2);
+    if (valid) {
+      uint4 a, b;
+      pack16(o, a, b);
+      uint4* po = reinterpret_cast<uint4*>(drp + row * N + cl * 16);
+      po[0] = a; po[1] = b;
+      if (g.dr_drop != nullptr) {
+        if (drop) {
+          const uint64_t q0 = (uint64_t)(row * N + cl * 16) >> 2;              // four hash quads (hftt_keep)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t k4 = hftt_keep_quad(g.drop_seed, g.drop_site, q0 + q, thr);
+#pragma unroll
+            for (int f = 0; f < 4; f++) o[4 * q + f] = ((k4 >> f) & 1u) ? o[4 * q + f] * inv_keep : 0.f;
+          }
+          pack16(o, a, b);
+        }
+        uint4* pd = reinterpret_cast<uint4*>(ddp + row * N + cl * 16);
+        pd[0] = a; pd[1] = b;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; e++) { red[wave * 4 + sub][0][cl * 16 + e] = dg[e]; red[wave * 4 + sub][1][cl * 16 + e] = db[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    const int which = i / N, c = i % N;
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc += red[q][which][c];                    // fixed order: reproducible
+    g.ws[(long)blockIdx.x * 2 * N + i] = acc;
+  }
+}
+
 // out[c] = beta*out[c] + sum_w ws[w][c]   (c over 2N entries: dgamma then dbeta)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int n_wg, int N, float* dgamma, float* dbeta, float beta) {
   __shared__ float red[16][17];
@@ -526,7 +628,11 @@ extern "C" int hftt_ln_bwd(const hftt_ln_bwd_desc* d, void* stream) {
   HFTT_REQUIRE(d && d->dy && d->r && d->mean && d->rstd && d->gamma && d->dr && d->ws, "ln_bwd: null operand");
   HFTT_REQUIRE(d->N == 64 || d->N == 128 || d->N == 256, "ln_bwd: N=%d must be 64, 128 or 256", d->N);
   const int wgs = hftt_ln_bwd_wgs(d->M);
-  if (d->N == 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  const uint32_t all_bf = HFTT_LNB_DY_BF16 | HFTT_LNB_DR_BF16 | HFTT_LNB_R_BF16;
+  const bool fast = d->N == 256 && (d->io_flags & all_bf) == all_bf && (d->dr_drop == nullptr || d->drop_bf16) &&
+                    ((((uintptr_t)d->dy | (uintptr_t)d->r | (uintptr_t)d->dr | (uintptr_t)d->dr_drop) & 15) == 0);
+  if (fast) hipLaunchKernelGGL(ln_bwd256_bf16_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  else if (d->N == 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   else if (d->N == 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   HFTT_CHECK_LAUNCH("ln_bwd");

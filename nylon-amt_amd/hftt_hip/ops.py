@@ -290,7 +290,9 @@ def ln_bwd(dy, r, mean, rstd, gamma, drop_p=0.0, drop_site=0, drop_seed=0, drop_
     d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
     d.ws = ws.data_ptr()
     d.drop_bf16 = 1 if drop_dtype == BF16 else 0
-    d.io_flags = (1 if dy.dtype == BF16 else 0) | (2 if dr_dtype == BF16 else 0)
+    d.io_flags = (1 if dy.dtype == BF16 else 0) | (2 if dr_dtype == BF16 else 0) | (4 if r.dtype == BF16 else 0)
+    if r.dtype not in (BF16, torch.float32) or dy.dtype not in (BF16, torch.float32):
+        raise HfttError('ln_bwd: dy / r must be fp32 or bf16')
     st = _stream(dy.device)
     check(L.hftt_ln_bwd(C.byref(d), st), 'ln_bwd')
     dg = torch.empty(N, device=dy.device)

@@ -169,6 +169,30 @@ def test_ln_bwd(dev, N):
     assert rel_err(drd, r64.grad * mask / (1.0 - float(np.float32(p)))) < 1e-5
 
 
+@pytest.mark.parametrize('M,p', [(1234, 0.2), (4099, 0.0), (3, 0.1), (65536, 0.1)])
+def test_ln_bwd_all_bf16_four_rows_per_wave(dev, M, p):
+    """N = 256 with dy, r, dr and the dropped copy stored as bf16 (the strip plans' gradient stream): the four-rows-per-wave kernel, ragged M
+    included, against the fp64 LayerNorm backward of the SAME bf16-rounded operands."""
+    ops = _ops()
+    N = 256
+    g = torch.Generator().manual_seed(M)
+    r = (torch.randn(M, N, generator=g) * 2 + 0.5).to(torch.bfloat16); dy = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    gam = torch.randn(N, generator=g)
+    r64 = r.double().requires_grad_(True); g64 = gam.double().requires_grad_(True); b64 = torch.zeros(N, dtype=torch.float64, requires_grad=True)
+    (F.layer_norm(r64, (N,), g64, b64, 1e-5) * dy.double()).sum().backward()
+    mean = r.double().mean(1); rstd = 1.0 / torch.sqrt(r.double().var(1, unbiased=False) + 1e-5)
+    site, seed = 5, 1234
+    dr, drd, dg, db = ops.ln_bwd(dy.to(dev), r.to(dev), mean.float().to(dev), rstd.float().to(dev), gam.to(dev), drop_p=p, drop_site=site,
+                                 drop_seed=seed, drop_dtype=torch.bfloat16, dr_dtype=torch.bfloat16)
+    assert dr.dtype == torch.bfloat16
+    assert rel_err(dr, r64.grad) < 6e-3                 # one bf16 rounding of the output
+    assert rel_err(dg, g64.grad) < 2e-5 and rel_err(db, b64.grad) < 2e-5
+    if p > 0:
+        mask = keep_mask_t(seed, site, (M, N), p).double()
+        assert drd.dtype == torch.bfloat16 and rel_err(drd, r64.grad * mask / (1.0 - float(np.float32(p)))) < 6e-3
+        assert torch.equal((drd == 0).cpu() | (mask == 1), torch.ones(M, N, dtype=torch.bool))      # exactly the masked elements are zero
+
+
 def test_colsum_and_adam(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(1)
