@@ -146,3 +146,44 @@ def test_fused_adam_is_a_torch_optimizer_and_drives_reduce_lr_on_plateau():
     opt.zero_grad()
     with pytest.raises(HfttError):
         opt.step()                                                        # parameters on the CPU: no engine, no fallback
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# f4: label generation (corpus/conv_note2label.py) against the reference function's output
+@pytest.mark.parametrize('case', [0, 1])
+@pytest.mark.parametrize('flag', [False, True])
+def test_note2label_equals_the_reference(case, flag):
+    from corpus.conv_note2label import note2label, note2label_arrays
+    from corpus.make_dataset import assemble_store
+    g = np.load(os.path.join(G, 'labels.npz'))
+    notes = [{'pitch': int(r[0]), 'onset': float(r[1]), 'offset': float(r[2]), 'velocity': int(r[3])} for r in g['c%d.notes' % case]]
+    config = {'feature': {'sr': 16000, 'hop_sample': 256, 'mel_bins': 8, 'log_offset': 1e-8}, 'midi': {'note_min': 21, 'num_note': 88, 'num_velocity': 128},
+              'input': {'margin_b': 32, 'margin_f': 32, 'num_frame': 128}}
+    lab = note2label_arrays(config, notes, flag)
+    for k in ('mpe', 'onset', 'offset', 'velocity'):
+        ref = g['c%d.%d.%s' % (case, int(flag), k)]
+        assert lab[k].dtype == ref.dtype and lab[k].shape == ref.shape, k
+        assert np.array_equal(lab[k], ref), (k, int((lab[k] != ref).sum()))
+    as_lists = note2label(config, notes, flag)                       # the reference's return type: nested lists
+    assert set(as_lists) == {'mpe', 'onset', 'offset', 'velocity'} and isinstance(as_lists['mpe'][0][0], bool)
+    assert as_lists['onset'][5] == lab['onset'][5].tolist()
+    # properties of the targets: peaks below one between frames, re-struck pitch without an offset target, mpe covers onset..offset
+    assert 0.5 < lab['onset'].max() <= 1.0 and lab['velocity'].max() <= 127 and lab['velocity'].min() >= 0
+    p60 = 60 - 21
+    f_restrike = int(0.5 * 62.5 + 0.5)
+    assert lab['offset'][f_restrike, p60] == 0.0 and lab['onset'][f_restrike, p60] > 0.5
+    assert lab['mpe'][:f_restrike + 1, p60].all()
+    # ... and they feed the store assembly (labels longer / shorter than the feature of a file are both handled, make_dataset.py:52)
+    feat = np.zeros((lab['mpe'].shape[0] - 7, 8), np.float32)
+    store = assemble_store([feat], [lab], config)
+    assert store['idx'].shape[0] == lab['mpe'].shape[0] and store['label_velocity'].dtype == np.int8
+    assert np.array_equal(store['label_onset'][32:32 + lab['onset'].shape[0]], lab['onset'])
+
+
+def test_note2label_edge_cases():
+    from corpus.conv_note2label import note2label_arrays
+    config = {'feature': {'sr': 16000, 'hop_sample': 256}, 'midi': {'note_min': 21, 'num_note': 88}}
+    empty = note2label_arrays(config, [], False)
+    assert empty['mpe'].shape == (1, 88) and not empty['mpe'].any()
+    one = note2label_arrays(config, [{'pitch': 21, 'onset': 0.0, 'offset': 0.0, 'velocity': 5}], True)      # zero-length note at t = 0
+    assert one['mpe'].shape == (1, 88) and one['mpe'][0, 0] and one['onset'][0, 0] == 1.0 and one['offset'][0, 0] == 0.0 and one['velocity'][0, 0] == 5
