@@ -112,6 +112,7 @@ class FfnDesc(C.Structure):
 
 
 SL_X_BF16, SL_C_BF16, SL_RES_BF16, SL_RELU = 1, 2, 4, 8
+TE_X_BF16, TE_Y_BF16, TE_M_BF16 = 1, 2, 4          # hftt_time_embed_fwd / _bwd io_flags
 
 
 class LossDesc(C.Structure):
