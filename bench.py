@@ -146,11 +146,11 @@ def _newest_profile(suffix):
     return files[-1] if files else None
 
 
-def pmc_traffic_bytes(kernel_key):
+def pmc_traffic_bytes(kernel_key, kind='bench'):
     """(HBM bytes per launch of `kernel_key`, source file) from the newest committed PMC summary (profiles/*_bench_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, FETCH_SIZE doubled for gfx950); (None, None)
     when that file has no such kernel symbol -- an older profile of a different kernel is never quoted."""
-    f = _newest_profile('_bench_pmc_traffic.json')
+    f = _newest_profile('_%s_pmc_traffic.json' % kind)
     if f is None:
         return None, None
     try:
@@ -162,10 +162,10 @@ def pmc_traffic_bytes(kernel_key):
         return None, None
 
 
-def pmc_busy(kernel_key):
+def pmc_busy(kernel_key, kind='bench'):
     """MFMA-busy fraction of `kernel_key` (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES... as tools/save_profiles.py derives it) from the newest
     committed profiles/*_bench_pmc_busy.json, or None"""
-    f = _newest_profile('_bench_pmc_busy.json')
+    f = _newest_profile('_%s_pmc_busy.json' % kind)
     if f is None:
         return None
     try:
@@ -175,7 +175,7 @@ def pmc_busy(kernel_key):
         return None
 
 
-def roofline_object(key, v, steps, peak_tf, total_ms):
+def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench'):
     """roofline object of one kernel symbol from the profiling pass: ALGORITHMIC flops / bytes of its launches (engine plan meta, DESIGN.md
     section 5) over the measured launch durations; the bound is the side of the ridge its arithmetic intensity falls on."""
     ai = v['flops'] / max(v['bytes'], 1.0)
@@ -186,8 +186,10 @@ def roofline_object(key, v, steps, peak_tf, total_ms):
         roof = {'bound': 'mfma', 'achieved': tf, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': tf / peak_tf}
     else:
         roof = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS}
-    traffic, src = pmc_traffic_bytes(key)
-    roof.update({'traffic': traffic, 'traffic_source': src, 'mfma_busy': pmc_busy(key), 'kernel': key,
+    # (PMC figures are per-launch averages over ALL launches of the kernel symbol in the profiled command: `kind` picks the training step's
+    # files or the inference plan's)
+    traffic, src = pmc_traffic_bytes(key, kind)
+    roof.update({'traffic': traffic, 'traffic_source': src, 'mfma_busy': pmc_busy(key, kind), 'kernel': key,
                  'launches_per_step': v['launches'] / steps, 'avg_launch_ms': v['ms'] / v['launches'],
                  'share_of_step_device_time': v['ms'] / max(total_ms, 1e-9), 'arithmetic_intensity': ai,
                  'algorithmic_flops_per_launch': v['flops'] / v['launches'], 'algorithmic_bytes_per_launch': v['bytes'] / v['launches'],
@@ -317,22 +319,27 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
 
+    # ---- profiling pass (after the timed region): per-launch HIP events, harvested after every step.  EVERY rank runs it (the step
+    # contains the gradient all-reduce: a pass on rank 0 alone would wait for its peers forever); rank 0 reports.
+    prof = None
+    psteps = max(2, min(5, args.steps))
+    if not args.no_profile:
+        prof = LaunchProfiler()
+        ts.engine.profiler = prof
+        for i in range(psteps):
+            x, lab = batch(i)
+            ts(x, *lab)
+            prof.step_done()
+        ts.engine.profiler = None
+        sync()
+
     result = None
     if rank == 0:
         value = B * world * args.steps / dt
         peak_tf = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
         roof = roof_ffn = kernels = None
         extras = {}
-        if not args.no_profile:
-            # ---- profiling pass (after the timed region): per-launch HIP events, harvested after every step
-            psteps = max(2, min(5, args.steps))
-            prof = LaunchProfiler()
-            ts.engine.profiler = prof
-            for i in range(psteps):
-                x, lab = batch(i)
-                ts(x, *lab)
-                prof.step_done()
-            ts.engine.profiler = None
+        if prof is not None:
             summ = prof.summary()
             total_ms = sum(v['ms'] for v in summ.values())
             # dominant kernel among the calls that launch exactly one kernel (hftt_gemm_tn launches its split kernel plus a slab reduce, so
@@ -345,6 +352,16 @@ def main():
                         'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else None,
                         'gbs': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['bytes'] else None} for k, v in top]
             extras['profiled_device_ms_per_step'] = total_ms / psteps
+            # the same kernels split by problem shape (one symbol serves the encoder's S_e = B*T*F tokens and the decoder's S_n = B*T*N)
+            by_shape = {}
+            for k, v in prof.samples.items():
+                for m_, t_ in zip(v['meta'], v['ms']):
+                    e = by_shape.setdefault((k, tuple(m_.get('shape', ()))), [0, 0.0, 0.0, 0.0])
+                    e[0] += 1; e[1] += t_; e[2] += m_['flops']; e[3] += m_['bytes']
+            big = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:16]
+            extras['kernels_by_shape'] = [{'kernel': k, 'shape': list(sh), 'launches_per_step': e[0] / psteps, 'avg_launch_us': 1e3 * e[1] / e[0],
+                                           'tflops': e[2] / (e[1] * 1e-3) / 1e12 if e[2] else None, 'gbs': e[3] / (e[1] * 1e-3) / 1e9 if e[3] else None}
+                                          for (k, sh), e in big]
         if world == 1 and not args.no_extras:
             x0, lab0 = batch(0)
             # ---- inference plan (model.eval(): nothing saved for a backward) at the same batch
@@ -371,7 +388,7 @@ def main():
                         sel = [(m_, t_) for m_, t_ in zip(v_ffn['meta'], prof.samples[k_ffn]['ms']) if m_['shape'][0] >= 200000]
                         v_sel = {'launches': len(sel), 'ms': sum(t_ for _, t_ in sel), 'flops': sum(m_['flops'] for m_, _ in sel),
                                  'bytes': sum(m_['bytes'] for m_, _ in sel), 'stalls': 0}
-                        roof_ffn = roofline_object(k_ffn, v_sel, 3, peak_tf, tot_inf)
+                        roof_ffn = roofline_object(k_ffn, v_sel, 3, peak_tf, tot_inf, kind='inference')
                         roof_ffn['entry_point'] = 'hftt_ffn_res_ln_fwd'
                         roof_ffn['plan'] = 'inference (no hidden / pre-LN stores), tokens per launch %d' % sel[0][0]['shape'][0]
             # ---- the 1e-3 parity mode on the same clips: throughput of its training step and the error of the benchmarked mode against it

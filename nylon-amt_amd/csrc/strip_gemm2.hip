@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
   const unsigned char* abase = smem + lane * 16;
   unsigned short* pend_ptr = cb;                    // where the deferred results go (meaningful while pend_valid)
+  int dbg_pass = 0;
   bool pend_valid = false;
 
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -343,13 +344,20 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
         const unsigned short* pf_src = (KCH > 1 && !last_step) ? (xb + tokc * g.ldx + (kc + 1 == KCH ? 0 : kc + 1) * 256 + 16 * hb) : xrow_next;
         const bool pf_res = has_res && (kc == KCH - 1);
         const unsigned short* res_src = rb + (has_res ? rrow * g.ldr + pass * 256 + 16 * hb : 0);
+        // HFTT_STRIP2_DEBUG & 4 (dev, !LN only): thread 0 of each workgroup's SECOND block stamps the shader clock around the phases of every
+        // slot of pass 1 into the (otherwise unused) ln_mean buffer: [workgroup][slot 0..7][4] + [workgroup][8][0..1] for the pass epilogue
+        const bool stamp = !LN && (g.pad & 4) && pass == (passes > 1 ? 1 : 0) && kc == 0 && blk == (long)blockIdx.x + gridDim.x && tid == 0;
+        unsigned long long* sb = reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40;
         static_for<8>([&](auto pt_c) __attribute__((always_inline)) {
           constexpr int pt = decltype(pt_c)::value;
           constexpr int BUF = pt & 3;
+          if (stamp) sb[pt * 4 + 0] = __builtin_amdgcn_s_memtime();
           P.template begin_slot<BUF>();
+          if (stamp) sb[pt * 4 + 1] = __builtin_amdgcn_s_memtime();
           const unsigned char* slot = abase + BUF * SLOT_BYTES;
           // fragment i = u * 8 + tile; the ring refill (four pieces) and the slot's share of the block's memory traffic ride along
           slot_mfmas(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { acc[i & 7] = mfma32(a, as_frag(xf[2 * pt + (i >> 3)]), acc[i & 7]); });
+          if (stamp) sb[pt * 4 + 2] = __builtin_amdgcn_s_memtime();
           static_for<4>([&](auto q_c) __attribute__((always_inline)) {
             constexpr int q = decltype(q_c)::value;
             P.template fill_piece<BUF, q>();
@@ -357,13 +365,19 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
               if (pf_x) { pload16(xn[2 * pt + q], pf_src + piece_off(2 * pt + q)); P.issued += 1; }
             } else {
               constexpr int i = 2 * pt + (q - 2);
-              if (pend_valid) { astore16(pend_ptr + piece_off(i), pend[i]); P.issued += 1; }
+              if (pend_valid) {
+                // (HFTT_STRIP2_DEBUG & 8, timing only: the same bytes as one contiguous 1 KB run per wave instruction, inside the wave's own rows)
+                unsigned short* sp = (g.pad & 8) ? cb + (blk * 128 + wave * 32) * g.ldc + (long)dbg_pass * 8192 + i * 512 + lane * 8 : pend_ptr + piece_off(i);
+                astore16(sp, pend[i]); P.issued += 1;
+              }
               if (pf_res) { pload16(pend[i], res_src + piece_off(i)); P.issued += 1; }      // (behind the store of the same registers)
             }
           });
           P.template fill_close<BUF>();
+          if (stamp) sb[pt * 4 + 3] = __builtin_amdgcn_s_memtime();
           if (pt == 7) pend_valid = false;
         });
+        if (stamp) sb[32] = __builtin_amdgcn_s_memtime();
       }
       // ---------------- epilogue of this pass: results into the pending registers ----------------
             const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;
@@ -399,7 +413,10 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
                 [&](int ot, u4v a, u4v b) __attribute__((always_inline)) { pend[2 * ot] = a; pend[2 * ot + 1] = b; });
       }
       pend_ptr = cb + tok * g.ldc + pass * 256 + 16 * hb;
+      dbg_pass = pass;
       pend_valid = wave_ok;
+      if (!LN && (g.pad & 4) && pass == (passes > 1 ? 1 : 0) && blk == (long)blockIdx.x + gridDim.x && tid == 0)
+        (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[33] = __builtin_amdgcn_s_memtime();
     }
   }
   if (pend_valid) {                                   // drain: the last pass's results

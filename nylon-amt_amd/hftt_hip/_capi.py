@@ -188,6 +188,9 @@ def lib():
         if not os.path.exists(path):
             raise HfttError('libhftt_hip.so not found at %s -- build it with `python nylon-amt_amd/build.py` '
                             '(the HIP library is the only compute path; there is no CPU fallback)' % path)
+        # torch first: the library's streams and device pointers come from torch, so both must sit on ONE HIP runtime.  Loaded before torch, the
+        # library pulls in /opt/rocm's libamdhip64 and torch then brings its own copy -- every launch fails with "no ROCm-capable device".
+        import torch   # noqa: F401
         handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if the symbol is missing: also loud

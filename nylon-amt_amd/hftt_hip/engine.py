@@ -518,11 +518,14 @@ class HfttEngine:
         if bwd:
             hb = 'true' if (flags & 7) == 7 else 'false'
             meta = {'kernel': 'attn_bwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
-                    'bytes': qkv_bytes + n_seq * ((2.0 if flags & 8 else 4.0) * Lq + 2 * (2.0 if flags & 16 else 4.0) * Lk) * self.d + 2 * eo * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
+                    'bytes': qkv_bytes + n_seq * ((2.0 if flags & 8 else 4.0) * Lq + 2 * (2.0 if flags & 16 else 4.0) * Lk) * self.d + 2 * eo * n_seq * Lq * self.d
+                    + 8.0 * n_seq * H * Lq, 'shape': (n_seq, H, Lq, Lk, dh)}
         else:
             hb = 'true' if (flags & 7) == 7 else 'false'
             meta = {'kernel': 'attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
-                    'bytes': qkv_bytes + eo * n_seq * Lq * self.d, 'shape': (n_seq, H, Lq, Lk, dh)}
+                    # q, k, v, out + the row statistics (max, 1/sum) + the attention map where it is a model output (fp32, mandatory)
+                    'bytes': qkv_bytes + eo * n_seq * Lq * self.d + 8.0 * n_seq * H * Lq + (4.0 * n_seq * H * Lq * Lk if probs else 0.0),
+                    'shape': (n_seq, H, Lq, Lk, dh)}
         plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd', meta))
         return dsc
 
