@@ -129,8 +129,9 @@ __device__ __forceinline__ void drop16(float* v, uint64_t seed, uint32_t site, u
 }
 __device__ __forceinline__ bf16x8 as_frag(const u4v& u) { return __builtin_bit_cast(bf16x8, u); }
 
-// per-wave pipeline state: the ring and the count of vector-memory instructions issued from asm
-struct Pipe {
+// The first form of the pipeline state (exact waits from an issue counter and a mark per fill, no fetch past the end of the stream): still
+// used by the fused two-GEMM kernel, whose register allocation is at the limit (the always-fill form below tipped it into 132 bytes of scratch).
+struct PipeDyn {
   const unsigned short* w;      // strip-packed weight stream of ONE block (S slots)
   int S;                        // slots per block
   long fill_left;               // slots this workgroup still has to fetch (its blocks x S at the start)
@@ -189,6 +190,45 @@ struct Pipe {
       fill_pos = (fill_pos + 1 == S) ? 0 : fill_pos + 1;
     }
   }
+};
+
+// per-wave pipeline state: the weight ring.  The stream is fetched three slots ahead and ALWAYS: past the workgroup's last slot the fetch
+// simply wraps to the head of the stream (three harmless extra slots, drained before the kernel ends).  With a four-piece refill in
+// every slot, "at least eight vector-memory instructions were issued after the fill of the slot about to be consumed" holds at every
+// slot boundary, so the wait is the constant s_waitcnt vmcnt(8) (vmcnt retires in issue order; the prefetch loads and stores issued in
+// between only make it stricter).  The first form kept an issue counter, a mark per fill and a branch tree for exact waits at the stream's
+// tail: ~25 scalar instructions per slot, each ~8 cycles with one wave per SIMD (tools/stamp_linear2.py) -- more than the precision bought.
+struct Pipe {
+  const unsigned short* w;      // strip-packed weight stream of ONE block (S slots)
+  int S;                        // slots per block
+  int fill_pos;                 // stream position (0 .. S-1) of the next slot to fetch
+  unsigned ring;
+  int wave, lane;
+  int issued;                   // (unused; kept so that the call sites read the same)
+  bool nobar, nofill;           // timing experiments only (HFTT_STRIP2_DEBUG bits 1 / 0): results are garbage
+
+  __device__ __forceinline__ const unsigned short* src_of(int pos) const { return w + ((long)pos * 16 + wave * 4) * 512 + lane * 8; }
+  __device__ __forceinline__ void advance() { fill_pos = (fill_pos + 1 == S) ? 0 : fill_pos + 1; }
+  // prologue: fetch the next slot of the stream into ring buffer BUF; wave w moves fragments 4w .. 4w+3
+  template <int BUF>
+  __device__ __forceinline__ void fill() {
+    if (!nofill) glds16x4(src_of(fill_pos), ring + (unsigned)BUF * SLOT_BYTES + (unsigned)wave * 4096u);
+    advance();
+  }
+  // top of slot BUF: its DMA has landed in every wave and the buffer consumed one slot ago is free
+  template <int BUF>
+  __device__ __forceinline__ void begin_slot() {
+    HFTT_WAITVM(8);
+    if (!nobar) __builtin_amdgcn_s_barrier();
+  }
+  template <int BUF, int I>
+  __device__ __forceinline__ void fill_piece() {      // BUF: the slot being consumed; the refill goes to (BUF + 3) % 4 (all four pieces at I == 0)
+    if (I == 0 && !nofill) glds16x4(src_of(fill_pos), ring + (unsigned)((BUF + FILL_AHEAD) & (NSLOT - 1)) * SLOT_BYTES + (unsigned)wave * 4096u);
+  }
+  template <int BUF>
+  __device__ __forceinline__ void fill_close() { advance(); }
+  // before the kernel ends: nothing may still be on its way into LDS (the extra slots fetched past the end)
+  __device__ __forceinline__ void drain() { HFTT_WAITVM(0); }
 };
 
 // The 16 weight fragments of a slot -> 16 MFMAs.  With ONE wave per SIMD nobody else covers an LDS round trip, and left alone hipcc
@@ -259,7 +299,7 @@ __device__ __forceinline__ void ln_rows(f32x16 (&acc)[8], const float* gamma_lds
 // ---------------------------------------------------------------------------------------------------------------------
 // PASSES = N / 256, KCH = K / 256 are template parameters: with run-time trip counts the allocator shuffled whole register sets
 // through scratch at the step boundaries (152 spilled registers in the plain form).
-template <bool LN, int PASSES, int KCH>
+template <bool LN, int PASSES, int KCH, bool HR>
 __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_desc g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -275,16 +315,16 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   unsigned short* preb = reinterpret_cast<unsigned short*>(g.pre_ln_out);
   const unsigned short* rb = reinterpret_cast<const unsigned short*>(g.residual);
   const bool relu = g.flags & HFTT_SL_RELU;
-  const bool has_res = g.residual != nullptr;
+  const bool plain = !relu && g.out_scale == 1.0f;
+  constexpr bool has_res = HR;                      // residual rows are prefetched into the pending registers (a template parameter: no per-slot test)
 
   Pipe P;
-  P.w = g.w; P.S = steps * 8; P.fill_left = (g.pad & 1) ? 0 : my_blocks * P.S; P.fill_pos = 0; P.nobar = g.pad & 2; P.closing = false;
+  P.w = g.w; P.S = steps * 8; P.nofill = g.pad & 1; P.fill_pos = 0; P.nobar = g.pad & 2;
   P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
   P.wave = wave; P.lane = lane; P.issued = 0;
-#pragma unroll
-  for (int i = 0; i < NSLOT; i++) P.fill_mark[i] = 0;
 
   auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
+  if (!LN && (g.pad & 4) && tid == 0) (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[34] = __builtin_amdgcn_s_memtime();
 
   // ---- prologue: parameters to LDS (compiler loads), first block's activations, first ring slots
   for (int i = tid; i < g.N; i += 256) prm[i] = g.bias != nullptr ? g.bias[i] : 0.f;
@@ -307,7 +347,6 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
   const unsigned char* abase = smem + lane * 16;
   unsigned short* pend_ptr = cb;                    // where the deferred results go (meaningful while pend_valid)
-  int dbg_pass = 0;
   bool pend_valid = false;
 
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -340,9 +379,9 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
           for (int i = 0; i < 16; i++) xf[i] = xn[i];
         }
         const bool last_step = (pass == passes - 1) && (kc == KCH - 1);
-        const bool pf_x = (KCH > 1) ? (!last_step || has_next) : (last_step && has_next);
+        const bool pf_x = (KCH > 1) ? true : last_step;      // (past the last block the address falls back to this block's rows: a harmless re-read)
         const unsigned short* pf_src = (KCH > 1 && !last_step) ? (xb + tokc * g.ldx + (kc + 1 == KCH ? 0 : kc + 1) * 256 + 16 * hb) : xrow_next;
-        const bool pf_res = has_res && (kc == KCH - 1);
+        const bool pf_res = (KCH == 1) || (kc == KCH - 1);
         const unsigned short* res_src = rb + (has_res ? rrow * g.ldr + pass * 256 + 16 * hb : 0);
         // HFTT_STRIP2_DEBUG & 4 (dev, !LN only): thread 0 of each workgroup's SECOND block stamps the shader clock around the phases of every
         // slot of pass 1 into the (otherwise unused) ln_mean buffer: [workgroup][slot 0..7][4] + [workgroup][8][0..1] for the pass epilogue
@@ -358,21 +397,12 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
           // fragment i = u * 8 + tile; the ring refill (four pieces) and the slot's share of the block's memory traffic ride along
           slot_mfmas(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { acc[i & 7] = mfma32(a, as_frag(xf[2 * pt + (i >> 3)]), acc[i & 7]); });
           if (stamp) sb[pt * 4 + 2] = __builtin_amdgcn_s_memtime();
-          static_for<4>([&](auto q_c) __attribute__((always_inline)) {
-            constexpr int q = decltype(q_c)::value;
-            P.template fill_piece<BUF, q>();
-            if (q < 2) {
-              if (pf_x) { pload16(xn[2 * pt + q], pf_src + piece_off(2 * pt + q)); P.issued += 1; }
-            } else {
-              constexpr int i = 2 * pt + (q - 2);
-              if (pend_valid) {
-                // (HFTT_STRIP2_DEBUG & 8, timing only: the same bytes as one contiguous 1 KB run per wave instruction, inside the wave's own rows)
-                unsigned short* sp = (g.pad & 8) ? cb + (blk * 128 + wave * 32) * g.ldc + (long)dbg_pass * 8192 + i * 512 + lane * 8 : pend_ptr + piece_off(i);
-                astore16(sp, pend[i]); P.issued += 1;
-              }
-              if (pf_res) { pload16(pend[i], res_src + piece_off(i)); P.issued += 1; }      // (behind the store of the same registers)
-            }
-          });
+          // the slot's share of the block's memory traffic: the ring refill, two pieces of the next activations (ONE test for both), two
+          // pending result pieces (one test), two residual pieces (no test: HR and the k-chunk are compile-time)
+          P.template fill_piece<BUF, 0>();
+          if (pf_x) { pload16(xn[2 * pt], pf_src + piece_off(2 * pt)); pload16(xn[2 * pt + 1], pf_src + piece_off(2 * pt + 1)); }
+          if (pend_valid) { astore16(pend_ptr + piece_off(2 * pt), pend[2 * pt]); astore16(pend_ptr + piece_off(2 * pt + 1), pend[2 * pt + 1]); }
+          if (HR && pf_res) { pload16(pend[2 * pt], res_src + piece_off(2 * pt)); pload16(pend[2 * pt + 1], res_src + piece_off(2 * pt + 1)); }   // (behind the stores of the same registers)
           P.template fill_close<BUF>();
           if (stamp) sb[pt * 4 + 3] = __builtin_amdgcn_s_memtime();
           if (pt == 7) pend_valid = false;
@@ -385,11 +415,16 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
       for (int ot = 0; ot < 8; ot++) {
         const int col0 = pass * 256 + ot * 32 + 16 * hb;
         float v[16];
+        if (plain) {                                  // (wave-uniform) no ReLU, unit scale: the common projection -- nothing to do per element
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-          float t = acc[ot][q];
-          if (!LN && relu) t = fmaxf(t, 0.f);
-          v[q] = t * g.out_scale;
+          for (int q = 0; q < 16; q++) v[q] = acc[ot][q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            float t = acc[ot][q];
+            if (!LN && relu) t = fmaxf(t, 0.f);
+            v[q] = t * g.out_scale;
+          }
         }
         if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 2), thr, inv_keep);
         if (has_res) {
@@ -413,7 +448,6 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
                 [&](int ot, u4v a, u4v b) __attribute__((always_inline)) { pend[2 * ot] = a; pend[2 * ot + 1] = b; });
       }
       pend_ptr = cb + tok * g.ldc + pass * 256 + 16 * hb;
-      dbg_pass = pass;
       pend_valid = wave_ok;
       if (!LN && (g.pad & 4) && pass == (passes > 1 ? 1 : 0) && blk == (long)blockIdx.x + gridDim.x && tid == 0)
         (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[33] = __builtin_amdgcn_s_memtime();
@@ -423,6 +457,8 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
 #pragma unroll
     for (int i = 0; i < 16; i++) astore16(pend_ptr + piece_off(i), pend[i]);
   }
+  P.drain();
+  if (!LN && (g.pad & 4) && tid == 0) (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[35] = __builtin_amdgcn_s_memtime();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -445,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
   const unsigned short* rb = reinterpret_cast<const unsigned short*>(g.residual);
   const bool has_res = (MODE == 1) && g.residual != nullptr;
 
-  Pipe P;
+  PipeDyn P;
   P.w = g.w; P.S = 2 * PT; P.fill_left = (g.pad & 1) ? 0 : my_blocks * P.S; P.fill_pos = 0; P.nobar = g.pad & 2; P.closing = false;
   P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
   P.wave = wave; P.lane = lane; P.issued = 0;
@@ -642,15 +678,15 @@ int set_lds(K kernel, int lds, const char* what) {
   if (e != hipSuccess) { hftt_set_error("%s: hipFuncSetAttribute(%d B LDS) failed: %s", what, lds, hipGetErrorString(e)); return 2; }
   return 0;
 }
-template <bool LN, int PASSES, int KCH>
+template <bool LN, int PASSES, int KCH, bool HR>
 int launch_linear2(const hftt_strip_desc& d, hipStream_t st) {
   const int lds = RING_BYTES + 4 * (d.N + 512);
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(strip_linear2_kernel<LN, PASSES, KCH>, lds, "strip_linear2")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(strip_linear2_kernel<LN, PASSES, KCH, HR>, lds, "strip_linear2")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("strip_linear2: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  hipLaunchKernelGGL((strip_linear2_kernel<LN, PASSES, KCH>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  hipLaunchKernelGGL((strip_linear2_kernel<LN, PASSES, KCH, HR>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("strip_linear2");
   return 0;
 }
@@ -679,18 +715,21 @@ int hftt_strip_linear2_try(const hftt_strip_desc& d0, hipStream_t st) {
   if (!v2_enabled() || (d.flags & bf) != bf || d.K % 256 != 0 || d.M % 32 != 0 || d.gate != nullptr) return -1;
   if (d.residual != nullptr && !(d.flags & HFTT_SL_RES_BF16)) return -1;
   const int passes = d.N / 256, kch = d.K / 256;
+  const bool hr = d.residual != nullptr;
+  // the shapes of the model: QKV (3 passes), cross K/V (2), single projections and the dX forms with K = 256 / 512 / 768; LayerNorm forms
+#define HFTT_L2(LN_, P_, K_) return hr ? launch_linear2<LN_, P_, K_, true>(d, st) : launch_linear2<LN_, P_, K_, false>(d, st)
   if (d.ln_gamma != nullptr) {
-    if (kch == 1) return launch_linear2<true, 1, 1>(d, st);
-    if (kch == 2) return launch_linear2<true, 1, 2>(d, st);
-    if (kch == 3) return launch_linear2<true, 1, 3>(d, st);
+    if (kch == 1) HFTT_L2(true, 1, 1);
+    if (kch == 2) HFTT_L2(true, 1, 2);
+    if (kch == 3) HFTT_L2(true, 1, 3);
     return -1;
   }
-  // the shapes of the model: QKV (3 passes), cross K/V (2), single projections and the dX forms with K = 256 / 512 / 768
-  if (kch == 1 && passes == 1) return launch_linear2<false, 1, 1>(d, st);
-  if (kch == 1 && passes == 2) return launch_linear2<false, 2, 1>(d, st);
-  if (kch == 1 && passes == 3) return launch_linear2<false, 3, 1>(d, st);
-  if (kch == 2 && passes == 1) return launch_linear2<false, 1, 2>(d, st);
-  if (kch == 3 && passes == 1) return launch_linear2<false, 1, 3>(d, st);
+  if (kch == 1 && passes == 1) HFTT_L2(false, 1, 1);
+  if (kch == 1 && passes == 2) HFTT_L2(false, 2, 1);
+  if (kch == 1 && passes == 3) HFTT_L2(false, 3, 1);
+  if (kch == 2 && passes == 1) HFTT_L2(false, 1, 2);
+  if (kch == 3 && passes == 1) HFTT_L2(false, 1, 3);
+#undef HFTT_L2
   return -1;
 }
 int hftt_strip_mlp2_try(const hftt_ffn_desc& d0, hipStream_t st) {

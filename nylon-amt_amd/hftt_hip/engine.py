@@ -430,7 +430,7 @@ class HfttEngine:
         passes, kch = N // 256, K // 256
         v2 = (os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and x_bf and c_bf and K % 256 == 0 and M % 32 == 0 and not gate and (not residual or res_bf)
               and ((ln is not None and kch <= 3) or (ln is None and (kch, passes) in ((1, 1), (1, 2), (1, 3), (2, 1), (3, 1)))))
-        kname = ('strip_linear2_kernel<%s, %d, %d>' % (tf(ln is not None), 1 if ln is not None else passes, kch)) if v2 \
+        kname = ('strip_linear2_kernel<%s, %d, %d, %s>' % (tf(ln is not None), 1 if ln is not None else passes, kch, tf(bool(residual)))) if v2 \
             else 'strip_linear_kernel<%s, %s, %s>' % (tf(x_bf), tf(c_bf), tf(ln is not None))
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_strip_linear, (C.byref(dsc),), 'strip_linear', meta))

@@ -37,3 +37,12 @@ gap = sl[:, 1:, 0] - sl[:, :-1, 3]
 print('%-32s mean %7.0f' % ('slot end -> next slot start', gap.mean()))
 print('slot start -> next slot start: mean %.0f cycles' % (sl[:, 1:, 0] - sl[:, :-1, 0]).mean())
 print('pass: 8 slots %.0f cycles, epilogue %.0f cycles' % ((t[:, 32] - sl[:, 0, 0]).mean(), (t[:, 33] - t[:, 32]).mean()))
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ev[0].record()
+for _ in range(10):
+    check(lib().hftt_strip_linear(C.byref(dsc), st), 'strip_linear')
+ev[1].record()
+torch.cuda.synchronize()
+us = ev[0].elapsed_time(ev[1]) * 100
+t = stamps.view(256, 40).cpu().double()
+print('kernel: %.1f us by events; %.0f ticks from a workgroup\'s first to its last instruction (mean) -> %.2f ticks per ns' % (us, (t[:, 35] - t[:, 34]).mean(), (t[:, 35] - t[:, 34]).mean() / (us * 1e3)))
