@@ -288,3 +288,45 @@ def test_two_process_data_parallel_step_equals_the_global_batch(dev, tmp_path):
         assert abs(a - b) < 1e-4 * abs(b), (r['losses'], losses)
     assert (r['flat'] - flat).abs().mean().item() < 2e-5
     assert (r['flat'] - flat).abs().max().item() <= 2.1e-3 * 2 * n_steps            # Adam: ~lr per step where a noise-level gradient flips sign
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# inference scatter with real engines: two processes, one engine each on the one GPU, gloo as the transport
+def _amt_worker(rank, world, port, tmp):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from model.amt import AMT
+    g = np.load(os.path.join(G, 'ref_ckpt.npz'))
+    c = {str(k): int(v) for k, v in zip(g['cfg_keys'], g['cfg'])}
+    config = {'feature': {'sr': 16000, 'hop_sample': 256, 'mel_bins': c['n_bin'], 'n_bins': c['n_bin'], 'log_offset': 1e-8},
+              'input': {'margin_b': c['n_margin'], 'margin_f': c['n_margin'], 'num_frame': c['n_frame'], 'min_value': -18.420681},
+              'midi': {'note_min': 21, 'note_max': 21 + c['n_note'] - 1, 'num_note': c['n_note'], 'num_velocity': c['n_velocity']}}
+    amt = AMT(config, os.path.join(G, 'ref_ckpt_model.pkl'), batch_size=1, device='cuda:0')          # rank / world from torch.distributed
+    assert (amt.rank, amt.world) == (rank, world)
+    outs = amt.transcript(g['feature'])                        # 4 clips of batch 1: this rank runs two of them, then all-gathers
+    outs_s = amt.transcript_stride(g['feature'], 3)
+    np.savez(os.path.join(tmp, 'amt_rank%d.npz' % rank), **{'o%d' % k: o for k, o in enumerate(outs)}, **{'s%d' % k: o for k, o in enumerate(outs_s)})
+    dist.destroy_process_group()
+
+
+def test_two_process_inference_scatter_equals_one_engine(dev, tmp_path):
+    """model/amt.py under world 2 (clip batches dealt round-robin, results all-gathered by clip index) is BIT-EQUAL, on every rank, to the
+    single-engine run of the same reference-made checkpoint (amt.py:86-113 stitching order)."""
+    from model.amt import AMT
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_amt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = np.load(os.path.join(G, 'ref_ckpt.npz'))
+    c = {str(k): int(v) for k, v in zip(g['cfg_keys'], g['cfg'])}
+    config = {'feature': {'sr': 16000, 'hop_sample': 256, 'mel_bins': c['n_bin'], 'n_bins': c['n_bin'], 'log_offset': 1e-8},
+              'input': {'margin_b': c['n_margin'], 'margin_f': c['n_margin'], 'num_frame': c['n_frame'], 'min_value': -18.420681},
+              'midi': {'note_min': 21, 'note_max': 21 + c['n_note'] - 1, 'num_note': c['n_note'], 'num_velocity': c['n_velocity']}}
+    amt = AMT(config, os.path.join(G, 'ref_ckpt_model.pkl'), batch_size=1, rank=0, world=1)
+    one = amt.transcript(g['feature'])
+    one_s = amt.transcript_stride(g['feature'], 3)
+    for rank in range(2):
+        r = np.load(tmp_path / ('amt_rank%d.npz' % rank))
+        for k in range(8):
+            assert r['o%d' % k].dtype == one[k].dtype and np.array_equal(r['o%d' % k], one[k]), (rank, k)
+            assert np.array_equal(r['s%d' % k], one_s[k]), (rank, 's', k)
