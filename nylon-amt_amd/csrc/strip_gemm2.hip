@@ -250,6 +250,23 @@ __device__ __forceinline__ void slot_mfmas(const unsigned char* slot, F&& mfma_i
   __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 }
 
+// The same, with the slot's memory work (`side(i)`, called behind MFMA i) in program order BETWEEN the MFMAs: a wave alone on its SIMD
+// issues in order, so whatever follows the last MFMA is paid in full, while an instruction placed between two MFMAs issues in the 24 of
+// 32 cycles the matrix pipe leaves free.
+template <typename F, typename G>
+__device__ __forceinline__ void slot_mfmas_mix(const unsigned char* slot, F&& mfma_i, G&& side) {
+  bf16x8 fr[16];
+#pragma unroll
+  for (int i = 0; i < 6; i++) fr[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
+  static_for<16>([&](auto i_c) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value;
+    mfma_i(i, fr[i]);
+    if (i + 6 < 16) fr[i + 6] = *reinterpret_cast<const bf16x8*>(slot + (i + 6) * 1024);
+    side(i_c);
+    __builtin_amdgcn_sched_barrier(0);               // keep this MFMA, its refill read and its share of the side work together
+  });
+}
+
 // element offset (inside the lane's 16-feature-per-tile row view) of load / store piece i = 0..15: tile (i >> 1), 8-element half (i & 1)
 __device__ __forceinline__ long piece_off(int i) { return (long)(i >> 1) * 32 + (i & 1) * 8; }
 
@@ -324,7 +341,9 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   P.wave = wave; P.lane = lane; P.issued = 0;
 
   auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
+#ifdef HFTT_STRIP_STAMPS
   if (!LN && (g.pad & 4) && tid == 0) (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[34] = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- prologue: parameters to LDS (compiler loads), first block's activations, first ring slots
   for (int i = tid; i < g.N; i += 256) prm[i] = g.bias != nullptr ? g.bias[i] : 0.f;
@@ -350,6 +369,11 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   bool pend_valid = false;
 
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+#ifdef HFTT_STRIP_STAMPS
+    const bool bstamp = !LN && (g.pad & 4) && blk == (long)blockIdx.x + gridDim.x && tid == 0;
+    unsigned long long* bsb = reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40;
+    if (bstamp) bsb[36] = __builtin_amdgcn_s_memtime();
+#endif
     int hb = h;                                       // opaque per iteration: column arithmetic that only depends on (h, tile) is
     asm volatile("" : "+v"(hb));                      // otherwise hoisted out of this loop and kept live in dozens of registers
     const long tok = blk * 128 + wave * 32 + j;
@@ -378,36 +402,47 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
 #pragma unroll
           for (int i = 0; i < 16; i++) xf[i] = xn[i];
         }
+#ifdef HFTT_STRIP_STAMPS
+        if (bstamp && pass == 0 && kc == 0) bsb[37] = __builtin_amdgcn_s_memtime();
+#endif
         const bool last_step = (pass == passes - 1) && (kc == KCH - 1);
         const bool pf_x = (KCH > 1) ? true : last_step;      // (past the last block the address falls back to this block's rows: a harmless re-read)
         const unsigned short* pf_src = (KCH > 1 && !last_step) ? (xb + tokc * g.ldx + (kc + 1 == KCH ? 0 : kc + 1) * 256 + 16 * hb) : xrow_next;
         const bool pf_res = (KCH == 1) || (kc == KCH - 1);
         const unsigned short* res_src = rb + (has_res ? rrow * g.ldr + pass * 256 + 16 * hb : 0);
-        // HFTT_STRIP2_DEBUG & 4 (dev, !LN only): thread 0 of each workgroup's SECOND block stamps the shader clock around the phases of every
+        // -DHFTT_STRIP_STAMPS builds only (tools/stamp_linear2.sh), HFTT_STRIP2_DEBUG & 4, !LN: thread 0 of each workgroup's SECOND block stamps the shader clock around the phases of every
         // slot of pass 1 into the (otherwise unused) ln_mean buffer: [workgroup][slot 0..7][4] + [workgroup][8][0..1] for the pass epilogue
-        const bool stamp = !LN && (g.pad & 4) && pass == (passes > 1 ? 1 : 0) && kc == 0 && blk == (long)blockIdx.x + gridDim.x && tid == 0;
+#ifdef HFTT_STRIP_STAMPS
+        const bool stamp = !LN && (g.pad & 4) && pass == (int)((g.pad >> 8) & 3) && kc == 0 && blk == (long)blockIdx.x + gridDim.x && tid == 0;
         unsigned long long* sb = reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40;
+#define L2STAMP(k) do { if (stamp) sb[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define L2STAMP(k) do { } while (0)
+#endif
         static_for<8>([&](auto pt_c) __attribute__((always_inline)) {
           constexpr int pt = decltype(pt_c)::value;
           constexpr int BUF = pt & 3;
-          if (stamp) sb[pt * 4 + 0] = __builtin_amdgcn_s_memtime();
+          L2STAMP(pt * 4 + 0);
           P.template begin_slot<BUF>();
-          if (stamp) sb[pt * 4 + 1] = __builtin_amdgcn_s_memtime();
+          L2STAMP(pt * 4 + 1);
           const unsigned char* slot = abase + BUF * SLOT_BYTES;
           // fragment i = u * 8 + tile; the ring refill (four pieces) and the slot's share of the block's memory traffic ride along
-          slot_mfmas(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { acc[i & 7] = mfma32(a, as_frag(xf[2 * pt + (i >> 3)]), acc[i & 7]); });
-          if (stamp) sb[pt * 4 + 2] = __builtin_amdgcn_s_memtime();
-          // the slot's share of the block's memory traffic: the ring refill, two pieces of the next activations (ONE test for both), two
-          // pending result pieces (one test), two residual pieces (no test: HR and the k-chunk are compile-time)
-          P.template fill_piece<BUF, 0>();
-          if (pf_x) { pload16(xn[2 * pt], pf_src + piece_off(2 * pt)); pload16(xn[2 * pt + 1], pf_src + piece_off(2 * pt + 1)); }
-          if (pend_valid) { astore16(pend_ptr + piece_off(2 * pt), pend[2 * pt]); astore16(pend_ptr + piece_off(2 * pt + 1), pend[2 * pt + 1]); }
-          if (HR && pf_res) { pload16(pend[2 * pt], res_src + piece_off(2 * pt)); pload16(pend[2 * pt + 1], res_src + piece_off(2 * pt + 1)); }   // (behind the stores of the same registers)
-          P.template fill_close<BUF>();
-          if (stamp) sb[pt * 4 + 3] = __builtin_amdgcn_s_memtime();
+          // the slot's share of the block's memory traffic rides BETWEEN the MFMAs: the ring refill, two pieces of the next activations
+          // (ONE test for both), two pending result pieces (one test), two residual pieces (no test: HR and the k-chunk are compile-time)
+          slot_mfmas_mix(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { acc[i & 7] = mfma32(a, as_frag(xf[2 * pt + (i >> 3)]), acc[i & 7]); },
+                         [&](auto i_c) __attribute__((always_inline)) {
+                           constexpr int i = decltype(i_c)::value;
+                           if (i == 1) P.template fill_piece<BUF, 0>();
+                           if (i == 4) { if (pf_x) { pload16(xn[2 * pt], pf_src + piece_off(2 * pt)); pload16(xn[2 * pt + 1], pf_src + piece_off(2 * pt + 1)); } }
+                           if (i == 7) { if (pend_valid) { astore16(pend_ptr + piece_off(2 * pt), pend[2 * pt]); astore16(pend_ptr + piece_off(2 * pt + 1), pend[2 * pt + 1]); } }
+                           if (i == 10) { if (HR && pf_res) { pload16(pend[2 * pt], res_src + piece_off(2 * pt)); pload16(pend[2 * pt + 1], res_src + piece_off(2 * pt + 1)); } }
+                           if (i == 12) P.template fill_close<BUF>();
+                         });
+          L2STAMP(pt * 4 + 2);
+          L2STAMP(pt * 4 + 3);
           if (pt == 7) pend_valid = false;
         });
-        if (stamp) sb[32] = __builtin_amdgcn_s_memtime();
+        L2STAMP(32);
       }
       // ---------------- epilogue of this pass: results into the pending registers ----------------
             const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;
@@ -449,8 +484,13 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
       }
       pend_ptr = cb + tok * g.ldc + pass * 256 + 16 * hb;
       pend_valid = wave_ok;
-      if (!LN && (g.pad & 4) && pass == (passes > 1 ? 1 : 0) && blk == (long)blockIdx.x + gridDim.x && tid == 0)
+#ifdef HFTT_STRIP_STAMPS
+      if (bstamp && pass == passes - 1) bsb[38] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef HFTT_STRIP_STAMPS
+      if (!LN && (g.pad & 4) && pass == (int)((g.pad >> 8) & 3) && blk == (long)blockIdx.x + gridDim.x && tid == 0)
         (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[33] = __builtin_amdgcn_s_memtime();
+#endif
     }
   }
   if (pend_valid) {                                   // drain: the last pass's results
@@ -458,7 +498,9 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
     for (int i = 0; i < 16; i++) astore16(pend_ptr + piece_off(i), pend[i]);
   }
   P.drain();
+#ifdef HFTT_STRIP_STAMPS
   if (!LN && (g.pad & 4) && tid == 0) (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[35] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

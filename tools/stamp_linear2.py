@@ -5,7 +5,8 @@ import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd'))
-os.environ['HFTT_STRIP2_DEBUG'] = str(4 | int(os.environ.get('EXTRA', '0')))
+os.environ['HFTT_STRIP2_DEBUG'] = str(4 | int(os.environ.get('EXTRA', '0')) | (int(os.environ.get('PASS', '1')) << 8))
+print('stamped pass:', os.environ.get('PASS', '1'))
 from hftt_hip import ops
 from hftt_hip._capi import StripDesc, SL_X_BF16, SL_C_BF16, check, lib
 dev = torch.device('cuda:0')
@@ -37,6 +38,7 @@ gap = sl[:, 1:, 0] - sl[:, :-1, 3]
 print('%-32s mean %7.0f' % ('slot end -> next slot start', gap.mean()))
 print('slot start -> next slot start: mean %.0f cycles' % (sl[:, 1:, 0] - sl[:, :-1, 0]).mean())
 print('pass: 8 slots %.0f cycles, epilogue %.0f cycles' % ((t[:, 32] - sl[:, 0, 0]).mean(), (t[:, 33] - t[:, 32]).mean()))
+print('second block: top of loop -> first slot %.0f ticks (activations of the block copied in: waits for the prefetch), whole block %.0f ticks' % ((t[:, 37] - t[:, 36]).mean(), (t[:, 38] - t[:, 36]).mean()))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
 for _ in range(10):
