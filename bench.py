@@ -366,6 +366,7 @@ def main():
             x0, lab0 = batch(0)
             # ---- inference plan (model.eval(): nothing saved for a backward) at the same batch
             model.eval()
+            model.hftt_freeze_weights(True)            # what model.amt.AMT does: a transcriber's weights are constant
             with torch.no_grad():
                 t_inf = timed(lambda i: model(batch(i)[0]), 10, warm=2)
                 post_bf = [t.clone() for k, t in enumerate(model(x0)) if k in (0, 1, 2, 5, 6, 7)]
@@ -391,6 +392,7 @@ def main():
                         roof_ffn = roofline_object(k_ffn, v_sel, 3, peak_tf, tot_inf, kind='inference')
                         roof_ffn['entry_point'] = 'hftt_ffn_res_ln_fwd'
                         roof_ffn['plan'] = 'inference (no hidden / pre-LN stores), tokens per launch %d' % sel[0][0]['shape'][0]
+            model.hftt_freeze_weights(False)
             # ---- the 1e-3 parity mode on the same clips: throughput of its training step and the error of the benchmarked mode against it
             if args.precision == 'bf16':
                 model.hftt_precision = 'parity'

@@ -86,6 +86,8 @@ class HfttEngine:
         self._ws = {}
         self._site = 0
         self.profiler = None                        # optional per-launch HIP-event timer (bench.py)
+        self.frozen_weights = False                 # the caller's promise that the parameters do not change (see prepare_weights)
+        self._prepared_frozen = False
 
     # ------------------------------------------------------------------ precision / parameters
     def set_precision(self, precision):
@@ -100,6 +102,7 @@ class HfttEngine:
         # strip kernels (csrc/strip_gemm.hip): bf16 mode at the paper's width.  Then the WHOLE activation stream between kernels is
         # bf16 (residual stream, pre-LayerNorm sums, hidden), fp32 lives only inside a kernel (accumulators, LayerNorm statistics).
         self.strip = self.sb and getattr(self, 'strip_opt', True) and self.d == 256 and self.p % 64 == 0
+        self._prepared_frozen = False
         if getattr(self, '_bound', None) is not None:
             self._build_prep()
 
@@ -320,12 +323,18 @@ class HfttEngine:
         return self.wstrip.data_ptr() + 2 * self.Woff['s.' + key]
 
     def prepare_weights(self, stream):
+        """parameters -> the kernels' operand forms (bf16 / fp32 planes, folded embedding, strip packs): every forward, because the flat buffer
+        may have changed in ways nobody tells the engine about (an optimizer step, ``p.data.copy_``) -- unless the caller has declared the
+        parameters constant (``frozen_weights``: inference servers; model.amt.AMT does), then once."""
+        if self.frozen_weights and self._prepared_frozen:
+            return
         check(self.lib.hftt_prep_weights(self.flat_params.data_ptr(), self.wbf.data_ptr() if self.npass == 1 else 0,
                                          self.wf32.data_ptr() if self.npass == 3 else 0,
                                          self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights')
         check(self.lib.hftt_embed_fold_fwd(C.byref(self.fold), stream), 'embed_fold_fwd')
         if self.strip and self.n_spack:
             check(self.lib.hftt_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, stream), 'strip_pack')
+        self._prepared_frozen = self.frozen_weights
 
     # ------------------------------------------------------------------ plan building helpers
     def _new_site(self):

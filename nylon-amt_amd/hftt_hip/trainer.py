@@ -98,6 +98,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         ops.adam_step(self.engine.flat_params, self.engine.flat_grads, self.exp_avg, self.exp_avg_sq, self.step_count,
                       lr=float(g['lr']), beta1=g['betas'][0], beta2=g['betas'][1], eps=g['eps'], grad_scale=grad_scale)
+        self.engine._prepared_frozen = False          # (a frozen-weights inference engine must prepare its operands again)
         for p in self._params():
             self.state[p]['step'].fill_(self.step_count)
         return loss

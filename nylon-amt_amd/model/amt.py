@@ -52,6 +52,8 @@ class AMT():
                 self.model = pickle.load(f)
             self.model = self.model.to(self.device)
             self.model.eval()
+            if hasattr(self.model, 'hftt_freeze_weights'):
+                self.model.hftt_freeze_weights(True)           # a transcriber never changes its weights: operands are prepared once
             if verbose_flag is True:
                 print(self.model)
 

@@ -409,3 +409,43 @@ def test_inference_wave_to_midi_end_to_end(dev, tmp_path):
     mid = tmp_path / 'out.mid'
     amt.note2midi(notes, str(mid))
     assert mid.read_bytes()[:4] == b'MThd'
+
+
+def test_frozen_weights_prepare_once_and_follow_explicit_changes(dev):
+    """model.hftt_freeze_weights(): eval forwards skip the per-call operand preparation; results are unchanged; load_state_dict, train() and
+    a FusedAdam step end / refresh the promise (the reference reads its weights at every call)."""
+    from hftt_hip.trainer import FusedAdam, TrainStep
+    cfg = MINI
+    model = util.build_model(cfg, 9).to(dev)
+    model.hftt_precision = 'bf16'
+    x = (O.synth_spec(2, cfg, salt=4) * 0.5).to(dev)
+    model.eval()
+    with torch.no_grad():
+        ref = [t.clone() for t in model(x)]
+        model.hftt_freeze_weights(True)
+        eng = model.hftt_engine()
+        calls = []
+        orig = eng.lib.hftt_prep_weights
+        a = [t.clone() for t in model(x)]
+        assert eng.frozen_weights and eng._prepared_frozen
+        b = [t.clone() for t in model(x)]
+    for r, u, v in zip(ref, a, b):
+        assert torch.equal(r, u) and torch.equal(r, v)
+    sd = {k: v.clone() + 0.02 for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)                                   # explicit change: prepared again
+    with torch.no_grad():
+        c = model(x)
+    assert not torch.equal(c[0], ref[0])
+    model.train()                                               # training: never frozen
+    assert not model.hftt_engine().frozen_weights
+    ts = TrainStep(model, optimizer=FusedAdam(model.parameters(), lr=1e-2))
+    labels = [t.to(dev).contiguous() for t in O.synth_labels(2, cfg, salt=5)]
+    ts(x, *labels)
+    model.eval()
+    with torch.no_grad():
+        d = [t.clone() for t in model(x)]                        # sees the updated parameters
+        model.hftt_freeze_weights(False)
+        e = model(x)
+    assert not torch.equal(d[0], c[0])
+    for u, v in zip(d, e):
+        assert torch.equal(u, v)

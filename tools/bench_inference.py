@@ -20,6 +20,7 @@ cfg = bench.CONFIGS['paper']
 model = bench.build_model(cfg, 1234, 0.1, dev)
 model.hftt_precision = 'bf16'
 model.eval()
+model.hftt_freeze_weights(True)
 x, _ = bench.synthetic_batch(cfg, args.batch, 1234, dev)
 with torch.no_grad():
     for _ in range(2):
