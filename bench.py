@@ -246,8 +246,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    # HFTT_BENCH_FORCE_DDP=1 (rehearsal on a one-GPU box): take the N > 1 code path with a one-rank RCCL group -- init_process_group('nccl'),
+    # parameter broadcast, the bucketed all-reduce on the side stream, the barriers -- so that branch has run on real hardware before the
+    # multi-GPU node sees it
+    force_ddp = os.environ.get('HFTT_BENCH_FORCE_DDP') == '1'
+    if world > 1 or force_ddp:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('LOCAL_RANK', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if share:
             dist.init_process_group('gloo')
@@ -260,10 +266,12 @@ def main():
     model.hftt_precision = args.precision
     model.train()
     grad_sync = None
-    if world > 1:
+    if world > 1 or force_ddp:
         from hftt_hip.ddp import FlatGradSync, broadcast_parameters
         eng = model.hftt_engine()
         broadcast_parameters(eng)
+        if force_ddp and world == 1:
+            dist.broadcast(eng.flat_params, 0)                 # (broadcast_parameters skips a one-rank job)
         grad_sync = FlatGradSync(eng, world, rank=rank)        # folds the rank into the dropout seed: every rank draws its own masks
     ts = TrainStep(model, lr=1e-4, grad_sync=grad_sync)
 
@@ -283,7 +291,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -302,7 +310,7 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     loss_val = float(loss[0].item())
-    if world > 1:
+    if world > 1 or force_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         if share:
             t = t.cpu()
@@ -443,7 +451,7 @@ def main():
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 
