@@ -653,7 +653,7 @@ class HfttEngine:
         win = self._buf(ws, 'win', Se, self.Kp)
         x0 = self._abuf(ws, 'x0', Se, d)
         e = 'encoder_spec2midi.'
-        plan.append((self.lib.hftt_im2win, (spec.data_ptr(), win.data_ptr(), B, F, T, self.n_proc, self.Kp), 'im2win', None))
+        plan.append(('im2win', (win.data_ptr(), B, F, T, self.n_proc, self.Kp), 'im2win', None))       # (the source pointer is this forward's: ws['spec_ptr'])
         s_emb = self._new_site()
         ws['sites']['embed'] = s_emb
         self._nt(plan, ws, Se, d, self.Kp, win.data_ptr(), self.Kp, self.Wp('embed'), self.Fp('embed_b'), x0.data_ptr(), d,
@@ -1042,6 +1042,8 @@ class HfttEngine:
                 prof.begin(name, meta)
             if not isinstance(fn, str):
                 rc = fn(*args, stream)
+            elif fn == 'im2win':
+                rc = L.hftt_im2win(ws['spec_ptr'], *args, stream)
             elif fn == 'ln_reduce':
                 n_wg, n, dg, db, beta = args
                 rc = L.hftt_ln_bwd_reduce(ws['ln_ws_ptr'], n_wg, n, dg, db, beta, stream)
@@ -1096,7 +1098,13 @@ class HfttEngine:
     def _forward(self, spec, B, training, outputs, save):
         ws = self.workspace(B)
         self._cur_ws = ws
-        ws['bufs']['spec'].copy_(spec)
+        # the window gather reads the caller's tensor in place when it already is what the kernel wants (fp32, contiguous, on this device);
+        # anything else is converted into the workspace copy.  (torch's device-to-device copy_ is ~24 blit launches of 64 KB here: 80 us.)
+        if spec.is_cuda and spec.device == self.device and spec.dtype == torch.float32 and spec.is_contiguous():
+            ws['spec_ptr'], ws['spec_ref'] = spec.data_ptr(), spec
+        else:
+            ws['bufs']['spec'].copy_(spec)
+            ws['spec_ptr'], ws['spec_ref'] = ws['bufs']['spec'].data_ptr(), None
         T, N, V = self.T, self.N, self.V
         dev = self.device
         outs = outputs
