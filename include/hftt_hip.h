@@ -32,6 +32,17 @@ const char* hftt_last_error(void);
 int hftt_device_cus(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Dropout (nn.Dropout of model_spec2midi.py:95,236,242,372 and the attention probabilities :345).  Every kernel that drops takes
+ * (drop_p, drop_site, drop_seed) and decides element `idx` of its site (idx = row*N + col of the tensor it produces; attention:
+ * ((seq*H + head)*Lq + q)*Lk + k) with the counter-based generator of csrc/hftt_common.h:
+ *     key  = splitmix64 round over (drop_seed + 0x9E3779B97F4A7C15 * (drop_site + 1))
+ *     word = 32-bit two-multiply mix of (idx >> 2) with key          (one word per FOUR consecutive elements)
+ *     keep = byte (idx & 3) of word  <  round((1 - drop_p) * 256)
+ * kept elements are scaled by 1 / (1 - drop_p).  The backward of a site regenerates the same decisions from the same three numbers
+ * (no mask tensor exists); tests/util.py::keep_mask is the numpy restatement the tests compare against.
+ * --------------------------------------------------------------------------------------------- */
+
+/* ---------------------------------------------------------------------------------------------
  * Weight preparation.  fp32 parameters -> the layouts the GEMMs consume (concatenated / transposed), as a bf16
  * plane `wbf` (npass 1) and/or an fp32 copy `wf32` (npass 3); either may be NULL.
  * (replaces nothing in the reference: it is the operand format of the MFMA kernels).
