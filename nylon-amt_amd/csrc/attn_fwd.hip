@@ -22,6 +22,8 @@
 #define ABL(g, bit) false
 #endif
 
+int hftt_attn_fwd8_try(const hftt_attn_desc& d, hipStream_t st);      // attn_fwd8.hip
+
 namespace {
 
 // npass == 1: K/V as bf16 planes (layout notes below).  npass == 3 (parity): K/V stay fp32 in LDS and every product runs on
@@ -409,6 +411,12 @@ extern "C" int hftt_attn_fwd(const hftt_attn_desc* d0, void* stream) {
 #endif
   const hftt_attn_desc* d = &dd;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#ifndef HFTT_ATTN_ABLATE
+  {                                                   // the long-row form (attn_fwd8.hip) where it applies
+    const int rc8 = hftt_attn_fwd8_try(*d, st);
+    if (rc8 >= 0) return rc8;
+  }
+#endif
   const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
   const bool hb = (d->io_flags & all_half) == all_half && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 2 == 0 &&
                   d->q_seq_stride % 8 == 0 && d->k_seq_stride % 8 == 0 && d->v_seq_stride % 8 == 0 && d->o_seq_stride % 2 == 0;
