@@ -269,3 +269,28 @@ def test_pipelined_ffn_is_bit_identical(dev, monkeypatch, M):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     a, b = _both_forms(monkeypatch, lambda: ops.ffn_bwd_dx(x, wfb, pf, hid, gate_scale=1.0))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mover-wave form (csrc/strip_gemm4.hip, opt-in with HFTT_STRIP_V4=1): compute waves + mover waves, one barrier per ring slot.
+# Same operand order and epilogue arithmetic as the second form -> bit-identical, also on ragged last blocks and when a workgroup walks
+# several blocks (M = 70,016 = 547 blocks on 256 CUs).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M', [128, 4096, 38432, 70016])
+def test_mover_wave_linear_is_bit_identical(dev, monkeypatch, M):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + 7)
+    for (N, K) in ((768, 256), (512, 256), (256, 256), (256, 512), (256, 768)):
+        x = torch.randn(M, K, generator=g).to(dev).to(BF)
+        W = (torch.randn(N, K, generator=g) / 16).to(dev); b = torch.randn(N, generator=g).to(dev)
+        w = ops.strip_pack(W)
+        for kw in ({}, {'relu': True, 'drop_p': 0.1, 'drop_site': 2, 'drop_seed': 5}):
+            monkeypatch.setenv('HFTT_STRIP_V4', '0')
+            _scrub_lds(dev)
+            a = ops.strip_linear(x, w, N, bias=b, **kw)
+            monkeypatch.setenv('HFTT_STRIP_V4', '1')
+            _scrub_lds(dev)
+            c = ops.strip_linear(x, w, N, bias=b, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(a, c), (N, K, kw)
+    monkeypatch.setenv('HFTT_STRIP_V4', '0')
