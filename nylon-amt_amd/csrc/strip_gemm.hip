@@ -651,7 +651,9 @@ extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
     HFTT_REQUIRE(d->pre_ln_out == nullptr || ((uintptr_t)d->pre_ln_out & 15) == 0, "strip_linear: pre_ln_out alignment");
   }
   {                                                   // persistent software-pipelined forms where they apply (strip_gemm3.hip, then strip_gemm2.hip)
-    int rc = hftt_strip_linear4_try(*d, st);
+    int rc = hftt_strip_linear5_try(*d, st);
+    if (rc >= 0) return rc;
+    rc = hftt_strip_linear4_try(*d, st);
     if (rc >= 0) return rc;
     rc = hftt_strip_linear3_try(*d, st);
     if (rc >= 0) return rc;

@@ -17,7 +17,7 @@
 // slot in each role, plus the prologue's and the tail's), so both roles execute the same number of barriers by construction; there are
 // no flags and no spin waits.  Covered: bf16 tensors, no LayerNorm, no residual, K / 256 in {1, 2, 3}, N / 256 in {1, 2, 3}.
 //
-// RESULT (MI355X; tools/chk_v4.py, tools/ablate_v4.py).  Bit-identical to the second form on every shape.  Faster where the launch is short
+// RESULT (MI355X; tools/chk_forms.py, tools/ablate_v4.py).  Bit-identical to the second form on every shape.  Faster where the launch is short
 // (M = 38,432: 5-10 % on all five shapes) and on K = N = 256 at S_e (78 against 85 us); NOT faster on the big shapes (QKV at S_e 176-200 us
 // against 179 us) -- so it stays OPT-IN (HFTT_STRIP_V4=1).  What the role split makes measurable (QKV, S_e, HFTT_STRIP4_DEBUG bits):
 //     compute waves alone (movers idle, barriers kept)      107 us   (MFMAs + LDS reads only, no barriers: 95 us = 1,170 cycles per slot of 16 MFMAs)

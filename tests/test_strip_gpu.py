@@ -294,3 +294,27 @@ def test_mover_wave_linear_is_bit_identical(dev, monkeypatch, M):
             torch.cuda.synchronize()
             assert torch.equal(a, c), (N, K, kw)
     monkeypatch.setenv('HFTT_STRIP_V4', '0')
+
+
+# two-strips-per-wave form (csrc/strip_gemm5.hip, opt-in with HFTT_STRIP_V5=1): 256-token blocks, 128-column passes, with / without residual
+@pytest.mark.parametrize('M', [128, 4096, 38432, 70016])
+def test_two_strip_linear_is_bit_identical(dev, monkeypatch, M):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + 11)
+    for (N, K) in ((768, 256), (512, 256), (256, 256), (256, 512), (256, 768)):
+        x = torch.randn(M, K, generator=g).to(dev).to(BF)
+        W = (torch.randn(N, K, generator=g) / 16).to(dev); b = torch.randn(N, generator=g).to(dev)
+        res = torch.randn(M, N, generator=g).to(dev).to(BF)
+        w = ops.strip_pack(W)
+        for kw in ({}, {'relu': True, 'drop_p': 0.1, 'drop_site': 2, 'drop_seed': 5}, {'residual': res}, {'residual': res, 'drop_p': 0.1, 'drop_site': 1, 'drop_seed': 9}):
+            if 'residual' in kw and N != 256:
+                continue                              # (the model's residual forms are the dX projections, N = 256)
+            monkeypatch.setenv('HFTT_STRIP_V5', '0')
+            _scrub_lds(dev)
+            a = ops.strip_linear(x, w, N, bias=b, **kw)
+            monkeypatch.setenv('HFTT_STRIP_V5', '1')
+            _scrub_lds(dev)
+            c = ops.strip_linear(x, w, N, bias=b, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(a, c), (N, K, sorted(kw))
+    monkeypatch.setenv('HFTT_STRIP_V5', '0')
