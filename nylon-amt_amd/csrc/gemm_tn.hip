@@ -27,7 +27,17 @@ TnPlan tn_plan(int M, int N, int K) {
   TnPlan p;
   static int force_small = -1;
   if (force_small < 0) { const char* e = getenv("HFTT_TN_SMALL"); force_small = (e && e[0] == '1') ? 1 : 0; }
-  if (N >= 256 && K >= 256 && !force_small) { p.tm = 2; p.tn = 4; }
+  if (N >= 256 && K >= 256 && !force_small) {
+    p.tm = 2; p.tn = 4;
+    // Few token rows per split (S_n = 90,112 with N, K = 256 / 512: 352 / 704) make the 256 KB partial tile each workgroup writes to the
+    // slab -- and the reduce kernel reads back -- as large as its operands.  The 128 x 256 tile has twice the tiles, so half the splits for
+    // the same 256 workgroups: half the slab traffic, twice the steps per workgroup; X is then read by two tiles (same XCD: its L2).
+    const int tiles2 = ((N + 255) / 256) * ((K + 255) / 256);
+    int s2 = 256 / tiles2;
+    if (s2 >= 8) s2 = (256 / 8 / tiles2) * 8;
+    if (s2 < 1) s2 = 1;
+    if ((M + s2 - 1) / s2 < 1024) p.tm = 1;
+  }
   else if (N >= 128 && K >= 128) { p.tm = 1; p.tn = 2; }
   else { p.tm = 1; p.tn = 1; }
   p.tile_n = 128 * p.tm;
@@ -35,7 +45,7 @@ TnPlan tn_plan(int M, int N, int K) {
   p.n_tiles = (N + p.tile_n - 1) / p.tile_n;
   p.k_tiles = (K + p.tile_k - 1) / p.tile_k;
   const int tiles = p.n_tiles * p.k_tiles;
-  int target = (p.tm == 2) ? 256 : 512;
+  int target = (p.tm == 2 || p.tn == 4) ? 256 : 512;
   int splits = target / tiles;
   // the tiles of a split share an XCD (kernel: block -> (tile, split) map), so splits come in groups of eight and one group's
   // tiles must not exceed that XCD's share of the resident workgroups -- 33 workgroups on 32 CUs would run two rounds
@@ -388,6 +398,7 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   const bool dyb = d->io_flags & HFTT_TN_DY_BF16, xb = d->io_flags & HFTT_TN_X_BF16;
   if (d->npass == 3) {
     if (p.tm == 2) rc = launch_tn<2, 4, 3, false, false>(*d, p, st);
+    else if (p.tn == 4) rc = launch_tn<1, 4, 3, false, false>(*d, p, st);
     else if (p.tn == 2) rc = launch_tn<1, 2, 3, false, false>(*d, p, st);
     else rc = launch_tn<1, 1, 3, false, false>(*d, p, st);
   } else {
@@ -395,6 +406,7 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
     (dyb ? (xb ? launch_tn<TM_, TN_, 1, true, true>(*d, p, st) : launch_tn<TM_, TN_, 1, true, false>(*d, p, st)) \
          : (xb ? launch_tn<TM_, TN_, 1, false, true>(*d, p, st) : launch_tn<TM_, TN_, 1, false, false>(*d, p, st)))
     if (p.tm == 2) rc = HFTT_TN_GO(2, 4);
+    else if (p.tn == 4) rc = HFTT_TN_GO(1, 4);
     else if (p.tn == 2) rc = HFTT_TN_GO(1, 2);
     else rc = HFTT_TN_GO(1, 1);
 #undef HFTT_TN_GO
