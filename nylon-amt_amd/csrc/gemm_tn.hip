@@ -29,14 +29,12 @@ TnPlan tn_plan(int M, int N, int K) {
   if (force_small < 0) { const char* e = getenv("HFTT_TN_SMALL"); force_small = (e && e[0] == '1') ? 1 : 0; }
   if (N >= 256 && K >= 256 && !force_small) {
     p.tm = 2; p.tn = 4;
-    // Few token rows per split (S_n = 90,112 with N, K = 256 / 512: 352 / 704) make the 256 KB partial tile each workgroup writes to the
-    // slab -- and the reduce kernel reads back -- as large as its operands.  The 128 x 256 tile has twice the tiles, so half the splits for
-    // the same 256 workgroups: half the slab traffic, twice the steps per workgroup; X is then read by two tiles (same XCD: its L2).
-    const int tiles2 = ((N + 255) / 256) * ((K + 255) / 256);
-    int s2 = 256 / tiles2;
-    if (s2 >= 8) s2 = (256 / 8 / tiles2) * 8;
-    if (s2 < 1) s2 = 1;
-    if ((M + s2 - 1) / s2 < 1024) p.tm = 1;
+    // A single 256 x 256 output tile (N, K <= 256) means 256 splits, and the 256 KB partial tile each workgroup writes to the slab -- and
+    // the reduce kernel reads back -- is as large as the operands at S_n.  The 128 x 256 tile makes two tiles, so half the splits for the
+    // same 256 workgroups: half the slab traffic, twice the steps per workgroup; X is read by both tiles (same XCD: its L2).  Measured
+    // (tools/bench_tn.py, main + reduce): 45 -> 37 us at S_n, 80 -> 73 us at S_e.  With two or more 256-wide tiles the half tile only
+    // adds re-reads (N = 768 at S_e: 145 -> 182 us), so those keep the full tile.
+    if (N <= 256 && K <= 256) p.tm = 1;
   }
   else if (N >= 128 && K >= 128) { p.tm = 1; p.tn = 2; }
   else { p.tm = 1; p.tn = 1; }

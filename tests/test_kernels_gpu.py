@@ -265,7 +265,7 @@ def test_gemm_nt_bf16_storage(dev, M, N, K):
         assert rel_err(o, F.layer_norm(lin + res.double(), (N,), gam.double(), bet.double(), 1e-5)) < 1e-4
 
 
-# (below 1,024 token rows per split the plan takes the 128 x 256 tile; 262,144 rows keep the 256 x 256 tile of the encoder shapes)
+# (N, K <= 256 take the 128 x 256 tile, the wider shapes the 256 x 256 tile; the two long cases are the model's S_n and S_e row counts)
 @pytest.mark.parametrize('M,N,K', [(5000, 256, 256), (3000, 512, 256), (1000, 192, 256), (2000, 768, 256), (90112, 256, 256), (262144, 256, 256)])
 def test_gemm_tn_bf16_storage(dev, M, N, K):
     ops = _ops()
