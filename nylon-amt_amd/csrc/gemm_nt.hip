@@ -179,6 +179,17 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
     if (F32) {
       const float* As = sm32 + buf * Cfg::BUF_ELEMS;
       const float* Ws = As + Cfg::A_ELEMS;
+      // Two-level summation: the 32 k values of a stage are accumulated from zero (16 MFMA steps), then added to the running sum -- a
+      // chain of 16 + K/32 roundings instead of K/2.  One running accumulator over K = 256 measured 1.35x (rms) / 2x (max) the error of a
+      // CPU sgemm on the first encoder layer's Q / K projections (|x| ~ 600), and those feed logits of ~1e5 whose near-ties decide the
+      // first layer's gradients (tests/dev_layer_diff.py).
+      f32x16 part[TM][TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) part[i][j][r] = 0.f;
 #pragma unroll
       for (int t = 0; t < 16; t++) {
         float a[TM], b[TN];
@@ -189,8 +200,12 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) acc[i][j] = mfma32_f32(a[i], b[j], acc[i][j]);
+          for (int j = 0; j < TN; j++) part[i][j] = mfma32_f32(a[i], b[j], part[i][j]);
       }
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] += part[i][j];
     } else {
       const unsigned short* As = sm16 + buf * Cfg::BUF_ELEMS;
       const unsigned short* Ws = As + Cfg::A_ELEMS;

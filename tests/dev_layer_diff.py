@@ -85,3 +85,27 @@ if prec == 'parity' and 'g.eq' in b:
     print('fc_q.weight: fp64 product of the device buffers vs fp64 oracle rel=%.3g' % ((g_from_bufs - r64).abs().max().item() / sc))
     g32 = (b['g.eq'].cpu()[:, :d].T @ b['x0'].cpu().reshape(-1, d)).double()
     print('fc_q.weight: CPU fp32 product of the device buffers vs their fp64 product rel=%.3g' % ((g32 - g_from_bufs).abs().max().item() / sc))
+
+# ---- optional dump of layer 0's attention backward operands (first 8 sequences) for offline emulation: HFTT_DUMP_ATTN0=path.npz ----
+if prec == 'parity' and os.environ.get('HFTT_DUMP_ATTN0') and 'enc0.qkv' in b:
+    import numpy as np
+    ns, L = 8, Fq
+    np.savez_compressed(os.environ['HFTT_DUMP_ATTN0'],
+                        qkv=b['enc0.qkv'].float().cpu().numpy().reshape(-1, L, 3 * d)[:ns], ctx=b['enc0.ctx'].float().cpu().numpy().reshape(-1, L, d)[:ns],
+                        lse=b['enc0.lse'].float().cpu().numpy().reshape(-1)[:ns * cfg.enc_head * L * 2], dout=b['g.ex'].float().cpu().numpy().reshape(-1, L, d)[:ns],
+                        dqkv=b['g.eq'].float().cpu().numpy().reshape(-1, L, 3 * d)[:ns], heads=cfg.enc_head)
+    print('dumped', os.environ['HFTT_DUMP_ATTN0'])
+
+# ---- is layer 0's Q | K | V projection as accurate as a CPU sgemm?  (same device input x0, fp64 product as the reference) ----
+if prec == 'parity' and 'enc0.qkv' in b:
+    pa = e + 'layers_freq.0.self_attention.'
+    x0d = b['x0'].float().cpu().reshape(-1, d)
+    for i, nm in enumerate(('fc_q', 'fc_k', 'fc_v')):
+        W, bias = sd[pa + nm + '.weight'], sd[pa + nm + '.bias']
+        ref = x0d.double() @ W.double().T + bias.double()
+        cpu = (x0d @ W.T + bias).double()
+        devq = b['enc0.qkv'].float().cpu().reshape(-1, 3 * d)[:, i * d:(i + 1) * d].double()
+        sc = ref.abs().max().item()
+        print('%s: max|ref|=%.4g  device rel=%.3g (rms %.3g)   CPU sgemm rel=%.3g (rms %.3g)' % (
+            nm, sc, (devq - ref).abs().max().item() / sc, (devq - ref).pow(2).mean().sqrt().item() / sc,
+            (cpu - ref).abs().max().item() / sc, (cpu - ref).pow(2).mean().sqrt().item() / sc))

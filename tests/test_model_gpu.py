@@ -138,14 +138,66 @@ def test_golden_fixture(dev, name):
         e = max_err(gr[::st], ref) / stats[1]
         worst = max(worst, e)
         # Gradients that flow through the FIRST encoder layer's attention are ill-conditioned on raw log-mel input (logits
-        # ~1e4, near one-hot softmax): two correct fp32 implementations differ there by ~1e-3..1e-2 relative (the
-        # reference's own fp32 vs fp64: 1e-3 at tiny size).  Everything downstream of the first LayerNorm is tight.
+        # ~1e5, near one-hot softmax): two correct fp32 implementations differ there by ~1e-3..1e-2 relative -- against an fp64
+        # evaluation the device is at 2.5e-3 and a CPU fp32 run at 4e-3 on this input (test_parity_gradients_against_fp64_evaluation),
+        # the recorded reference run (another host, another BLAS blocking) at ~1.2e-2.  Everything downstream of the first LayerNorm is tight.
         first = any(t in pname for t in ('encoder_spec2midi.conv', 'tok_embedding_freq', 'encoder_spec2midi.pos_embedding_freq',
                                          'layers_freq.0.self_attention.fc_q', 'layers_freq.0.self_attention.fc_k')) and pname.startswith('encoder')
-        assert e < (3e-2 if first else 5e-3), (pname, e)
-        assert abs(gr.double().norm().item() - stats[2]) < (3e-2 if first else 2e-3) * stats[2], pname
+        if first:
+            rep['first_layer_worst'] = max(rep.get('first_layer_worst', 0.0), e)
+        assert e < (2e-2 if first else 5e-3), (pname, e)
+        assert abs(gr.double().norm().item() - stats[2]) < (2e-2 if first else 2e-3) * stats[2], pname
     rep['worst_grad_rel'] = worst
     print(name, 'parity:', json.dumps(rep))
+
+
+def test_parity_gradients_against_fp64_evaluation(dev):
+    """Paper size, B = 1: every parity-mode gradient against an fp64 evaluation of the oracle graph, with the same graph in CPU fp32 as the
+    yardstick.  The tensors behind the first encoder layer's attention (logits ~1e5, 99.6 % of the rows one-hot to 1e-6) are where any fp32
+    implementation is noisy: a CPU fp32 run is 3-4e-3 from fp64 there.  Since the fp32 MFMA GEMM sums each 32-wide k stage from zero before adding
+    it to the running sum (gemm_nt.hip), the device sits at the CPU's level (one running accumulator: 6x above it, 2.5e-2)."""
+    from hftt_hip.trainer import TrainStep
+    cfg, B, seed = O.PAPER, 1, 2024
+    model = util.build_model(cfg, seed)
+    util.perturb(model, seed + 1)
+    x = O.synth_spec(B, cfg, salt=seed)
+    labels = O.synth_labels(B, cfg, salt=seed + 7)
+    sd = util.sd_cpu(model)
+
+    def oracle_grads(dt):
+        p = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd.items()}
+        O.spec2midi_loss(O.model_forward(p, x.to(dt), cfg), *labels).backward()
+        return {k: v.grad.double().reshape(-1) for k, v in p.items() if v.grad is not None}
+
+    g64, g32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    model = model.to(dev)
+    model.hftt_precision = 'parity'
+    model.train()
+    ts = TrainStep(model)
+    ts.forward_backward(x.to(dev), *_to_dev(labels, dev))
+    worst, worst_first, worst_ratio, rows = 0.0, 0.0, 0.0, []
+    for (pname, _, o, n) in ts.engine._bound:
+        ref = g64[pname]
+        sc = ref.abs().max().item()
+        if sc < 1e-7:
+            continue                                  # (fc_k biases: exactly zero gradient in exact arithmetic)
+        e_dev = (ts.engine.flat_grads[o:o + n].cpu().double() - ref).abs().max().item() / sc
+        e_cpu = (g32[pname] - ref).abs().max().item() / sc
+        first = any(t in pname for t in ('encoder_spec2midi.conv', 'tok_embedding_freq', 'encoder_spec2midi.pos_embedding_freq',
+                                         'layers_freq.0.self_attention.fc_q', 'layers_freq.0.self_attention.fc_k')) and pname.startswith('encoder')
+        if first:
+            worst_first = max(worst_first, e_dev)
+            worst_ratio = max(worst_ratio, e_dev / max(e_cpu, 1e-12))
+            rows.append((pname, e_dev, e_cpu))
+        else:
+            worst = max(worst, e_dev)
+            assert e_dev < 5e-3, (pname, e_dev, e_cpu)
+    for r in rows:
+        print('  %-66s device %.2e  cpu fp32 %.2e' % r)
+    print('parity gradients vs fp64 (paper B=1): others worst %.2e, first-layer worst %.2e (at most %.2f x the CPU fp32 error)' % (worst, worst_first, worst_ratio))
+    # the noise of these tensors is heavy-tailed (a handful of near-tied rows decide it) and moves with the seed: 2.5e-3 .. 9e-3 on the device,
+    # 3e-3 .. 5e-3 on the CPU.  Bound: a small multiple of the CPU's own error (it was 6x before the two-level sum), and 1.5e-2 absolute.
+    assert worst_ratio < 3.0 and worst_first < 1.5e-2, (worst_ratio, worst_first)
 
 
 def test_bf16_mode_error_and_frame_f1(dev):
