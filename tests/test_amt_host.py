@@ -88,3 +88,63 @@ def test_mpe2note_matches_reference(tmp_path):
     b = f.read_bytes()
     assert b[:4] == b'MThd' and b[14:18] == b'MTrk'
     assert bytes([0x90, 60, 100]) in b and bytes([0x90, 64, 64]) in b and bytes([0x90, 60, 0]) in b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# WAV loader and resampler of wav2feature (reference: torchaudio.load + transforms.Resample, amt.py:55-58; torchaudio is
+# not in this image, so the resampler is a restatement of its published algorithm -- checked here against analytic
+# signals and against scipy's polyphase resampler as an independent implementation).
+# ---------------------------------------------------------------------------------------------------------------------
+import math
+import pytest
+
+
+@pytest.mark.parametrize('sr_in', [44100, 48000, 22050, 8000])
+def test_resample_reproduces_a_band_limited_signal(sr_in):
+    from model.amt import _resample
+    sr_out, dur = 16000, 0.25
+    n = int(sr_in * dur)
+    f1, f2 = 440.0, 2500.0                                    # both below every Nyquist involved
+    t_in = torch.arange(n, dtype=torch.float64) / sr_in
+    x = (0.6 * torch.sin(2 * math.pi * f1 * t_in) + 0.3 * torch.cos(2 * math.pi * f2 * t_in)).float()
+    y = _resample(x, sr_in, sr_out)
+    g = math.gcd(sr_in, sr_out)
+    assert y.numel() == math.ceil((sr_out // g) * n / (sr_in // g))               # torchaudio's output length
+    t_out = torch.arange(y.numel(), dtype=torch.float64) / sr_out
+    ref = 0.6 * torch.sin(2 * math.pi * f1 * t_out) + 0.3 * torch.cos(2 * math.pi * f2 * t_out)
+    edge = 64                                                                      # the filter's support at the borders sees zero padding
+    err = (y.double() - ref)[edge:-edge].abs().max().item()
+    assert err < 5e-3, err
+    from scipy.signal import resample_poly
+    z = resample_poly(x.double().numpy(), sr_out // g, sr_in // g)
+    m = min(len(z), y.numel())
+    assert np.abs(z[edge:m - edge] - y.double().numpy()[edge:m - edge]).max() < 2e-2
+
+
+def test_resample_removes_what_the_new_rate_cannot_carry():
+    from model.amt import _resample
+    sr_in, sr_out = 44100, 16000
+    t = torch.arange(sr_in // 4, dtype=torch.float64) / sr_in
+    tone = torch.sin(2 * math.pi * 11000.0 * t).float()                            # above the new Nyquist (8 kHz)
+    y = _resample(tone, sr_in, sr_out)
+    assert y[64:-64].abs().max().item() < 2e-2
+    dc = _resample(torch.ones(sr_in // 4), sr_in, sr_out)
+    assert (dc[64:-64] - 1.0).abs().max().item() < 2e-3                            # unit gain in the pass band
+
+
+@pytest.mark.parametrize('dtype,scale,offset', [(np.int16, 32768.0, 0.0), (np.int32, 2147483648.0, 0.0), (np.uint8, 128.0, 128.0), (np.float32, 1.0, 0.0)])
+def test_wav_loader_scales_and_orders_channels(tmp_path, dtype, scale, offset):
+    from scipy.io import wavfile
+    from model.amt import _load_wav
+    rng = np.random.default_rng(3)
+    want = rng.uniform(-0.9, 0.9, size=(1000, 2)).astype(np.float32)               # [frames, channels] as wavfile stores it
+    raw = want if dtype == np.float32 else np.round(want * scale + offset).astype(dtype)
+    p = tmp_path / 'a.wav'
+    wavfile.write(str(p), 22050, raw)
+    x, sr = _load_wav(str(p))
+    assert sr == 22050 and x.shape == (2, 1000) and x.dtype == np.float32 and x.flags['C_CONTIGUOUS']
+    assert np.abs(x.T - want).max() <= (1.0 / scale if dtype != np.float32 else 0.0) + 1e-7
+    mono = tmp_path / 'm.wav'
+    wavfile.write(str(mono), 16000, raw[:, 0].copy())
+    x1, sr1 = _load_wav(str(mono))
+    assert sr1 == 16000 and x1.shape == (1, 1000)
