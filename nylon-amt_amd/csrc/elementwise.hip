@@ -590,7 +590,7 @@ inline int grid_for(long work_items, int block, int cap = 4096) {
 extern "C" int hftt_prep_weights(const float* params, uint16_t* wbf, float* wf32, float* fdst,
                                  const hftt_prep_entry* table_dev, int n_entries, void* stream) {
   HFTT_REQUIRE(params && (wbf || wf32 || fdst) && table_dev && n_entries > 0, "prep_weights: null operand");
-  hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)n_entries, 8), dim3(256), 0, (hipStream_t)stream, params, wbf, wf32, fdst, table_dev);
+  hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)n_entries, 48), dim3(256), 0, (hipStream_t)stream, params, wbf, wf32, fdst, table_dev);
   HFTT_CHECK_LAUNCH("prep_weights");
   return 0;
 }

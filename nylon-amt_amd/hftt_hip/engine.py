@@ -287,12 +287,10 @@ class HfttEngine:
         self.wbf = torch.zeros(n_w if self.npass == 1 else 8, dtype=torch.int16, device=self.device)
         self.wf32 = torch.zeros(n_w if self.npass == 3 else 8, dtype=torch.float32, device=self.device)
         self.fprep = torch.zeros(_align(fl.off, 8), dtype=torch.float32, device=self.device)
-        arr = (PrepEntry * len(entries))()
-        for i, (so, do, r, c_, sld, dld, kind) in enumerate(entries):
-            arr[i] = PrepEntry(so, do, r, c_, sld, dld, kind, 0)
-        raw = bytes(arr)
-        self.prep_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-        self.n_prep = len(entries)
+        self._prep_entries = list(entries)
+        self._wl_regions = sorted((off, name) for name, off in wl.items.items())      # matrix planes by element offset
+        self._wp_used, self._prep_built_for = set(), -1
+        self._set_prep_table(entries)
         self.n_spack = len(sentries)
         if sentries:
             self.wstrip = torch.zeros(_align(sl.off, 512), dtype=torch.int16, device=self.device)
@@ -312,8 +310,36 @@ class HfttEngine:
                              self.G(e + 'conv.weight'), self.G(e + 'conv.bias'), self.G(e + 'tok_embedding_freq.weight'),
                              self.G(e + 'tok_embedding_freq.bias'))
 
+    def _set_prep_table(self, entries):
+        arr = (PrepEntry * len(entries))()
+        for i, (so, do, r, c_, sld, dld, kind) in enumerate(entries):
+            arr[i] = PrepEntry(so, do, r, c_, sld, dld, kind, 0)
+        self.prep_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self.n_prep = len(entries)
+
+    # per-block matrix planes that only the general GEMM reads: with the strip plans most of them are never asked for (the strip packs
+    # replace them), and preparing all of them every step cost 80 us.  A plane is prepared once any launch plan has asked for it (Wp).
+    _BLOCK_PLANES = ('.qkv', '.qkv_t', '.o', '.o_t', '.q', '.q_t', '.kv', '.kv_t', '.f1', '.f1_t', '.f2', '.f2_t')
+
+    def _refresh_prep_table(self):
+        if not self.strip or self._prep_built_for == len(self._wp_used):
+            return
+        import bisect
+        offs = [o for o, _ in self._wl_regions]
+        keep = []
+        for ent in self._prep_entries:
+            do, kind = ent[1], ent[6]
+            if kind != 2:                            # (kind 2: vectors in the fp32 plane, always prepared)
+                name = self._wl_regions[bisect.bisect_right(offs, do) - 1][1]
+                if name.endswith(self._BLOCK_PLANES) and name not in self._wp_used:
+                    continue
+            keep.append(ent)
+        self._set_prep_table(keep)
+        self._prep_built_for = len(self._wp_used)
+
     def Wp(self, key):   # device address of a prepared matrix (bf16 plane or fp32 copy, by precision)
         o = self.Woff[key]
+        self._wp_used.add(key)
         return (self.wbf.data_ptr() + 2 * o) if self.npass == 1 else (self.wf32.data_ptr() + 4 * o)
 
     def Fp(self, key):
@@ -328,6 +354,7 @@ class HfttEngine:
         parameters constant (``frozen_weights``: inference servers; model.amt.AMT does), then once."""
         if self.frozen_weights and self._prepared_frozen:
             return
+        self._refresh_prep_table()
         check(self.lib.hftt_prep_weights(self.flat_params.data_ptr(), self.wbf.data_ptr() if self.npass == 1 else 0,
                                          self.wf32.data_ptr() if self.npass == 3 else 0,
                                          self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights')
