@@ -468,7 +468,7 @@ __global__ void heads_split_bwd_kernel(const float* __restrict__ p_on, const flo
 }
 
 // ------------------------------------------------------------------ fused loss (6x BCE + 2x CE) and its gradient
-constexpr int LOSS_WGS = 1024;
+constexpr int LOSS_WGS = 4096;
 __global__ __launch_bounds__(256) void loss_kernel(const hftt_loss_desc g) {
   __shared__ float red[4][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -523,12 +523,80 @@ __global__ __launch_bounds__(256) void loss_kernel(const hftt_loss_desc g) {
   __syncthreads();
   if (threadIdx.x < 8) g.ws[(long)blockIdx.x * 8 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
+// V <= 128, V % 4 == 0 (the model's 128 velocity classes): half a wave per element, four classes per lane -- 16-byte loads and stores, two
+// elements per wave step (the general kernel above moves 4 bytes per lane and keeps 58 lanes idle in its BCE part: 1.5 TB/s).
+__device__ __forceinline__ float half_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+  return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
+  v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return v;
+}
+__global__ __launch_bounds__(256) void loss_v4_kernel(const hftt_loss_desc g) {
+  __shared__ float red[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l32 = lane & 31, hf = lane >> 5;
+  const float inv_n = 1.0f / (float)g.n;
+  float part = 0.f;    // per half: lanes 0..5 BCE terms; lanes 6,7 CE terms (A, B)
+  for (long el0 = ((long)blockIdx.x * 4 + wave) * 2; el0 < g.n; el0 += (long)gridDim.x * 8) {
+    const long el = el0 + hf;
+    const bool ok = el < g.n;                       // (odd n: the second half of the last pair idles, but takes part in the shuffles)
+    const long elc = ok ? el : g.n - 1;
+    if (l32 < 6 && ok) {
+      const float p = g.prob[l32][el];
+      const float y = (l32 % 3 == 0) ? g.label_onset[el] : ((l32 % 3 == 1) ? g.label_offset[el] : g.label_mpe[el]);
+      const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
+      part += -(y * lp + (1.f - y) * l1p);
+      if (g.d_prob[l32] != nullptr) {
+        const float w = (l32 < 3) ? g.weight_A : g.weight_B;
+        g.d_prob[l32][el] = (p - y) / fmaxf((1.f - p) * p, 1e-12f) * (w * inv_n * g.grad_scale);
+      }
+    }
+    const int label = (int)g.label_velocity[elc];
+    const int c0 = 4 * l32;
+    const bool cok = c0 < g.V;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const float* lg = g.vel[side] + elc * g.V;
+      float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (cok) v = *reinterpret_cast<const float4*>(lg + c0);
+      const float mx = half_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+      float4 ex = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cok) ex = make_float4(expf(v.x - mx), expf(v.y - mx), expf(v.z - mx), expf(v.w - mx));
+      const float s = half_sum((ex.x + ex.y) + (ex.z + ex.w));
+      const float lse = mx + logf(s);
+      const int k = label - c0;
+      float picked = (k == 0) ? v.x : (k == 1) ? v.y : (k == 2) ? v.z : (k == 3) ? v.w : 0.f;
+      picked = half_sum(picked);
+      if (l32 == 6 + side && ok) part += lse - picked;
+      if (g.d_vel[side] != nullptr && cok && ok) {
+        const float w = (side == 0 ? g.weight_A : g.weight_B) * inv_n * g.grad_scale;
+        const float inv_s = 1.0f / s;
+        float4 o;
+        o.x = (ex.x * inv_s - (k == 0 ? 1.f : 0.f)) * w; o.y = (ex.y * inv_s - (k == 1 ? 1.f : 0.f)) * w;
+        o.z = (ex.z * inv_s - (k == 2 ? 1.f : 0.f)) * w; o.w = (ex.w * inv_s - (k == 3 ? 1.f : 0.f)) * w;
+        *reinterpret_cast<float4*>(g.d_vel[side] + el * g.V + c0) = o;
+      }
+    }
+  }
+  part += __shfl_xor(part, 32, 64);                 // the two halves' terms
+  if (lane < 8) red[wave][lane] = part;
+  __syncthreads();
+  if (threadIdx.x < 8) g.ws[(long)blockIdx.x * 8 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const hftt_loss_desc g, int n_wg) {
   __shared__ float red[32][8];
   const int term = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  float acc = 0.f;
-  for (int w = grp; w < n_wg; w += 32) acc += g.ws[(long)w * 8 + term];
-  red[grp][term] = acc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four independent chains (fixed order: the sum is reproducible), loads in flight together
+  int w = grp;
+  for (; w + 96 < n_wg; w += 128) {
+    const float v0 = g.ws[(long)w * 8 + term], v1 = g.ws[(long)(w + 32) * 8 + term], v2 = g.ws[(long)(w + 64) * 8 + term], v3 = g.ws[(long)(w + 96) * 8 + term];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; w < n_wg; w += 32) a0 += g.ws[(long)w * 8 + term];
+  red[grp][term] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (threadIdx.x < 8) {
     float s = 0.f;
@@ -703,8 +771,11 @@ extern "C" int hftt_loss(const hftt_loss_desc* d, void* stream) {
   for (int i = 0; i < 6; i++) HFTT_REQUIRE(d->prob[i] != nullptr, "loss: null probability tensor %d", i);
   HFTT_REQUIRE(d->vel[0] && d->vel[1] && d->label_onset && d->label_offset && d->label_mpe && d->label_velocity && d->loss_out && d->ws, "loss: null operand");
   int wgs = (int)((d->n + 3) / 4);
+  const bool v4 = d->V <= 128 && d->V % 4 == 0 && (((uintptr_t)d->vel[0] | (uintptr_t)d->vel[1] | (uintptr_t)d->d_vel[0] | (uintptr_t)d->d_vel[1]) & 15) == 0;
+  if (v4) wgs = (int)((d->n + 7) / 8);
   if (wgs > LOSS_WGS) wgs = LOSS_WGS;
-  hipLaunchKernelGGL(loss_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  if (v4) hipLaunchKernelGGL(loss_v4_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(loss_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   HFTT_CHECK_LAUNCH("loss");
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d, wgs);
   HFTT_CHECK_LAUNCH("loss_reduce");

@@ -25,7 +25,7 @@ def _st(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-@pytest.mark.parametrize('V,n', [(128, 8 * 16 * 11), (16, 1000), (5, 37)])
+@pytest.mark.parametrize('V,n', [(128, 8 * 16 * 11), (128, 1001), (16, 1000), (12, 77), (5, 37), (130, 50)])
 def test_loss_kernel_values_and_gradients(dev, V, n):
     """training/train.py:141-153: 6x BCELoss(mean) (log clamped at -100, like torch) + 2x CrossEntropyLoss(mean), weights wA / wB."""
     capi, L = _lib()
