@@ -222,7 +222,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='clips per GPU')
     ap.add_argument('--config', default='paper', choices=['paper', 'tiny'])
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'parity'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'x3', 'parity'])
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--data', default='synthetic', choices=['synthetic', 'store'],
                     help="'store': every step gathers its clips from a device-resident MAESTRO-format store (the gather is inside the step)")
@@ -344,7 +344,7 @@ def main():
     result = None
     if rank == 0:
         value = B * world * args.steps / dt
-        peak_tf = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+        peak_tf = PEAK_F32_TFLOPS if args.precision == 'parity' else PEAK_BF16_TFLOPS
         roof = roof_ffn = kernels = None
         extras = {}
         if prof is not None:

@@ -13,9 +13,15 @@
  *     operands may be stored as bf16 (`io_flags` of each descriptor; leading dimensions and strides then count bf16
  *     elements) -- numerically identical to rounding at load time, half the traffic.  `npass` selects the MFMA arithmetic:
  *       1 = operands rounded to bf16, fp32 accumulate (v_mfma_f32_32x32x16_bf16): the "bf16" throughput mode,
- *       3 = exact fp32 products and accumulation (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate): the <=1e-3
- *           parity mode.  (A 3-pass split-bf16 scheme was measured first: its ~1e-5 relative error is not enough
- *           for the reference's first encoder layer, whose attention logits reach ~1e4 on raw log-mel input.)
+ *       2 = "x3", split fp16: every fp32 operand is carried as fp16 hi + fp16 lo and a product as three MFMA passes
+ *           (lo.hi + hi.lo + hi.hi, v_mfma_f32_32x32x16_f16, fp32 accumulate): ~22 significant bits, outputs within 1.3e-4 of the
+ *           fp32 reference at paper size (budget 1e-3) at 3/16 of the cost of (3).  All tensors fp32 in HBM.  Forward products.
+ *       3 = exact fp32 products and accumulation (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate): the round-1 parity mode,
+ *       4 = "x3", split bf16 (bf16 hi + bf16 lo, three passes): ~16 significant bits with fp32's exponent range: products with a
+ *           GRADIENT operand (1e-4 .. 1e-10 in magnitude: subnormal or zero as fp16).  On the forward it is not enough for the
+ *           reference's first encoder layer, whose attention logits reach ~1e5 on raw log-mel input (velocity logits 1.2e-3 off).
+ *     hftt_attn_bwd with npass 2 recomputes the scores in split fp16 (bit for bit the forward's) and forms the four gradient
+ *     products in split bf16.
  */
 #ifndef HFTT_HIP_H
 #define HFTT_HIP_H
@@ -24,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HFTT_ABI_VERSION 3
+#define HFTT_ABI_VERSION 4
 
 int hftt_abi_version(void);
 const char* hftt_last_error(void);
@@ -60,6 +66,11 @@ typedef struct {
 } hftt_prep_entry;
 int hftt_prep_weights(const float* params, uint16_t* wbf, float* wf32, float* fdst,
                       const hftt_prep_entry* table_dev, int n_entries, void* stream);
+/* The same table for the split ("x3") modes: every matrix entry is written as TWO 16-bit planes, whi[dst] + wlo[dst] ~ the fp32 value,
+ * with the entry's `pad` field naming the element type (2 = fp16 for the forward matrices, 4 = bf16 for the transposed matrices of
+ * the dX products); kind 2 entries copy fp32 vectors into fdst as above. */
+int hftt_prep_weights_x3(const float* params, uint16_t* whi, uint16_t* wlo, float* fdst,
+                         const hftt_prep_entry* table_dev, int n_entries, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * NT GEMM with fused epilogue:  C[M,N] = epi( A[M,K] . W[N,K]^T + bias )
@@ -76,7 +87,8 @@ int hftt_prep_weights(const float* params, uint16_t* wbf, float* wf32, float* fd
  *                 mean/rstd written per row                              (nn.LayerNorm, :225,236)
  *   C[row*ldc+col] = v
  * W is the prepared matrix [N_pad, K] (K % 32 == 0, N_pad % 64 == 0, rows >= N zero): bf16 when npass == 1,
- * fp32 when npass == 3 (passed through the same pointer).
+ * fp32 when npass == 3 (passed through the same pointer); npass 2 / 4: the hi plane in W and the lo plane in W_lo
+ * (hftt_prep_weights_x3), A / C / residual / gate fp32.
  * --------------------------------------------------------------------------------------------- */
 #define HFTT_NT_A_BF16 1u
 #define HFTT_NT_C_BF16 2u      /* not with LayerNorm */
@@ -96,6 +108,7 @@ typedef struct {
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   const float* residual; int64_t ldr; int32_t res_mod;
   const float* ln_gamma; const float* ln_beta; float* pre_ln_out; float* ln_mean; float* ln_rstd;
+  const void* W_lo;                               /* npass 2 / 4: lo plane of the prepared weights (same layout as W) */
 } hftt_gemm_nt_desc;
 int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream);
 
@@ -197,7 +210,7 @@ typedef struct {
   int32_t K_out;             /* number of K columns to write (<= K), destination leading dim */
   uint32_t io_flags;         /* HFTT_TN_* (npass 1 only) */
   void* ws; int64_t ws_bytes;
-} hftt_gemm_tn_desc;
+} hftt_gemm_tn_desc;          /* npass 4 (split bf16): dY and X fp32, both split on their way into LDS */
 int64_t hftt_gemm_tn_ws_bytes(int32_t M, int32_t N, int32_t K);
 int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream);
 
@@ -254,6 +267,7 @@ typedef struct {
   const float* dweff;   /* [d, Kp] */
   const float* dbeff;   /* [d] */
   float* g_wconv; float* g_bconv; float* g_wtok; float* g_btok;
+  uint16_t* weff_hi; uint16_t* weff_lo;   /* split fp16 planes of Weff for the x3 mode (both or neither) */
 } hftt_fold_desc;
 int hftt_embed_fold_fwd(const hftt_fold_desc* d, void* stream);
 int hftt_embed_fold_bwd(const hftt_fold_desc* d, void* stream);

@@ -11,6 +11,7 @@
 #include <type_traits>
 #include "hftt_common.h"
 #include "hftt_host.h"
+#include "x3_internal.h"
 #include "../../include/hftt_hip.h"
 #include <math.h>
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
   constexpr float LOG2E = 1.4426950408889634f;
   const float c2 = scale * LOG2E;
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   // one hash per four elements needs Lk % 4 == 0 and quad indices below 2^32 for the whole launch (attn_fwd.hip makes the same choice;
   // either way the decisions are those of hftt_keep)
   const bool pair_ok = (Lk & 3) == 0 && (((uint64_t)g.n_seq * (uint64_t)g.n_heads * (uint64_t)g.Lq * (uint64_t)Lk) >> 34) == 0;
@@ -525,6 +526,7 @@ extern "C" int hftt_attn_bwd(const hftt_attn_desc* d0, void* stream) {
   const bool hb = (d->io_flags & all_half) == all_half && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 8 == 0 &&
                   d->q_seq_stride % 8 == 0 && d->k_seq_stride % 8 == 0 && d->v_seq_stride % 8 == 0 && d->o_seq_stride % 8 == 0;
   HFTT_REQUIRE(!(d->io_flags & HFTT_ATTN_DQ_BF16) || (d->lddq % 2 == 0 && d->dq_seq_stride % 2 == 0), "attn_bwd: bf16 dq needs even strides");
+  if (d->npass == 2) return hftt_x3_attn_bwd(*d, st);
   if (d->npass == 3) return d->dh == 64 ? dispatch_ab<64, 3, false>(*d, st) : dispatch_ab<32, 3, false>(*d, st);
   if (d->dh == 64) return hb ? dispatch_ab<64, 1, true>(*d, st) : dispatch_ab<64, 1, false>(*d, st);
   return hb ? dispatch_ab<32, 1, true>(*d, st) : dispatch_ab<32, 1, false>(*d, st);

@@ -9,6 +9,7 @@
 #include <type_traits>
 #include "hftt_common.h"
 #include "hftt_host.h"
+#include "x3_internal.h"
 #include "../../include/hftt_hip.h"
 #include <math.h>
 
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
 
   const float scale = 1.0f / sqrtf((float)DH);
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const int nqb = (Lq + 31) / 32;
   const bool vec_probs = (Lk % 4) == 0;
   const uint64_t hk = hftt_hash_key(g.drop_seed, g.drop_site);
@@ -386,7 +387,7 @@ int hftt_attn_check(const hftt_attn_desc* d, bool bwd) {
   HFTT_REQUIRE(d->n_seq > 0 && d->n_heads > 0, "attn: bad batch");
   HFTT_REQUIRE(d->Lq >= 1 && d->Lq <= 256 && d->Lk >= 1 && d->Lk <= 256, "attn: Lq=%d Lk=%d must be in 1..256", d->Lq, d->Lk);
   HFTT_REQUIRE(d->dh == 32 || d->dh == 64, "attn: head_dim=%d must be 32 or 64", d->dh);
-  HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "attn: npass must be 1 or 3");
+  HFTT_REQUIRE(d->npass == 1 || d->npass == 2 || d->npass == 3, "attn: npass must be 1 (bf16), 2 (split fp16 / bf16) or 3 (fp32)");
   HFTT_REQUIRE(d->q && d->k && d->v && d->out && d->lse, "attn: null operand");
   HFTT_REQUIRE(d->ldq % 4 == 0 && d->ldk % 4 == 0 && d->ldv % 4 == 0 && d->ldo % 4 == 0, "attn: row strides must be multiples of 4");
   HFTT_REQUIRE(d->q_seq_stride % 4 == 0 && d->k_seq_stride % 4 == 0 && d->v_seq_stride % 4 == 0, "attn: seq strides must be multiples of 4");
@@ -411,6 +412,7 @@ extern "C" int hftt_attn_fwd(const hftt_attn_desc* d0, void* stream) {
 #endif
   const hftt_attn_desc* d = &dd;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->npass == 2) return hftt_x3_attn_fwd(*d, st);
 #ifndef HFTT_ATTN_ABLATE
   {                                                   // the long-row form (attn_fwd8.hip) where it applies
     const int rc8 = hftt_attn_fwd8_try(*d, st);

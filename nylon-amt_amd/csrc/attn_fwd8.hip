@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const hftt_attn_desc 
   constexpr float LOG2E = 1.4426950408889634f;
   const float c2 = scale * LOG2E;
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const uint64_t hk = hftt_hash_key(g.drop_seed, g.drop_site);
   const bool quad_ok = (Lk & 3) == 0 && (((uint64_t)g.n_seq * (uint64_t)g.n_heads * (uint64_t)Lq * (uint64_t)Lk) >> 34) == 0;
   int lh4 = 4 * lh;                                    // opaque (attn_fwd.hip: keeps per-register key numbers out of LICM's reach)

@@ -3,11 +3,20 @@
 // All of them stream fp32 with 16-byte accesses where the layout allows; reductions are two-stage and
 // deterministic (no float atomics).  Entry points and reference citations: include/hftt_hip.h.
 #include "hftt_common.h"
+#include "x3_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
 #include <math.h>
 
 namespace {
+
+// one fp32 value -> the two 16-bit halves of the split ("x3") operand form
+template <int E>
+__device__ __forceinline__ void x3_split1(float x, uint16_t& hi, uint16_t& lo) {
+  unsigned h, l;
+  x3_split2<E>(x, 0.f, h, l);
+  hi = (uint16_t)(h & 0xFFFFu); lo = (uint16_t)(l & 0xFFFFu);
+}
 
 // ------------------------------------------------------------------ weight preparation
 __global__ void prep_weights_kernel(const float* __restrict__ params, uint16_t* __restrict__ wbf, float* __restrict__ wf32,
@@ -23,6 +32,25 @@ __global__ void prep_weights_kernel(const float* __restrict__ params, uint16_t* 
       const long d = (e.kind == 1) ? (e.dst_off + (long)c * e.dst_ld + r) : (e.dst_off + (long)r * e.dst_ld + c);
       if (wbf != nullptr) wbf[d] = f2bf(x);
       if (wf32 != nullptr) wf32[d] = x;
+    }
+  }
+}
+
+// the same table, matrices as two 16-bit planes (hi + lo ~ the fp32 value); e.pad = element type (2 fp16, 4 bf16)
+__global__ void prep_weights_x3_kernel(const float* __restrict__ params, uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo,
+                                       float* __restrict__ fdst, const hftt_prep_entry* __restrict__ table) {
+  const hftt_prep_entry e = table[blockIdx.x];
+  const long total = (long)e.rows * e.cols;
+  for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.y * blockDim.x) {
+    const int r = (int)(i / e.cols), c = (int)(i % e.cols);
+    const float x = params[e.src_off + (long)r * e.src_ld + c];
+    if (e.kind == 2) {
+      fdst[e.dst_off + (long)r * e.dst_ld + c] = x;
+    } else {
+      const long d = (e.kind == 1) ? (e.dst_off + (long)c * e.dst_ld + r) : (e.dst_off + (long)r * e.dst_ld + c);
+      uint16_t hi, lo;
+      if (e.pad == X3_BF16) x3_split1<X3_BF16>(x, hi, lo); else x3_split1<X3_F16>(x, hi, lo);
+      whi[d] = hi; wlo[d] = lo;
     }
   }
 }
@@ -44,6 +72,7 @@ __global__ void fold_fwd_kernel(const hftt_fold_desc f) {
     }
     if (f.weff_bf != nullptr) f.weff_bf[i] = f2bf(acc);
     if (f.weff_f32 != nullptr) f.weff_f32[i] = acc;
+    if (f.weff_hi != nullptr) x3_split1<X3_F16>(acc, f.weff_hi[i], f.weff_lo[i]);
     if (u == 0 && j < f.d) {
       float b = f.btok[j];
       for (int c = 0; c < f.C; c++) {
@@ -126,7 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
   __shared__ float red[4][2][N];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const bool dy_bf = g.io_flags & HFTT_LNB_DY_BF16, dr_bf = g.io_flags & HFTT_LNB_DR_BF16, r_bf = g.io_flags & HFTT_LNB_R_BF16;
   float gam[VPL], dg[VPL], db[VPL];
 #pragma unroll
@@ -216,7 +245,7 @@ __global__ __launch_bounds__(256) void ln_bwd256_bf16_kernel(const hftt_ln_bwd_d
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane >> 4, cl = lane & 15;               // row within the group of four, 16-column chunk
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const bool drop = g.dr_drop != nullptr && g.drop_p > 0.f;
   const unsigned short* dyp = reinterpret_cast<const unsigned short*>(g.dy);
   const unsigned short* rp = reinterpret_cast<const unsigned short*>(g.r);
@@ -331,7 +360,7 @@ __global__ void time_embed_fwd_kernel(const float* __restrict__ x, const float* 
   const int d4 = d / 4;
   const long total = (long)B * Nn * T * d4;
   const uint32_t thr = hftt_keep_thr(drop_p);
-  const float inv_keep = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(drop_p);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % d4);
     const long orow = i / d4;                      // (b*Nn + n)*T + t
@@ -355,7 +384,7 @@ __global__ void time_embed_bwd_kernel(const float* __restrict__ dy, float* __res
   const int d4 = d / 4;
   const long total = (long)B * Nn * T * d4;
   const uint32_t thr = hftt_keep_thr(drop_p);
-  const float inv_keep = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(drop_p);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % d4);
     const long orow = i / d4;
@@ -377,7 +406,7 @@ __global__ void time_embed_bwd_kernel(const float* __restrict__ dy, float* __res
 }
 __global__ void dropout_bwd_kernel(float* __restrict__ gbuf, long n, float drop_p, uint32_t site, uint64_t seed, uint32_t bf) {
   const uint32_t thr = hftt_keep_thr(drop_p);
-  const float inv_keep = 1.0f / (1.0f - drop_p);
+  const float inv_keep = hftt_keep_scale(drop_p);
   const long n4 = n >> 2;                          // n % 4 == 0 (host check): 4 consecutive elements = one hash quad per thread
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const float4 a = hftt_load4(gbuf, bf, i * 4);
@@ -663,8 +692,17 @@ extern "C" int hftt_prep_weights(const float* params, uint16_t* wbf, float* wf32
   return 0;
 }
 
+extern "C" int hftt_prep_weights_x3(const float* params, uint16_t* whi, uint16_t* wlo, float* fdst,
+                                    const hftt_prep_entry* table_dev, int n_entries, void* stream) {
+  HFTT_REQUIRE(params && whi && wlo && table_dev && n_entries > 0, "prep_weights_x3: null operand");
+  hipLaunchKernelGGL(prep_weights_x3_kernel, dim3((unsigned)n_entries, 48), dim3(256), 0, (hipStream_t)stream, params, whi, wlo, fdst, table_dev);
+  HFTT_CHECK_LAUNCH("prep_weights_x3");
+  return 0;
+}
+
 extern "C" int hftt_embed_fold_fwd(const hftt_fold_desc* d, void* stream) {
-  HFTT_REQUIRE(d && d->wconv && d->bconv && d->wtok && d->btok && (d->weff_bf || d->weff_f32) && d->beff, "embed_fold_fwd: null operand");
+  HFTT_REQUIRE(d && d->wconv && d->bconv && d->wtok && d->btok && (d->weff_bf || d->weff_f32 || d->weff_hi) && d->beff, "embed_fold_fwd: null operand");
+  HFTT_REQUIRE((d->weff_hi == nullptr) == (d->weff_lo == nullptr), "embed_fold_fwd: the split planes come as a pair");
   HFTT_REQUIRE(d->Kp % 32 == 0 && d->Kp >= d->n_proc && d->d_pad >= d->d && d->n_proc >= d->kw, "embed_fold_fwd: bad shape");
   hipLaunchKernelGGL(fold_fwd_kernel, dim3(grid_for((long)d->d_pad * d->Kp, 256)), dim3(256), 0, (hipStream_t)stream, *d);
   HFTT_CHECK_LAUNCH("embed_fold_fwd");

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "hftt_common.h"
+#include "x3_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
 
@@ -36,26 +37,34 @@ __device__ __forceinline__ void store_c4(float* C, bool bf, long off, float a, f
 constexpr int BM = 128;
 constexpr int BK = 32;
 
-template <int BN, bool F32>
+// PREC: 1 = bf16 operands, 3 = exact fp32 MFMA, 2 / 4 = split operands in three passes (x3_common.h: fp16 / bf16 halves; the A tile
+// is split on its way into LDS, the weights arrive as two prepared 16-bit planes W / W_lo)
+template <int BN, int PREC>
 struct NtCfg {
+  static constexpr bool F32 = (PREC == 3);
+  static constexpr bool X3M = (PREC == 2 || PREC == 4);
   static constexpr int WM = (BN == 64) ? 4 : 2;
   static constexpr int WN = 8 / WM;
   static constexpr int TM = BM / WM / 32;
   static constexpr int TN = BN / WN / 32;
   static constexpr int RS = F32 ? 33 : 40;                 // row stride in elements (floats / bf16)
   static constexpr int ESZ = F32 ? 4 : 2;
-  static constexpr int A_ELEMS = BM * RS;
-  static constexpr int W_ELEMS = BN * RS;
+  static constexpr int PLANES = X3M ? 2 : 1;               // x3: hi plane, then lo plane
+  static constexpr int A_ELEMS = PLANES * BM * RS;
+  static constexpr int W_ELEMS = PLANES * BN * RS;
   static constexpr int BUF_ELEMS = A_ELEMS + W_ELEMS;
   static constexpr int LOOP_BYTES = 2 * BUF_ELEMS * ESZ;
   static constexpr int STAGE_LD = BN + 4;
   static constexpr int STAGE_BYTES = BM * STAGE_LD * 4;
-  static constexpr int WCH = F32 ? (BN * 8 + 511) / 512 : (BN * 4 + 511) / 512;   // 16-byte weight chunks per thread
+  static constexpr int WCHP = (BN * 4 + 511) / 512;        // 16-byte chunks per thread of one 16-bit weight plane
+  static constexpr int WCH = F32 ? (BN * 8 + 511) / 512 : PLANES * WCHP;   // 16-byte weight chunks per thread
 };
 
-template <int BN, bool F32, bool LN>
+template <int BN, int PREC, bool LN>
 __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g) {
-  using Cfg = NtCfg<BN, F32>;
+  using Cfg = NtCfg<BN, PREC>;
+  constexpr bool F32 = Cfg::F32, X3M = Cfg::X3M;
+  constexpr int XE = X3M ? PREC : X3_BF16;          // element type of the split (unused otherwise)
   constexpr int WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN, RS = Cfg::RS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
@@ -78,14 +87,15 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 
   float4 areg[2];
   uint4 abreg = make_uint4(0u, 0u, 0u, 0u);        // A tile chunk when A is stored as bf16 (16 B = 8 elements per thread)
-  const bool a_bf = !F32 && (g.io_flags & HFTT_NT_A_BF16);
-  const bool c_bf = !F32 && (g.io_flags & HFTT_NT_C_BF16);
-  const bool gate_bf = !F32 && (g.io_flags & HFTT_NT_GATE_BF16);
+  const bool a_bf = !F32 && !X3M && (g.io_flags & HFTT_NT_A_BF16);
+  const bool c_bf = !F32 && !X3M && (g.io_flags & HFTT_NT_C_BF16);
+  const bool gate_bf = !F32 && !X3M && (g.io_flags & HFTT_NT_GATE_BF16);
   uint4 wreg[Cfg::WCH];
 #pragma unroll
   for (int j = 0; j < Cfg::WCH; j++) wreg[j] = make_uint4(0u, 0u, 0u, 0u);
   const float* Wf = reinterpret_cast<const float*>(g.W);
   const unsigned short* Wb = reinterpret_cast<const unsigned short*>(g.W);
+  const unsigned short* Wlo = reinterpret_cast<const unsigned short*>(g.W_lo);
 
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
@@ -114,6 +124,12 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
           const int row = i >> 3, ch = i & 7;
           wreg[j] = *reinterpret_cast<const uint4*>(Wf + (long)(n0 + row) * g.K + k0 + ch * 4);
         }
+      } else if (X3M) {
+        const int pl = j / Cfg::WCHP, ip = tid + 512 * (j % Cfg::WCHP);
+        if (ip < BN * 4) {
+          const int row = ip >> 2, ch = ip & 3;
+          wreg[j] = *reinterpret_cast<const uint4*>((pl ? Wlo : Wb) + (long)(n0 + row) * g.K + k0 + ch * 8);
+        }
       } else {
         if (i < BN * 4) {
           const int row = i >> 2, ch = i & 3;
@@ -141,6 +157,26 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
           float* d = Ws + row * RS + ch * 4;
           d[0] = __uint_as_float(wreg[j].x); d[1] = __uint_as_float(wreg[j].y);
           d[2] = __uint_as_float(wreg[j].z); d[3] = __uint_as_float(wreg[j].w);
+        }
+      }
+    } else if (X3M) {
+      unsigned short* As = sm16 + buf * Cfg::BUF_ELEMS;
+      unsigned short* Ws = As + Cfg::A_ELEMS;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int i = tid + 512 * j;
+        const int row = i >> 3, c4 = i & 7;
+        uint2 hi, lo;
+        x3_split4<XE>(areg[j], hi, lo);
+        *reinterpret_cast<uint2*>(As + row * RS + c4 * 4) = hi;
+        *reinterpret_cast<uint2*>(As + BM * RS + row * RS + c4 * 4) = lo;
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::WCH; j++) {
+        const int pl = j / Cfg::WCHP, ip = tid + 512 * (j % Cfg::WCHP);
+        if (ip < BN * 4) {
+          const int row = ip >> 2, ch = ip & 3;
+          *reinterpret_cast<uint4*>(Ws + pl * BN * RS + row * RS + ch * 8) = wreg[j];
         }
       }
     } else {
@@ -206,6 +242,27 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] += part[i][j];
+    } else if (X3M) {
+      const unsigned short* As = sm16 + buf * Cfg::BUF_ELEMS;
+      const unsigned short* Ws = As + Cfg::A_ELEMS;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          const unsigned short* p = As + (wm * TM * 32 + i * 32 + lr) * RS + s * 16 + lh * 8;
+          ah[i] = lds_read_b128(p); al[i] = lds_read_b128(p + BM * RS);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const unsigned short* p = Ws + (wn * TN * 32 + j * 32 + lr) * RS + s * 16 + lh * 8;
+          bh[j] = lds_read_b128(p); bl[j] = lds_read_b128(p + BN * RS);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = x3_mma<XE>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+      }
     } else {
       const unsigned short* As = sm16 + buf * Cfg::BUF_ELEMS;
       const unsigned short* Ws = As + Cfg::A_ELEMS;
@@ -228,7 +285,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 
   // ------------------------------- epilogue -------------------------------
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   float* stage = reinterpret_cast<float*>(smem);
 
 #pragma unroll
@@ -339,7 +396,7 @@ __global__ __launch_bounds__(512, (DBUF ? 2 : 4)) void gemm_nt_as_kernel(const h
   const long nblk = (g.M + BM_ - 1) / BM_;
   const unsigned short* Wb = reinterpret_cast<const unsigned short*>(g.W);
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
 
   uint4 wreg[WCH] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
   auto wload = [&](int s) {
@@ -698,7 +755,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_as1_kernel(const hftt_gemm_nt_
     for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
 
   // per k step u of an unrolled group of PF (so the register sets are named statically; PF must divide K / 32): set u held tile s
   // (already in the ring) and receives tile s + PF; set u + 1 holds tile s + 1, written to the ring once this step's MFMAs are issued
@@ -903,38 +960,38 @@ int launch_nt_as1(const hftt_gemm_nt_desc& d, hipStream_t st) {
   return 0;
 }
 
-template <int BN, bool F32, bool LN>
+template <int BN, int PREC, bool LN>
 int launch_nt(const hftt_gemm_nt_desc& d, hipStream_t st) {
-  using Cfg = NtCfg<BN, F32>;
+  using Cfg = NtCfg<BN, PREC>;
   int lds = Cfg::LOOP_BYTES;
   if (LN && Cfg::STAGE_BYTES > lds) lds = Cfg::STAGE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BN, F32, LN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BN, PREC, LN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { hftt_set_error("gemm_nt: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
   const int n_pad = ((d.N + 63) / 64) * 64;
   dim3 grid((unsigned)((d.M + BM - 1) / BM), (unsigned)((n_pad + BN - 1) / BN), 1);
-  hipLaunchKernelGGL((gemm_nt_kernel<BN, F32, LN>), grid, dim3(512), lds, st, d);
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, PREC, LN>), grid, dim3(512), lds, st, d);
   HFTT_CHECK_LAUNCH("gemm_nt");
   return 0;
 }
 
-template <bool F32>
+template <int PREC>
 int dispatch_nt(const hftt_gemm_nt_desc& d, hipStream_t st) {
   const int n_pad = ((d.N + 63) / 64) * 64;
   if (d.ln_gamma != nullptr) {
-    if (d.N == 256) return launch_nt<256, F32, true>(d, st);
-    if (d.N == 128) return launch_nt<128, F32, true>(d, st);
-    if (d.N == 64) return launch_nt<64, F32, true>(d, st);
+    if (d.N == 256) return launch_nt<256, PREC, true>(d, st);
+    if (d.N == 128) return launch_nt<128, PREC, true>(d, st);
+    if (d.N == 64) return launch_nt<64, PREC, true>(d, st);
     hftt_set_error("gemm_nt: fused LayerNorm needs N in {64,128,256}, got %d", d.N);
     return 1;
   }
-  if (n_pad % 256 == 0) return launch_nt<256, F32, false>(d, st);
-  if (n_pad % 128 == 0) return launch_nt<128, F32, false>(d, st);
-  return launch_nt<64, F32, false>(d, st);
+  if (n_pad % 256 == 0) return launch_nt<256, PREC, false>(d, st);
+  if (n_pad % 128 == 0) return launch_nt<128, PREC, false>(d, st);
+  return launch_nt<64, PREC, false>(d, st);
 }
 
 // weight-tile prefetch distance of the one-shot kernels in k steps (HFTT_NT_PF = 1 | 2 | 4 overrides for measurements)
@@ -979,7 +1036,7 @@ int dispatch_nt_bf16(const hftt_gemm_nt_desc& d, hipStream_t st) {
     return abf ? launch_nt_as<6, true, true>(d, st) : launch_nt_as<12, true, false>(d, st);
   }
   if (d.io_flags & HFTT_NT_RES_BF16) { hftt_set_error("gemm_nt: a bf16 residual needs the A-stationary path (N %% 256 == 0, M >= 256, K <= 768)"); return 1; }
-  return dispatch_nt<false>(d, st);      // small / ragged shapes: the k-tiled streaming kernel
+  return dispatch_nt<1>(d, st);      // small / ragged shapes: the k-tiled streaming kernel
 }
 
 }  // namespace
@@ -992,13 +1049,16 @@ extern "C" int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream) {
   HFTT_REQUIRE(!(d->io_flags & HFTT_NT_C_BF16) || d->ln_gamma == nullptr, "gemm_nt: a bf16 C cannot be combined with LayerNorm");
   HFTT_REQUIRE(d->lda % ((d->io_flags & HFTT_NT_A_BF16) ? 8 : 4) == 0, "gemm_nt: lda=%ld breaks 16-byte row alignment", (long)d->lda);
   HFTT_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->W & 15) == 0, "gemm_nt: A/W must be 16-byte aligned");
-  HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "gemm_nt: npass must be 1 (bf16) or 3 (fp32 parity)");
+  HFTT_REQUIRE(d->npass >= 1 && d->npass <= 4, "gemm_nt: npass must be 1 (bf16), 2 (split fp16), 3 (fp32) or 4 (split bf16)");
+  HFTT_REQUIRE((d->npass != 2 && d->npass != 4) || d->W_lo != nullptr, "gemm_nt: the split modes need the lo weight plane (W_lo)");
   HFTT_REQUIRE(d->A != nullptr && d->W != nullptr && d->C != nullptr, "gemm_nt: null operand");
   HFTT_REQUIRE(d->add_table == nullptr || d->add_mod > 0, "gemm_nt: add_mod must be > 0");
   HFTT_REQUIRE(d->residual == nullptr || d->res_mod > 0, "gemm_nt: res_mod must be > 0");
   HFTT_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm_nt: drop_p out of range");
   HFTT_REQUIRE(d->ln_gamma == nullptr || (d->ln_beta != nullptr && d->ldc == d->N), "gemm_nt: LN needs beta and ldc == N");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->npass == 3) return dispatch_nt<true>(*d, st);
+  if (d->npass == 3) return dispatch_nt<3>(*d, st);
+  if (d->npass == 2) return dispatch_nt<2>(*d, st);
+  if (d->npass == 4) return dispatch_nt<4>(*d, st);
   return dispatch_nt_bf16(*d, st);
 }

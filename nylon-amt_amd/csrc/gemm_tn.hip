@@ -5,10 +5,13 @@
 // fragments are fetched with ds_read_b64_tr_b16 (hardware transpose; lane map verified by tools/probe_mfma T5).
 // npass == 3 (parity): tiles stay fp32 in LDS and the product runs on v_mfma_f32_32x32x2_f32 (one f32 per lane per
 // operand, so the row-major tile IS the fragment layout: plain conflict-free ds_read_b32, no transpose needed).
+// npass == 2 / 4 ("x3", x3_common.h): fp32 operands are split into two 16-bit planes (hi, lo) on their way into LDS and every fragment
+// pair feeds three MFMAs (lo.hi + hi.lo + hi.hi); npass 4 (bf16 halves) is what the weight gradients use (dY is a gradient).
 // M is split over workgroups; partial tiles go to a slab workspace and a second kernel reduces them in a fixed
 // order (bitwise reproducible; no float atomics).
 #include <stdlib.h>
 #include "hftt_common.h"
+#include "x3_common.h"
 #include "hftt_host.h"
 #include "../../include/hftt_hip.h"
 
@@ -64,6 +67,8 @@ TnPlan tn_plan(int M, int N, int K) {
 template <int TM, int TN, int NPASS, bool DYB = false, bool XB = false>
 struct TnCfg {
   static constexpr bool F32 = (NPASS == 3);
+  static constexpr bool X3M = (NPASS == 2 || NPASS == 4);
+  static constexpr int PLANES = X3M ? 2 : 1;       // x3: hi plane, then lo plane of each tile
   static constexpr int YE = DYB ? 8 : 4;           // elements per 16-byte global slot (bf16- or fp32-stored operand)
   static constexpr int XE = XB ? 8 : 4;
   static constexpr int TILE_N = 128 * TM;
@@ -72,8 +77,8 @@ struct TnCfg {
   static constexpr int RSY = F32 ? TILE_N + 4 : TILE_N + 32;
   static constexpr int RSX = F32 ? TILE_K + 4 : TILE_K + 32;
   static constexpr int ESZ = F32 ? 4 : 2;
-  static constexpr int Y_ELEMS = BMT * RSY;
-  static constexpr int X_ELEMS = BMT * RSX;
+  static constexpr int Y_ELEMS = PLANES * BMT * RSY;
+  static constexpr int X_ELEMS = PLANES * BMT * RSX;
   static constexpr int BUF_ELEMS = Y_ELEMS + X_ELEMS;
   static constexpr int LDS_BYTES = 2 * BUF_ELEMS * ESZ;
   static constexpr int YSPR = TILE_N / YE;         // slots per tile row
@@ -88,8 +93,9 @@ template <int TM, int TN, int NPASS, bool DYB, bool XB>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g, const int k_tiles, const int rows_per_split,
                                                      const long nws, const long kws, const int n_tiles_total, const int n_splits) {
   using Cfg = TnCfg<TM, TN, NPASS, DYB, XB>;
-  constexpr bool F32 = Cfg::F32;
-  static_assert(!F32 || (!DYB && !XB), "bf16-stored operands are a bf16-mode feature");
+  constexpr bool F32 = Cfg::F32, X3M = Cfg::X3M;
+  constexpr int EX = X3M ? NPASS : X3_BF16;         // element type of the split
+  static_assert(!(F32 || X3M) || (!DYB && !XB), "bf16-stored operands are a bf16-mode feature");
   constexpr int RSY = Cfg::RSY, RSX = Cfg::RSX, TILE_N = Cfg::TILE_N, TILE_K = Cfg::TILE_K;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
@@ -161,6 +167,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
     if (F32) {
       float* base = sm32 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
       *reinterpret_cast<float4*>(base + off) = f;
+    } else if (X3M) {
+      unsigned short* base = sm16 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
+      uint2 hi, lo;
+      x3_split4<EX>(f, hi, lo);
+      *reinterpret_cast<uint2*>(base + off) = hi;
+      *reinterpret_cast<uint2*>(base + (which ? BMT * RSX : BMT * RSY) + off) = lo;
     } else {
       unsigned short* base = sm16 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
       uint2 ph;
@@ -213,13 +225,15 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   // conditional block makes hipcc's s_waitcnt insertion fall back to vmcnt(0), which drained the two-steps-ahead prefetch.
   gload(0, yregA, xregA);
   sstore(0, 0, yregA, xregA);
-  gload(1, yregB, xregB);
+  if (!X3M) gload(1, yregB, xregB);
   __syncthreads();
   // step s computes from LDS buffer (s&1); set `cur` (stored to LDS one step ago) is refilled with step s+2, set `nxt`
   // (holding step s+1, issued one step ago) is converted into the other LDS buffer after the MFMAs
   auto body = [&](int step, uint4 (&ycur)[Cfg::YL], uint4 (&xcur)[Cfg::XL], const uint4 (&ynxt)[Cfg::YL], const uint4 (&xnxt)[Cfg::XL]) {
     const int buf = step & 1;
-    gload(step + 2, ycur, xcur);
+    // x3: ONE staging set, loads one step ahead (three times the MFMA work per step covers the latency; two sets on top of the 128
+    // accumulator registers and the hi / lo fragments of the 256 x 256 tile spilled)
+    gload(X3M ? step + 1 : step + 2, ycur, xcur);
     __builtin_amdgcn_sched_barrier(0);      // keep the loads up here: hipcc otherwise sinks them below the MFMAs (one step of cover, not two)
     if (F32) {
       const float* Ys = sm32 + buf * Cfg::BUF_ELEMS;
@@ -236,6 +250,40 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
         for (int i = 0; i < TM; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++) acc[i][j] = mfma32_f32(a[i], b[j], acc[i][j]);
+      }
+    } else if (X3M) {
+      const unsigned short* Ys = sm16 + buf * Cfg::BUF_ELEMS;
+      const unsigned short* Xs = Ys + Cfg::Y_ELEMS;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        bf16x8 ah[TM], al[TM];
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          const unsigned short* p = Ys + (16 * s + frag_row) * RSY + wn4 * TM * 32 + i * 32 + frag_col;
+          ah[i] = join4(lds_read_tr16(p), lds_read_tr16(p + 4 * RSY));
+          al[i] = join4(lds_read_tr16(p + BMT * RSY), lds_read_tr16(p + BMT * RSY + 4 * RSY));
+        }
+        // one X fragment pair at a time (the next pair is read under this pair's six MFMAs): all TN pairs up front, as hipcc would
+        // schedule them, put the 256 x 256 tile over the register budget
+        bf16x8 bh, bl;
+        {
+          const unsigned short* p = Xs + (16 * s + frag_row) * RSX + wk2 * TN * 32 + frag_col;
+          bh = join4(lds_read_tr16(p), lds_read_tr16(p + 4 * RSX));
+          bl = join4(lds_read_tr16(p + BMT * RSX), lds_read_tr16(p + BMT * RSX + 4 * RSX));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          bf16x8 nh = bh, nl = bl;
+          if (j + 1 < TN) {
+            const unsigned short* p = Xs + (16 * s + frag_row) * RSX + wk2 * TN * 32 + (j + 1) * 32 + frag_col;
+            nh = join4(lds_read_tr16(p), lds_read_tr16(p + 4 * RSX));
+            nl = join4(lds_read_tr16(p + BMT * RSX), lds_read_tr16(p + BMT * RSX + 4 * RSX));
+          }
+#pragma unroll
+          for (int i = 0; i < TM; i++) acc[i][j] = x3_mma<EX>(ah[i], al[i], bh, bl, acc[i][j]);
+          bh = nh; bl = nl;
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     } else {
       const unsigned short* Ys = sm16 + buf * Cfg::BUF_ELEMS;
@@ -265,8 +313,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
     __syncthreads();
   };
   for (int step = 0; step < nsteps; step += 2) {      // an odd step count runs one extra step on zeros
-    body(step, yregA, xregA, yregB, xregB);
-    body(step + 1, yregB, xregB, yregA, xregA);
+    if (X3M) {
+      body(step, yregA, xregA, yregA, xregA);
+      body(step + 1, yregA, xregA, yregA, xregA);
+    } else {
+      body(step, yregA, xregA, yregB, xregB);
+      body(step + 1, yregB, xregB, yregA, xregA);
+    }
   }
 
   // partial tile -> slab [split][nws][kws]
@@ -381,7 +434,7 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
     HFTT_REQUIRE(d->lddy % ye == 0 && d->ldx % xe == 0, "gemm_tn: leading dims must keep rows 16-byte aligned");
   }
   HFTT_REQUIRE(((uintptr_t)d->dY & 15) == 0 && ((uintptr_t)d->X & 15) == 0, "gemm_tn: dY/X must be 16-byte aligned");
-  HFTT_REQUIRE(d->npass == 1 || d->npass == 3, "gemm_tn: npass must be 1 or 3");
+  HFTT_REQUIRE(d->npass >= 1 && d->npass <= 4, "gemm_tn: npass must be 1 .. 4");
   HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1, "gemm_tn: bf16-stored operands need npass == 1");
   HFTT_REQUIRE(d->n_seg >= 1 && d->n_seg <= 4, "gemm_tn: n_seg must be 1..4");
   HFTT_REQUIRE(d->K_out > 0 && d->K_out <= d->K, "gemm_tn: K_out out of range");
@@ -399,6 +452,16 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
     else if (p.tn == 4) rc = launch_tn<1, 4, 3, false, false>(*d, p, st);
     else if (p.tn == 2) rc = launch_tn<1, 2, 3, false, false>(*d, p, st);
     else rc = launch_tn<1, 1, 3, false, false>(*d, p, st);
+  } else if (d->npass == 4) {
+    if (p.tm == 2) rc = launch_tn<2, 4, 4, false, false>(*d, p, st);
+    else if (p.tn == 4) rc = launch_tn<1, 4, 4, false, false>(*d, p, st);
+    else if (p.tn == 2) rc = launch_tn<1, 2, 4, false, false>(*d, p, st);
+    else rc = launch_tn<1, 1, 4, false, false>(*d, p, st);
+  } else if (d->npass == 2) {
+    if (p.tm == 2) rc = launch_tn<2, 4, 2, false, false>(*d, p, st);
+    else if (p.tn == 4) rc = launch_tn<1, 4, 2, false, false>(*d, p, st);
+    else if (p.tn == 2) rc = launch_tn<1, 2, 2, false, false>(*d, p, st);
+    else rc = launch_tn<1, 1, 2, false, false>(*d, p, st);
   } else {
 #define HFTT_TN_GO(TM_, TN_)                                                     \
     (dyb ? (xb ? launch_tn<TM_, TN_, 1, true, true>(*d, p, st) : launch_tn<TM_, TN_, 1, true, false>(*d, p, st)) \

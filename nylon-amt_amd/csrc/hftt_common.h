@@ -124,9 +124,10 @@ __device__ __forceinline__ uint32_t hftt_hash(uint64_t seed, uint32_t site, uint
 }
 // One 32-bit hash serves FOUR consecutive elements (4q .. 4q+3): each takes one BYTE of the word, compared with an 8-bit threshold
 //   keep(idx) = byte (idx & 3) of hash(idx >> 2) < thr,   thr = round((1 - p) * 256)
-// so the keep probability is quantised to 1/256 (p = 0.1 -> thr 230, drop rate 0.1016).  Kept elements are still scaled by 1 / (1 - p), the
-// reference's nn.Dropout factor: the expected value of a dropped tensor is thr / 256 / (1 - p) of the input (0.9983 at p = 0.1; exact
-// whenever (1 - p) * 256 is an integer, e.g. p = 0.25, 0.5).  v_mul_lo_u32 issues at quarter rate, so the two multiplies of the mixer
+// so the keep probability is quantised to thr / 256 (p = 0.1 -> thr 230, drop rate 0.1016).  Kept elements are scaled by 256 / thr, the
+// reciprocal of the probability actually applied (hftt_keep_scale), so the expected value of a dropped tensor is exactly the input --
+// nn.Dropout's contract (the reference's 1 / (1 - p) is the same number whenever (1 - p) * 256 is an integer, e.g. p = 0.25, 0.5).
+// v_mul_lo_u32 issues at quarter rate, so the two multiplies of the mixer
 // are most of a hash: kernels whose lanes own adjacent elements hash once per quad; every other site calls hftt_keep per element
 // and gets the same decisions.
 __host__ __device__ inline uint32_t hftt_keep_thr(float p) {
@@ -134,6 +135,12 @@ __host__ __device__ inline uint32_t hftt_keep_thr(float p) {
   if (k >= 256.0) return 256u;
   if (k <= 0.0) return 0u;
   return (uint32_t)k;
+}
+// scale of the kept elements: 1 / (keep probability actually applied) = 256 / thr   (1 when nothing is dropped)
+__host__ __device__ inline float hftt_keep_scale(float p) {
+  if (!(p > 0.f)) return 1.0f;
+  const uint32_t thr = hftt_keep_thr(p);
+  return thr > 0u ? 256.0f / (float)thr : 0.0f;
 }
 __device__ __forceinline__ bool hftt_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr) {
   const uint32_t w = hftt_hash(seed, site, idx >> 2);

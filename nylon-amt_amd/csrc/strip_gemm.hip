@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void strip_linear_kernel(const hftt_strip_d
   for (int s = 0; s < FILL_AHEAD; s++) ring_fill(g.w, s, S - 1, ring, wave, lane);
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const unsigned char* abase = smem + lane * 16;
 
   int s = 0;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void strip_mlp_kernel(const hftt_ffn_desc g
   for (int s = 0; s < FILL_AHEAD; s++) ring_fill(g.w, s, S - 1, ring, wave, lane);
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const unsigned char* abase = smem + lane * 16;
   const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)g.p) >> 2;
 

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   __builtin_amdgcn_s_barrier();                       // the parameter rows in LDS are read (by every wave) before the first slot's barrier
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const unsigned char* abase = smem + lane * 16;
   unsigned short* pend_ptr = cb;                    // where the deferred results go (meaningful while pend_valid)
   bool pend_valid = false;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
   __builtin_amdgcn_s_barrier();                       // the parameter rows in LDS are read (by every wave) before the first slot's barrier
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const unsigned char* abase = smem + lane * 16;
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     int hb = h;                                       // (opaque per iteration: see strip_linear2_kernel)

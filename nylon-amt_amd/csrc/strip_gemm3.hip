@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear3_kernel(const hftt_strip_
 
   u4v xf[16], pend[16];
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const unsigned char* abase = smem + lane * 16;
   const unsigned char* xrow = smem + RING_BYTES + (wave * 32 + j) * 512;       // this lane's token row in the activation buffer
   unsigned short* pend_ptr = cb;                    // where the deferred results go (meaningful while pend_valid)

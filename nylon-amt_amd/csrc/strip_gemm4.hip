@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512, 1) void strip_linear4_kernel(const hftt_strip_
   // compute wave: weight fragments and activations from LDS, results to the staging ring; no global memory inside the loop
   // =======================================================================================================================
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const unsigned char* abase = smem + lane * 16;
   u4v pend[16];                                     // the finished pass's results, two pieces per slot into the staging ring
   unsigned short* pend_ptr = cb;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear5_kernel(const hftt_strip_
   __builtin_amdgcn_s_barrier();
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = (g.drop_p > 0.f) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const float inv_keep = hftt_keep_scale(g.drop_p);
   const unsigned char* abase = smem + lane * 16;
   unsigned short* pend_ptr[2] = {cb, cb};           // where the pending results of each strip go (this lane's view of the 128-column pass)
   bool pend_valid[2] = {false, false};

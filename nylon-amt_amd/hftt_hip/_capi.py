@@ -32,7 +32,8 @@ class GemmNtDesc(C.Structure):
                 ('gate', c_f32p), ('ldg', C.c_int64), ('gate_scale', C.c_float),
                 ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
                 ('residual', c_f32p), ('ldr', C.c_int64), ('res_mod', C.c_int32),
-                ('ln_gamma', c_f32p), ('ln_beta', c_f32p), ('pre_ln_out', c_f32p), ('ln_mean', c_f32p), ('ln_rstd', c_f32p)]
+                ('ln_gamma', c_f32p), ('ln_beta', c_f32p), ('pre_ln_out', c_f32p), ('ln_mean', c_f32p), ('ln_rstd', c_f32p),
+                ('W_lo', C.c_void_p)]
 
 
 class GemmTnDesc(C.Structure):
@@ -67,7 +68,8 @@ class FoldDesc(C.Structure):
                 ('wconv', c_f32p), ('bconv', c_f32p), ('wtok', c_f32p), ('btok', c_f32p),
                 ('weff_bf', c_u16p), ('weff_f32', c_f32p), ('beff', c_f32p),
                 ('dweff', c_f32p), ('dbeff', c_f32p),
-                ('g_wconv', c_f32p), ('g_bconv', c_f32p), ('g_wtok', c_f32p), ('g_btok', c_f32p)]
+                ('g_wconv', c_f32p), ('g_bconv', c_f32p), ('g_wtok', c_f32p), ('g_btok', c_f32p),
+                ('weff_hi', c_u16p), ('weff_lo', c_u16p)]
 
 
 class LnBwdDesc(C.Structure):
@@ -139,6 +141,7 @@ SIGNATURES = {
     'hftt_last_error': (C.c_char_p, []),
     'hftt_device_cus': (C.c_int, []),
     'hftt_prep_weights': (C.c_int, [c_f32p, c_u16p, c_u16p, c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
+    'hftt_prep_weights_x3': (C.c_int, [c_f32p, c_u16p, c_u16p, c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
     'hftt_gemm_nt': (C.c_int, [C.POINTER(GemmNtDesc), C.c_void_p]),
     'hftt_strip_pack': (C.c_int, [c_f32p, c_u16p, C.c_void_p, C.c_int, C.c_void_p]),
     'hftt_strip_linear': (C.c_int, [C.POINTER(StripDesc), C.c_void_p]),
@@ -173,7 +176,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HfttError(RuntimeError):

@@ -25,7 +25,20 @@ from . import _capi
 from ._capi import (AttnDesc, FfnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
                     SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, check, lib)
 
-PRECISION_NPASS = {'parity': 3, 'bf16': 1}
+# precision -> the descriptors' `npass` code (include/hftt_hip.h): 'x3' = split fp16 on forward products (2) and split bf16 on products with a
+# gradient operand (4): three bf16-rate MFMA passes per product, fp32 tensors in HBM, outputs within 1e-3 of the reference (measured 1e-4)
+PRECISION_NPASS = {'parity': 3, 'bf16': 1, 'x3': 2}
+
+
+def keep_scale(p):
+    """scale of the kept elements of a dropout site (csrc/hftt_common.h: hftt_keep_scale): 256 / thr, thr = round((1 - p) * 256) -- the
+    reciprocal of the keep probability the 8-bit generator actually applies, so E[dropout(x)] = x exactly (nn.Dropout's contract)."""
+    if not p > 0.0:
+        return 1.0
+    import numpy as np
+    kk = (1.0 - float(np.float32(p))) * 256.0 + 0.5
+    thr = 256 if kk >= 256.0 else (0 if kk <= 0.0 else int(kk))
+    return float(np.float32(256.0) / np.float32(thr)) if thr > 0 else 0.0
 
 
 def _align(x, a):
@@ -86,6 +99,7 @@ class HfttEngine:
         self._ws = {}
         self._site = 0
         self.profiler = None                        # optional per-launch HIP-event timer (bench.py)
+        self._in_backward = False                   # set while the backward plan is being built (x3: products with a gradient operand)
         self.frozen_weights = False                 # the caller's promise that the parameters do not change (see prepare_weights)
         self._prepared_frozen = False
 
@@ -286,6 +300,10 @@ class HfttEngine:
         n_w = _align(wl.off, 64)
         self.wbf = torch.zeros(n_w if self.npass == 1 else 8, dtype=torch.int16, device=self.device)
         self.wf32 = torch.zeros(n_w if self.npass == 3 else 8, dtype=torch.float32, device=self.device)
+        # x3: every prepared matrix as two 16-bit planes (hi, lo) at the same element offsets -- fp16 halves for the forward matrices,
+        # bf16 halves for the transposed ones (they only meet gradients)
+        self.whi = torch.zeros(n_w if self.npass == 2 else 8, dtype=torch.int16, device=self.device)
+        self.wlo = torch.zeros(n_w if self.npass == 2 else 8, dtype=torch.int16, device=self.device)
         self.fprep = torch.zeros(_align(fl.off, 8), dtype=torch.float32, device=self.device)
         self._prep_entries = list(entries)
         self._wl_regions = sorted((off, name) for name, off in wl.items.items())      # matrix planes by element offset
@@ -308,12 +326,14 @@ class HfttEngine:
                              self.fprep.data_ptr() + 4 * W['embed_b'],
                              self.dweff.data_ptr(), self.dbeff.data_ptr(),
                              self.G(e + 'conv.weight'), self.G(e + 'conv.bias'), self.G(e + 'tok_embedding_freq.weight'),
-                             self.G(e + 'tok_embedding_freq.bias'))
+                             self.G(e + 'tok_embedding_freq.bias'),
+                             (self.whi.data_ptr() + 2 * W['embed']) if self.npass == 2 else 0,
+                             (self.wlo.data_ptr() + 2 * W['embed']) if self.npass == 2 else 0)
 
     def _set_prep_table(self, entries):
         arr = (PrepEntry * len(entries))()
         for i, (so, do, r, c_, sld, dld, kind) in enumerate(entries):
-            arr[i] = PrepEntry(so, do, r, c_, sld, dld, kind, 0)
+            arr[i] = PrepEntry(so, do, r, c_, sld, dld, kind, 4 if kind == 1 else 2)      # pad: x3 element type (transposed = backward = bf16 halves)
         self.prep_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         self.n_prep = len(entries)
 
@@ -340,7 +360,12 @@ class HfttEngine:
     def Wp(self, key):   # device address of a prepared matrix (bf16 plane or fp32 copy, by precision)
         o = self.Woff[key]
         self._wp_used.add(key)
+        if self.npass == 2:
+            return self.whi.data_ptr() + 2 * o
         return (self.wbf.data_ptr() + 2 * o) if self.npass == 1 else (self.wf32.data_ptr() + 4 * o)
+
+    def Wp_lo(self, W):   # x3: the lo plane of the prepared matrix whose hi plane sits at device address W
+        return (W - self.whi.data_ptr() + self.wlo.data_ptr()) if self.npass == 2 else 0
 
     def Fp(self, key):
         return self.fprep.data_ptr() + 4 * self.Woff[key]
@@ -355,9 +380,13 @@ class HfttEngine:
         if self.frozen_weights and self._prepared_frozen:
             return
         self._refresh_prep_table()
-        check(self.lib.hftt_prep_weights(self.flat_params.data_ptr(), self.wbf.data_ptr() if self.npass == 1 else 0,
-                                         self.wf32.data_ptr() if self.npass == 3 else 0,
-                                         self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights')
+        if self.npass == 2:
+            check(self.lib.hftt_prep_weights_x3(self.flat_params.data_ptr(), self.whi.data_ptr(), self.wlo.data_ptr(),
+                                                self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights_x3')
+        else:
+            check(self.lib.hftt_prep_weights(self.flat_params.data_ptr(), self.wbf.data_ptr() if self.npass == 1 else 0,
+                                             self.wf32.data_ptr() if self.npass == 3 else 0,
+                                             self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights')
         check(self.lib.hftt_embed_fold_fwd(C.byref(self.fold), stream), 'embed_fold_fwd')
         if self.strip and self.n_spack:
             check(self.lib.hftt_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, stream), 'strip_pack')
@@ -390,9 +419,11 @@ class HfttEngine:
         a_bf, c_bf, gate_bf, res_bf = (a_bf and self.sb), (c_bf and self.sb), (gate_bf and self.sb), (res_bf and self.sb and bool(residual))
         dsc = GemmNtDesc()
         dsc.io_flags = (1 if a_bf else 0) | (2 if c_bf else 0) | (4 if gate_bf else 0) | (8 if res_bf else 0)
-        dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, self.npass
+        npass = self.npass if self.npass != 2 else (4 if self._in_backward else 2)       # x3: fp16 halves forward, bf16 halves with gradients
+        dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, npass
         dsc.A, dsc.lda = A, lda
         dsc.W = W
+        dsc.W_lo = self.Wp_lo(W)
         dsc.bias = bias
         dsc.C, dsc.ldc = Cp, ldc
         dsc.act, dsc.out_scale = act, out_scale
@@ -410,7 +441,7 @@ class HfttEngine:
         ws['keep'].append(dsc)
         n_pad = _align(N, 64)
         bn = N if ln is not None else (256 if n_pad % 256 == 0 else (128 if n_pad % 128 == 0 else 64))
-        esz = 2 if self.npass == 1 else 4
+        esz = 2 if self.npass == 1 else 4           # (x3: two 16-bit planes = 4 bytes per weight)
         nbytes = (2 if a_bf else 4) * M * K + (2 if c_bf else 4) * M * N + esz * N * K + ((2 if res_bf else 4) * M * N if residual else 0) + (4 * M * N if ln is not None else 0) \
             + ((2 if gate_bf else 4) * M * N if gate else 0)
         rich = bool(add_table or gate or drop_site or residual or ln is not None)
@@ -433,7 +464,7 @@ class HfttEngine:
             else:
                 kname = 'gemm_nt_as_kernel<6, true, true>' if a_bf else 'gemm_nt_as_kernel<12, true, false>'
         else:
-            kname = 'gemm_nt_kernel<%d, %s, %s>' % (bn, 'true' if self.npass == 3 else 'false', 'true' if ln is not None else 'false')
+            kname = 'gemm_nt_kernel<%d, %d, %s>' % (bn, npass, 'true' if ln is not None else 'false')
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_gemm_nt, (C.byref(dsc),), 'gemm_nt', meta))
         return dsc
@@ -508,7 +539,7 @@ class HfttEngine:
         need = self.lib.hftt_gemm_tn_ws_bytes(M, N, K)
         ws['tn_need'] = max(ws.get('tn_need', 0), need)
         dsc = GemmTnDesc()
-        dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, self.npass
+        dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, (4 if self.npass == 2 else self.npass)
         dy_bf, x_bf = (dy_bf and self.sb), (x_bf and self.sb)
         dsc.io_flags = (1 if dy_bf else 0) | (2 if x_bf else 0)
         dsc.dY, dsc.lddy, dsc.X, dsc.ldx = dY, lddy, X, ldx
@@ -520,7 +551,9 @@ class HfttEngine:
         ws['tn'].append(dsc)
         ws['keep'].append(dsc)
         tile = '2, 4' if (N >= 256 and K >= 256) else ('1, 2' if (N >= 128 and K >= 128) else '1, 1')
-        meta = {'kernel': 'gemm_tn_kernel<%s, %d, %s, %s>' % (tile, self.npass, 'true' if dy_bf else 'false', 'true' if x_bf else 'false'), 'flops': 2.0 * M * N * K,
+        if tile == '2, 4' and N <= 256 and K <= 256:
+            tile = '1, 4'                           # (csrc/gemm_tn.hip tn_plan: the 128 x 256 tile for single-tile shapes)
+        meta = {'kernel': 'gemm_tn_kernel<%s, %d, %s, %s>' % (tile, dsc.npass, 'true' if dy_bf else 'false', 'true' if x_bf else 'false'), 'flops': 2.0 * M * N * K,
                 'bytes': (2.0 if dy_bf else 4.0) * M * N + (2.0 if x_bf else 4.0) * M * K + 4.0 * N * K, 'shape': (M, N, K)}
         plan.append((self.lib.hftt_gemm_tn, (C.byref(dsc),), 'gemm_tn', meta))
         return dsc
@@ -553,14 +586,15 @@ class HfttEngine:
         qkv_bytes = n_seq * (eq * Lq + 2 * ekv * Lk) * self.d
         if bwd:
             hb = 'true' if (flags & 7) == 7 else 'false'
-            meta = {'kernel': 'attn_bwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
+            meta = {'kernel': ('x3_attn_bwd_kernel<%d, %d>' % (kt, dh)) if self.npass == 2 else 'attn_bwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
                     'bytes': qkv_bytes + n_seq * ((2.0 if flags & 8 else 4.0) * Lq + 2 * (2.0 if flags & 16 else 4.0) * Lk) * self.d + 2 * eo * n_seq * Lq * self.d
                     + 8.0 * n_seq * H * Lq, 'shape': (n_seq, H, Lq, Lk, dh)}
         else:
             hb = 'true' if (flags & 7) == 7 else 'false'
             long_rows = (hb == 'true' and dh == 64 and self.npass == 1 and 128 < Lk <= 256 and 128 < Lq <= 256 and not probs
                          and os.environ.get('HFTT_ATTN_FWD8', '1')[:1] != '0')                   # csrc/attn_fwd8.hip: hftt_attn_fwd8_try
-            meta = {'kernel': 'attn_fwd8_kernel' if long_rows else 'attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
+            meta = {'kernel': 'attn_fwd8_kernel' if long_rows else (('x3_attn_fwd_kernel<%d, %d>' % (kt, dh)) if self.npass == 2 else
+                                                                     'attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb)), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
                     # q, k, v, out + the row statistics (max, 1/sum) + the attention map where it is a model output (fp32, mandatory)
                     'bytes': qkv_bytes + eo * n_seq * Lq * self.d + 8.0 * n_seq * H * Lq + (4.0 * n_seq * H * Lq * Lk if probs else 0.0),
                     'shape': (n_seq, H, Lq, Lk, dh)}
@@ -599,7 +633,11 @@ class HfttEngine:
             self._site = 0
             self._build_forward(ws, save=False)
             assert self._site == n_sites
-        self._build_backward(ws)
+        self._in_backward = True
+        try:
+            self._build_backward(ws)
+        finally:
+            self._in_backward = False
         tnb = torch.empty(max(ws.get('tn_need', 8), 8) // 4 + 16, dtype=torch.float32, device=self.device)
         lnb = torch.empty(max(ws.get('ln_need', 8), 8) // 4 + 16, dtype=torch.float32, device=self.device)
         ws['bufs']['tn_ws'], ws['bufs']['ln_ws'] = tnb, lnb
@@ -1064,7 +1102,6 @@ class HfttEngine:
     def _run(self, ws, plan, stream, outs=None, seed=0, p=0.0):
         L = self.lib
         B, T, N, V, d = ws['B'], self.T, self.N, self.V, self.d
-        inv_keep = 1.0 / (1.0 - p) if p > 0.0 else 1.0
         prof = self.profiler
         for fn, args, name, meta in plan:
             if prof is not None:
@@ -1107,7 +1144,7 @@ class HfttEngine:
                 check(rc, name)
 
     def _patch(self, ws, p, seed):
-        inv_keep = 1.0 / (1.0 - p) if p > 0.0 else 1.0
+        inv_keep = keep_scale(p)
         for dsc in ws['drop']:
             dsc.drop_p = p
             dsc.drop_seed = seed

@@ -36,7 +36,7 @@ def _align(x, a):
 
 def prepare_weight(w: torch.Tensor, npass=3, transposed=False, n_pad=64):
     """fp32 [rows, cols] -> the GEMM operand [align(rows, n_pad), cols] (or its transpose): bf16 (int16 tensor) for npass 1,
-    fp32 for npass 3."""
+    fp32 for npass 3; npass 2 / 4 (split fp16 / bf16): an int16 tensor [2, rows_pad, cols] holding the hi plane, then the lo plane."""
     _need_cuda(w)
     w = w.contiguous().float()
     rows, cols = w.shape
@@ -44,6 +44,12 @@ def prepare_weight(w: torch.Tensor, npass=3, transposed=False, n_pad=64):
         out_r, out_c = _align(cols, n_pad), _align(rows, 32)
     else:
         out_r, out_c = _align(rows, n_pad), cols
+    if npass in (2, 4):
+        out = torch.zeros(2, out_r, out_c, dtype=torch.int16, device=w.device)
+        ent = (PrepEntry * 1)(PrepEntry(0, 0, rows, cols, cols, out_c, 1 if transposed else 0, npass))
+        table = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).to(w.device)
+        check(lib().hftt_prep_weights_x3(w.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), 0, table.data_ptr(), 1, _stream(w.device)), 'prep_weights_x3')
+        return out
     out = torch.zeros(out_r, out_c, dtype=torch.int16 if npass == 1 else torch.float32, device=w.device)
     ent = (PrepEntry * 1)(PrepEntry(0, 0, rows, cols, cols, out_c, 1 if transposed else 0, 0))
     table = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).to(w.device)
@@ -64,6 +70,8 @@ def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_
     d.M, d.N, d.K, d.npass = M, N, K, npass
     d.A, d.lda = A.data_ptr(), A.stride(0)
     d.W = Wprep.data_ptr()
+    if npass in (2, 4):
+        d.W_lo = Wprep[1].data_ptr()
     d.debug = debug
     d.io_flags = (NT_A_BF16 if A.dtype == BF16 else 0) | (NT_C_BF16 if out_dtype == BF16 else 0) | (NT_GATE_BF16 if (gate is not None and gate.dtype == BF16) else 0) \
         | (NT_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0)

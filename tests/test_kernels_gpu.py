@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 import util
-from util import rel_err, max_err, keep_mask_t
+from util import keep_scale, rel_err, max_err, keep_mask_t
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,7 @@ def test_gemm_nt_epilogues(dev, N):
     p, site, seed = 0.3, 5, 77
     mask = keep_mask_t(seed, site, (M, N), p).double()
     out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res5.to(dev), res_mod=5)
-    ref = lin * mask / (1.0 - float(np.float32(p))) + res5.double()[rows % 5]
+    ref = lin * mask * keep_scale(p) + res5.double()[rows % 5]
     assert rel_err(out, ref) < TOL[3]
     # residual + LayerNorm
     out, pre, mean, rstd = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), residual=res.to(dev), ln=(gam.to(dev), bet.to(dev)))
@@ -166,7 +166,7 @@ def test_ln_bwd(dev, N):
     assert rel_err(dg, g64.grad) < 1e-5
     assert rel_err(db, b64.grad) < 1e-5
     mask = keep_mask_t(seed, site, (M, N), p).double()
-    assert rel_err(drd, r64.grad * mask / (1.0 - float(np.float32(p)))) < 1e-5
+    assert rel_err(drd, r64.grad * mask * keep_scale(p)) < 1e-5
 
 
 @pytest.mark.parametrize('M,p', [(1234, 0.2), (4099, 0.0), (3, 0.1), (65536, 0.1)])
@@ -189,7 +189,7 @@ def test_ln_bwd_all_bf16_four_rows_per_wave(dev, M, p):
     assert rel_err(dg, g64.grad) < 2e-5 and rel_err(db, b64.grad) < 2e-5
     if p > 0:
         mask = keep_mask_t(seed, site, (M, N), p).double()
-        assert drd.dtype == torch.bfloat16 and rel_err(drd, r64.grad * mask / (1.0 - float(np.float32(p)))) < 6e-3
+        assert drd.dtype == torch.bfloat16 and rel_err(drd, r64.grad * mask * keep_scale(p)) < 6e-3
         assert torch.equal((drd == 0).cpu() | (mask == 1), torch.ones(M, N, dtype=torch.bool))      # exactly the masked elements are zero
 
 

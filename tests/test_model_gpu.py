@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import util
-from util import O, MINI, OUT_NAMES, max_err
+from util import keep_scale, O, MINI, OUT_NAMES, max_err
 
 pytestmark = pytest.mark.gpu
 TOL_OUT = 1e-3
@@ -45,7 +45,8 @@ def _grad_check(eng, names, ref_grads, tol_rel, report):
     report['worst_grad_rel'] = worst
 
 
-def test_mini_full_tensors_and_all_grads(dev):
+@pytest.mark.parametrize('precision', ['x3', 'parity'])
+def test_mini_full_tensors_and_all_grads(dev, precision):
     """Every output element, the loss and every parameter gradient at a small config (oracle pinned by golden/micro)."""
     from hftt_hip.trainer import TrainStep
     cfg, B = MINI, 3
@@ -56,7 +57,7 @@ def test_mini_full_tensors_and_all_grads(dev):
     labels = O.synth_labels(B, cfg, salt=6)
     ref_out, ref_loss, ref_grads = _oracle_run(sd, cfg, x, labels, 1.0, 0.7)
     model = model.to(dev)
-    model.hftt_precision = 'parity'
+    model.hftt_precision = precision
     model.train()                               # dropout 0.0: identical to eval
     ts = TrainStep(model, weight_A=1.0, weight_B=0.7)
     ts.engine.flat_grads.fill_(float('nan'))
@@ -69,7 +70,7 @@ def test_mini_full_tensors_and_all_grads(dev):
         assert rep[n] < TOL_OUT, (n, rep[n])
     assert abs(loss[0].item() - ref_loss) < 1e-4
     _grad_check(ts.engine, None, ref_grads, 2e-3, rep)
-    print('mini parity:', json.dumps(rep))
+    print('mini', precision, json.dumps(rep))
     # eval mode gives the same outputs; the autograd (compat) path gives the same gradients as the fast path
     model.eval()
     with torch.no_grad():
@@ -84,7 +85,9 @@ def test_mini_full_tensors_and_all_grads(dev):
     l2.backward()
     flat2 = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     flat1 = torch.cat([fast[o:o + n] for (_, _, o, n) in ts.engine._bound])
-    assert (flat1 - flat2).abs().max().item() < 1e-5 * max(1.0, flat1.abs().max().item())
+    # (x3: the gradient products run on bf16 pairs, 2^-16 per product -- the two paths differ in the last bits of the incoming output
+    # gradients, fused loss kernel vs torch autograd, and that much comes back out)
+    assert (flat1 - flat2).abs().max().item() < (3e-4 if precision == 'x3' else 1e-5) * max(1.0, flat1.abs().max().item())
     # one fused Adam step == oracle Adam step
     names = [n for n, _ in model.named_parameters()]
     ts.engine.flat_grads.copy_(fast)
@@ -100,9 +103,11 @@ def test_mini_full_tensors_and_all_grads(dev):
         assert diff.max().item() <= 2.0e-4 + 1e-7, k
 
 
+@pytest.mark.parametrize('precision', ['x3', 'parity'])
 @pytest.mark.parametrize('name', ['tiny_b2', 'paper_b1'])
-def test_golden_fixture(dev, name):
-    """Reference outputs / loss / gradient statistics recorded in tests/golden (no oracle in the loop)."""
+def test_golden_fixture(dev, name, precision):
+    """Reference outputs / loss / gradient statistics recorded in tests/golden (no oracle in the loop), at north_star's 1e-3, in both modes
+    that claim it: 'x3' (split fp16 / bf16 operands, three bf16-rate MFMA passes) and 'parity' (exact fp32 MFMA)."""
     from hftt_hip.trainer import TrainStep
     g = util.golden(name)
     cfg = util.cfg_from_golden(g)
@@ -110,7 +115,7 @@ def test_golden_fixture(dev, name):
     model = util.build_model(cfg, seed)
     util.perturb(model, seed + 1)
     model = model.to(dev)
-    model.hftt_precision = 'parity'
+    model.hftt_precision = precision
     model.train()
     x = O.synth_spec(B, cfg, salt=seed)
     labels = O.synth_labels(B, cfg, salt=seed + 7)
@@ -148,7 +153,7 @@ def test_golden_fixture(dev, name):
         assert e < (2e-2 if first else 5e-3), (pname, e)
         assert abs(gr.double().norm().item() - stats[2]) < (2e-2 if first else 2e-3) * stats[2], pname
     rep['worst_grad_rel'] = worst
-    print(name, 'parity:', json.dumps(rep))
+    print(name, precision, json.dumps(rep))
 
 
 def test_parity_gradients_against_fp64_evaluation(dev):
@@ -294,7 +299,7 @@ def test_dropout_on_outputs_and_gradients_with_the_device_masks_exported_to_the_
         if not (training and pp > 0.0):
             return t
         m = util.keep_mask_t(seed, next(site), tuple(t.shape), pp).to(t.dtype)
-        return t * m / (1.0 - float(np.float32(pp)))
+        return t * m * keep_scale(pp)
     monkeypatch.setattr(O, '_drop', drop)
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref_out = O.model_forward(sdg, x, cfg, p=p, training=True)
@@ -317,7 +322,7 @@ def test_dropout_on_outputs_and_gradients_with_the_device_masks_exported_to_the_
         # control: the same comparison with the oracle's masks taken from the WRONG sites (shifted by one) must be far off
         site2 = iter(list(range(2, n_sites + 1)) + [1])
         monkeypatch.setattr(O, '_drop', lambda t, pp, training: t if not (training and pp > 0.0) else
-                            t * util.keep_mask_t(seed, next(site2), tuple(t.shape), pp).to(t.dtype) / (1.0 - float(np.float32(pp))))
+                            t * util.keep_mask_t(seed, next(site2), tuple(t.shape), pp).to(t.dtype) * keep_scale(pp))
         sdw = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         O.spec2midi_loss(O.model_forward(sdw, x, cfg, p=p, training=True), *labels).backward()
         w = torch.cat([sdw[name].grad.reshape(-1) for (name, _, o, n) in eng._bound if not name.endswith('fc_k.bias')]).double()

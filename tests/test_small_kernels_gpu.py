@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 import util
-from util import rel_err, max_err, keep_mask_t
+from util import keep_scale, rel_err, max_err, keep_mask_t
 
 pytestmark = pytest.mark.gpu
 
@@ -127,7 +127,7 @@ def test_time_embed_forward_backward(dev, p, half):
     capi.check(L.hftt_time_embed_fwd(xd.data_ptr(), posd.data_ptr(), y.data_ptr(), B, T, N, d, scale, p, site, seed, fl, _st(dev)), 'te')
     ref = x.double().view(B, T, N, d).permute(0, 2, 1, 3).reshape(B * N, T, d) * scale + pos.double()[None]
     mask = keep_mask_t(seed, site, (B * N, T, d), p).double() if p > 0 else torch.ones(B * N, T, d, dtype=torch.float64)
-    ref = ref * mask / (1.0 - float(np.float32(p)))
+    ref = ref * mask * keep_scale(p)
     assert rel_err(y, ref) < (6e-3 if half else 2e-6)
     # backward: dx[(b,t),n,:] = mask * dy[(b,n),t,:] * scale / (1-p); dym = masked dy (for the positional table's column sum)
     dy = torch.randn(B * N, T, d, generator=g).to(dt)
@@ -136,7 +136,7 @@ def test_time_embed_forward_backward(dev, p, half):
     dym = torch.empty(B * N, T, d, device=dev, dtype=dt)
     dyd = dy.to(dev)
     capi.check(L.hftt_time_embed_bwd(dyd.data_ptr(), dx.data_ptr(), dym.data_ptr(), B, T, N, d, scale, p, site, seed, 0, flb, _st(dev)), 'te_bwd')
-    gm = dy.double() * mask / (1.0 - float(np.float32(p)))
+    gm = dy.double() * mask * keep_scale(p)
     assert rel_err(dym, gm) < (6e-3 if half else 2e-6)
     assert rel_err(dx, (gm * scale).view(B, N, T, d).permute(0, 2, 1, 3).reshape(B * T, N, d)) < (6e-3 if half else 2e-6)
 
@@ -199,7 +199,7 @@ def test_dropout_bwd_in_place(dev, half):
     buf = x.to(dev).clone()
     capi.check(L.hftt_dropout_bwd(buf.data_ptr(), M * N, p, site, seed, 1 if half else 0, _st(dev)), 'dropout_bwd')
     mask = keep_mask_t(seed, site, (M, N), p)
-    ref = x.double() * mask.double() / (1.0 - float(np.float32(p)))
+    ref = x.double() * mask.double() * keep_scale(p)
     assert rel_err(buf, ref) < (6e-3 if half else 1e-6)
     assert torch.equal((buf == 0).cpu() | mask, torch.ones(M, N, dtype=torch.bool))
     # the quantised keep rate: thr = round(0.9 * 256) = 230 of 256 (csrc/hftt_common.h), within sampling noise

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import util
-from util import rel_err, max_err, keep_mask_t
+from util import keep_scale, rel_err, max_err, keep_mask_t
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -95,7 +95,7 @@ def test_strip_linear_epilogues(dev):
         out = ops.strip_linear(xd, wp, N, bias=b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res7.to(dev).to(rdt), res_mod=7,
                                out_dtype=torch.float32)
         rr = res7.to(rdt).double()[rows % 7]
-        ref = (lin + b.double()) * mask / (1.0 - float(np.float32(p))) + rr
+        ref = (lin + b.double()) * mask * keep_scale(p) + rr
         assert rel_err(out, ref) < 1e-5
     out = ops.strip_linear(xd, wp, N, residual=res.to(dev), out_dtype=BF)
     assert rel_err(out, lin + res.double()) < 6e-3
@@ -115,7 +115,7 @@ def test_strip_linear_residual_layernorm(dev, M, K, p):
                                             residual=res.to(dev).to(BF), ln=(gam.to(dev), bet.to(dev)))
     lin = bfr(x) @ bfr(W).T + b.double()
     if p > 0:
-        lin = lin * keep_mask_t(seed, site, (M, N), p).double() / (1.0 - float(np.float32(p)))
+        lin = lin * keep_mask_t(seed, site, (M, N), p).double() * keep_scale(p)
     r = lin + bfr(res)
     mu = r.mean(1, keepdim=True); var = r.var(1, unbiased=False, keepdim=True)
     y = (r - mu) / torch.sqrt(var + 1e-5) * gam.double() + bet.double()
@@ -131,11 +131,11 @@ def _ffn_ref(x, W1, b1, W2, b2, gam, bet, p, site_h, site_o, seed):
     M = x.shape[0]
     h = torch.relu(bfr(x) @ bfr(W1).T + b1.double())
     if p > 0:
-        h = h * keep_mask_t(seed, site_h, tuple(h.shape), p).double() / (1.0 - float(np.float32(p)))
+        h = h * keep_mask_t(seed, site_h, tuple(h.shape), p).double() * keep_scale(p)
     hb = bfr(h)                                   # the hidden is the bf16 B operand of the second GEMM
     o = hb @ bfr(W2).T + b2.double()
     if p > 0:
-        o = o * keep_mask_t(seed, site_o, tuple(o.shape), p).double() / (1.0 - float(np.float32(p)))
+        o = o * keep_mask_t(seed, site_o, tuple(o.shape), p).double() * keep_scale(p)
     r = bfr(x) + o
     mu = r.mean(1, keepdim=True); var = r.var(1, unbiased=False, keepdim=True)
     y = (r - mu) / torch.sqrt(var + 1e-5) * gam.double() + bet.double()

@@ -1,0 +1,208 @@
+"""The split-operand ("x3") precision mode: kernels through the C ABI against fp64 references (the whole model in this mode against the
+reference-generated golden fixtures at north_star's 1e-3: tests/test_model_gpu.py, precision 'x3').
+
+npass 2 = fp16 hi + lo (forward products), npass 4 = bf16 hi + lo (products with a gradient operand); see csrc/x3_common.h."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import util
+from util import keep_scale, rel_err, max_err, keep_mask_t
+
+pytestmark = pytest.mark.gpu
+
+# relative to the output's max magnitude.  fp16 pair: 2^-22 operand error, the fp32 accumulation of the MFMA dominates; bf16 pair: 2^-16
+TOL = {2: 4e-6, 4: 6e-5}
+
+
+def _ops():
+    from hftt_hip import ops
+    return ops
+
+
+@pytest.mark.parametrize('npass', [2, 4])
+def test_split_planes_reconstruct_the_weights(dev, npass):
+    """hi + lo of hftt_prep_weights_x3, including values whose lo half is an fp16 subnormal and values beyond fp16's range (clamped)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(96, 64, generator=g) * torch.logspace(-6, 3, 64).unsqueeze(0)
+    pl = ops.prepare_weight(w.to(dev), npass=npass)
+    hi, lo = pl[0, :96].cpu(), pl[1, :96].cpu()
+    dt = torch.float16 if npass == 2 else torch.bfloat16
+    rec = hi.view(dt).double() + lo.view(dt).double()
+    err = (rec - w.double()).abs()
+    if npass == 2:
+        bound = torch.maximum(w.double().abs() * 2.0 ** -21, torch.full_like(err, 6.0e-8))       # 2^-22 relative, or half a subnormal step
+    else:
+        bound = w.double().abs() * 2.0 ** -15
+    assert (err <= bound).all(), (err / bound).max()
+    if npass == 2:
+        big = torch.tensor([[7.0e4, -9.9e4, 1.3e5, 3.0e38] + [0.0] * 28])
+        pl = ops.prepare_weight(big.to(dev), npass=2)
+        rec = pl[0, :1].cpu().view(torch.float16).double() + pl[1, :1].cpu().view(torch.float16).double()
+        assert torch.isfinite(rec).all()
+        assert max_err(rec[0, :3], big[0, :3]) <= 32.0                   # hi saturates at 65504, lo carries the rest (fp16 steps of 32 up there)
+        assert rec[0, 3] == 2 * 65504.0
+
+
+@pytest.mark.parametrize('npass', [2, 4])
+@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (128, 768, 256), (257, 192, 96), (90, 64, 64), (1000, 512, 256), (513, 131, 64), (2000, 256, 768)])
+def test_gemm_nt_plain(dev, M, N, K, npass):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=npass)
+    assert rel_err(out, ref) < TOL[npass]
+    out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=npass, act=1, out_scale=2.5)
+    assert rel_err(out, torch.relu(ref) * 2.5) < TOL[npass]
+
+
+def test_gemm_nt_small_and_large_magnitudes(dev):
+    """fp16 halves: activations of ~1e3 against weights of ~1e-4 (lo halves are subnormals) still carry fp32-grade products."""
+    ops = _ops()
+    M, N, K = 256, 256, 256
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g) * 900.0
+    W = torch.randn(N, K, generator=g) * 2e-4
+    ref = A.double() @ W.double().T
+    out = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=2)
+    assert rel_err(out, ref) < 2e-4          # the weights' absolute floor (3e-8 per element: half an fp16 subnormal step) relative to 2e-4
+    out3 = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=3)
+    assert rel_err(out, out3.double()) < 2e-4
+    # a flushed subnormal lo half would cost 6e-5 per weight, i.e. errors of order 0.1 here
+    W2 = torch.randn(N, K, generator=g) * 0.05
+    out = ops.gemm_nt(A.to(dev), W2.to(dev), None, npass=2)
+    assert rel_err(out, A.double() @ W2.double().T) < 3e-6
+
+
+@pytest.mark.parametrize('npass', [2, 4])
+@pytest.mark.parametrize('N', [256, 64, 128])
+def test_gemm_nt_epilogues(dev, N, npass):
+    ops = _ops()
+    M, K = 333, 128
+    tol = TOL[npass]
+    g = torch.Generator().manual_seed(N)
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    table = torch.randn(7, N, generator=g); res = torch.randn(M, N, generator=g); res5 = torch.randn(5, N, generator=g)
+    gate = torch.randn(M, N, generator=g); gam = torch.randn(N, generator=g); bet = torch.randn(N, generator=g)
+    lin = A.double() @ W.double().T + b.double()
+    rows = torch.arange(M)
+    out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=npass, out_scale=3.0, add_table=table.to(dev), add_mod=7)
+    assert rel_err(out, lin * 3.0 + table.double()[rows % 7]) < tol
+    out = ops.gemm_nt(A.to(dev), W.to(dev), None, npass=npass, gate=gate.to(dev), gate_scale=1.25)
+    ref = torch.where(gate.double() > 0, (A.double() @ W.double().T) * 1.25, torch.zeros((), dtype=torch.float64))
+    assert rel_err(out, ref) < tol
+    p, site, seed = 0.3, 5, 77
+    mask = keep_mask_t(seed, site, (M, N), p).double()
+    out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=npass, drop_p=p, drop_site=site, drop_seed=seed, residual=res5.to(dev), res_mod=5)
+    ref = lin * mask * keep_scale(p) + res5.double()[rows % 5]
+    assert rel_err(out, ref) < tol
+    out, pre, mean, rstd = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=npass, residual=res.to(dev), ln=(gam.to(dev), bet.to(dev)))
+    r = lin + res.double()
+    ref = F.layer_norm(r, (N,), gam.double(), bet.double(), 1e-5)
+    assert rel_err(pre, r) < tol
+    assert rel_err(out, ref) < 1e-4
+    assert rel_err(mean, r.mean(1)) < 1e-4
+    assert rel_err(rstd, 1.0 / torch.sqrt(r.var(1, unbiased=False) + 1e-5)) < 1e-4
+
+
+@pytest.mark.parametrize('npass', [4, 2])
+@pytest.mark.parametrize('M,N,K', [(5000, 256, 256), (1000, 192, 256), (777, 128, 96), (88, 64, 64), (4096, 768, 256), (3000, 512, 256), (2000, 256, 512)])
+def test_gemm_tn(dev, M, N, K, npass):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g) * 1e-6          # gradient-sized: zero or subnormal as fp16, exact range as bf16
+    X = torch.randn(M, K, generator=g)
+    if npass == 2:
+        dY = dY * 1e6
+    dW, db = ops.gemm_tn(dY.to(dev), X.to(dev), npass=npass, out_scale=0.5)
+    ref = 0.5 * dY.double().T @ X.double()
+    scale = math.sqrt(M) * dY.abs().max().item()
+    assert max_err(dW, ref) / scale < TOL[npass] * 3
+    assert max_err(db, 0.5 * dY.double().sum(0)) / scale < 1e-5
+
+
+def _attn_ref(q, k, v, H, mask=None, keep_sc=1.0):
+    n, Lq, d = q.shape
+    Lk = k.shape[1]
+    dh = d // H
+    qh = q.view(n, Lq, H, dh).transpose(1, 2); kh = k.view(n, Lk, H, dh).transpose(1, 2); vh = v.view(n, Lk, H, dh).transpose(1, 2)
+    e = qh @ kh.transpose(-1, -2) / math.sqrt(dh)
+    pr = torch.softmax(e, -1)
+    pd = pr if mask is None else pr * mask * keep_sc
+    o = (pd @ vh).transpose(1, 2).reshape(n, Lq, d)
+    return o, pr, torch.logsumexp(e, -1)
+
+
+GEOMS = [(5, 4, 256, 256, 64), (5, 4, 88, 256, 64), (5, 4, 88, 88, 64), (6, 4, 128, 128, 64),
+         (4, 2, 48, 48, 32), (4, 2, 12, 48, 32), (3, 2, 256, 256, 32), (3, 2, 16, 16, 32), (3, 2, 12, 12, 32), (2, 1, 100, 70, 64)]
+
+
+@pytest.mark.parametrize('qk_scale', [1.0, 40.0])
+@pytest.mark.parametrize('n,H,Lq,Lk,dh', GEOMS)
+def test_attention_fwd_bwd(dev, n, H, Lq, Lk, dh, qk_scale):
+    """qk_scale 40: logits of ~1e4 with near one-hot rows (the reference's first encoder layer on raw log-mel input)."""
+    ops = _ops()
+    d = H * dh
+    g = torch.Generator().manual_seed(Lq * 1000 + Lk + dh)
+    if Lq == Lk:
+        qkv = torch.randn(n, Lq, 3 * d, generator=g)
+        qkv[..., :2 * d] *= qk_scale
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        dq_, dk_, dv_ = (qkv.to(dev)[..., i * d:(i + 1) * d] for i in range(3))
+    else:
+        q = torch.randn(n, Lq, d, generator=g) * qk_scale
+        kv = torch.randn(n, Lk, 2 * d, generator=g)
+        kv[..., :d] *= qk_scale
+        k, v = kv[..., :d], kv[..., d:]
+        dq_ = q.to(dev); kvd = kv.to(dev); dk_, dv_ = kvd[..., :d], kvd[..., d:]
+    do = torch.randn(n, Lq, d, generator=g) * 1e-5        # gradient-sized
+    q64, k64, v64 = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    o_ref, p_ref, lse_ref = _attn_ref(q64, k64, v64, H)
+    (o_ref * do.double()).sum().backward()
+    out, lse, probs = ops.attn_fwd(dq_, dk_, dv_, H, npass=2, want_probs=True)
+    # logits of magnitude L carry an fp32 rounding of ~L * 6e-8 in ANY fp32 implementation; a probability moves by that much (relative)
+    lmax = (q64.detach().view(n, Lq, H, dh).transpose(1, 2) @ k64.detach().view(n, Lk, H, dh).transpose(1, 2).transpose(-1, -2)).abs().max().item() / math.sqrt(dh)
+    ptol = 4e-6 + 4e-7 * lmax
+    assert max_err(probs, p_ref) < ptol
+    assert abs(probs.sum(-1).mean().item() - 1.0) < 1e-4
+    assert rel_err(out, o_ref) < 2 * ptol
+    assert max_err(lse[..., 0] - torch.log(lse[..., 1]), lse_ref) < 1e-4 + 2e-7 * lmax
+    dq, dk, dv = ops.attn_bwd(dq_, dk_, dv_, out, lse, do.to(dev), H, npass=2)
+    gtol = 2e-4 + 3 * ptol
+    if qk_scale == 1.0:
+        assert rel_err(dq, q64.grad) < gtol
+        assert rel_err(dk, k64.grad) < gtol
+    else:
+        # rows that are one-hot to 1e-200 have gradients of 1e-265 in fp64: judge dq / dk against the scale of their factors instead
+        nat = do.abs().max().item() * v.abs().max().item() * max(q.abs().max().item(), k.abs().max().item()) * math.sqrt(dh)
+        assert max_err(dq, q64.grad) < gtol * nat
+        assert max_err(dk, k64.grad) < gtol * nat
+    assert rel_err(dv, v64.grad) < gtol
+
+
+def test_attention_shared_query_and_dropout(dev):
+    """Layer-zero geometry: one query block shared by all sequences (seq stride 0) + dropout with the device RNG."""
+    ops = _ops()
+    n, H, Lq, Lk, dh = 4, 4, 88, 256, 64
+    d = H * dh
+    g = torch.Generator().manual_seed(3)
+    q1 = torch.randn(1, Lq, d, generator=g); k = torch.randn(n, Lk, d, generator=g); v = torch.randn(n, Lk, d, generator=g)
+    do = torch.randn(n, Lq, d, generator=g)
+    p, site, seed = 0.1, 9, 12345
+    mask = keep_mask_t(seed, site, (n, H, Lq, Lk), p).double()
+    qd = q1.to(dev).expand(n, Lq, d)       # stride 0 over sequences
+    q64 = q1.double().clone().requires_grad_(True); k64 = k.double().clone().requires_grad_(True); v64 = v.double().clone().requires_grad_(True)
+    o_ref, p_ref, _ = _attn_ref(q64.expand(n, Lq, d), k64, v64, H, mask, keep_scale(p))
+    (o_ref * do.double()).sum().backward()
+    out, lse, probs = ops.attn_fwd(qd, k.to(dev), v.to(dev), H, npass=2, want_probs=True, drop_p=p, drop_site=site, drop_seed=seed)
+    assert max_err(probs, p_ref) < 2e-5          # returned probabilities are PRE-dropout (model_spec2midi.py:360)
+    assert rel_err(out, o_ref) < 1e-4
+    dq, dk, dv = ops.attn_bwd(qd, k.to(dev), v.to(dev), out, lse, do.to(dev), H, npass=2, drop_p=p, drop_site=site, drop_seed=seed)
+    assert rel_err(dq.sum(0, keepdim=True), q64.grad) < 3e-4
+    assert rel_err(dk, k64.grad) < 3e-4
+    assert rel_err(dv, v64.grad) < 3e-4

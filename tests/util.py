@@ -86,6 +86,15 @@ def keep_mask(seed, site, idx, p):
     return field < np.uint32(thr)
 
 
+def keep_scale(p):
+    """scale of the kept elements (csrc/hftt_common.h: hftt_keep_scale): 256 / thr, the reciprocal of the keep probability actually applied"""
+    if not p > 0.0:
+        return 1.0
+    kk = (1.0 - float(np.float32(p))) * 256.0 + 0.5
+    thr = 256 if kk >= 256.0 else (0 if kk <= 0.0 else int(kk))
+    return float(np.float32(256.0) / np.float32(thr)) if thr > 0 else 0.0
+
+
 def keep_mask_t(seed, site, shape, p):
     n = int(np.prod(shape))
     return torch.from_numpy(keep_mask(seed, site, np.arange(n, dtype=np.uint64), p).reshape(shape))
