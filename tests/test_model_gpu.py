@@ -97,7 +97,7 @@ def test_mini_full_tensors_and_all_grads(dev, precision):
     O.adam_step(params, grads, [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params], 1, lr=1e-4)
     for k, p, gr, mine in zip(names, params, grads, model.parameters()):
         # step 1 of Adam moves every element by lr * g/(|g| + eps): elements with |g| ~ eps amplify rounding noise
-        solid = gr.abs() > 1e-6
+        solid = gr.abs() > (1e-6 if precision == 'parity' else max(1e-6, 2e-2 * gr.abs().max().item()))      # x3: gradients carry ~2e-4 of the tensor's largest
         diff = (mine.detach().cpu().double() - p.double()).abs()
         assert diff[solid].max().item() < 3e-6 if solid.any() else True, k
         assert diff.max().item() <= 2.0e-4 + 1e-7, k
