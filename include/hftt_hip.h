@@ -143,11 +143,26 @@ typedef struct {
   int32_t slot_stride, slot_offset;
 } hftt_strip_pack_entry;
 int hftt_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_pack_entry* table_dev, int n_entries, void* stream);
+/* The split-operand form of the pack (same table type; elem = 2: fp16 halves, 4: bf16 halves).  Every fragment(tile, chunk) of the bf16
+ * pack becomes a (hi, lo) pair of 1 KB fragments, chunk = 2*pt + u naming the 16-deep k step; a 16 KB slot holds the pairs of 8 tiles for
+ * one chunk (order 0: slot = (tile >> 3)*(K/16) + chunk, fragment = 2*(tile & 7) + plane) or of 8 chunks for one tile (order 1, K == 256:
+ * slot = 2*tile + (chunk >> 3), fragment = 2*(chunk & 7) + plane); slots come in pairs: stream position = slot_offset +
+ * slot_stride*(slot >> 1) + (slot & 1) (plain stream: stride 2, offset 0; the fused block interleaves two pairs per hidden tile:
+ * stride 4, offsets 0 / 2).  A packed matrix takes 2 * rows * cols 16-bit elements. */
+int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_pack_entry* table_dev, int n_entries, int elem, void* stream);
 
 #define HFTT_SL_X_BF16 1u       /* x stored as bf16 (else fp32, rounded to bf16 on load) */
 #define HFTT_SL_C_BF16 2u       /* C (and pre_ln_out) stored as bf16 */
 #define HFTT_SL_RES_BF16 4u     /* residual stored as bf16 */
 #define HFTT_SL_RELU 8u
+/* split-operand ("x3") forms of the strip kernels: x, C, residual, pre_ln_out (and the fused block's h_out / gate) are fp32, `w` is an
+ * hftt_x3_strip_pack stream of fp16 (HFTT_SL_X3_F16: forward products) or bf16 (HFTT_SL_X3_BF16: products with a gradient operand)
+ * hi / lo fragment pairs; every product runs in three MFMA passes.  Shapes: K, N multiples of 256 with N/256 x K/256 in
+ * {1x1, 2x1, 3x1, 1x2, 1x3} (LayerNorm form: N == 256, K in {256, 512}), M % 32 == 0, no gate; fused block: d == 256, p == 512.
+ * Pack order: K == 256 without LayerNorm takes the TILE-MAJOR pack (order 1: the kernel walks one 32-column output tile at a time), every
+ * other form the linear pack (order 0). */
+#define HFTT_SL_X3_F16 16u
+#define HFTT_SL_X3_BF16 32u
 /* C[M,N] = epi(x[M,K] . Wl[N,K]^T + bias): same epilogue order as hftt_gemm_nt (relu, out_scale, gate, dropout, residual,
  * LayerNorm over N == 256).  N % 256 == 0; K % 32 == 0 and (K <= 256 or K % 256 == 0); gate is bf16. */
 typedef struct {

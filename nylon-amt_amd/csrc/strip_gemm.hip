@@ -17,6 +17,7 @@
 #include "hftt_common.h"
 #include "hftt_host.h"
 #include "strip_internal.h"
+#include "x3_internal.h"
 #include "../../include/hftt_hip.h"
 
 namespace {
@@ -629,6 +630,14 @@ extern "C" int hftt_strip_pack(const float* params, uint16_t* wstrip, const hftt
 
 extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
   HFTT_REQUIRE(d != nullptr, "strip_linear: null descriptor");
+  if (d->flags & (HFTT_SL_X3_F16 | HFTT_SL_X3_BF16)) {      // split-operand forms (x3_strip.hip): fp32 tensors
+    HFTT_REQUIRE(d->M > 0 && d->x != nullptr && d->w != nullptr && d->C != nullptr, "strip_linear: null operand");
+    HFTT_REQUIRE((((uintptr_t)d->x | (uintptr_t)d->C | (uintptr_t)d->w | (uintptr_t)d->residual | (uintptr_t)d->pre_ln_out) & 15) == 0, "strip_linear: operands must be 16-byte aligned");
+    HFTT_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && d->res_mod >= 0, "strip_linear: drop_p / res_mod out of range");
+    HFTT_REQUIRE((long)d->M * d->N < (1L << 33), "strip_linear: M*N too large for the 32-bit dropout pair index");
+    HFTT_REQUIRE(d->ln_gamma == nullptr || (d->N == 256 && d->ln_beta != nullptr && d->ldc == 256 && !(d->flags & HFTT_SL_RELU)), "strip_linear: LayerNorm needs N == 256 == ldc, beta, no ReLU");
+    return hftt_x3_strip_linear(*d, reinterpret_cast<hipStream_t>(stream));
+  }
   HFTT_REQUIRE(d->M > 0 && d->N >= 256 && d->N % 256 == 0 && d->N <= 2048, "strip_linear: N=%d must be a multiple of 256", d->N);
   HFTT_REQUIRE(d->K >= 128 && d->K % 128 == 0 && (d->K <= 256 || d->K % 256 == 0), "strip_linear: K=%d must be 128, 256 or a multiple of 256", d->K);
   HFTT_REQUIRE((long)d->M * d->N < (1L << 33), "strip_linear: M*N too large for the 32-bit dropout pair index");
@@ -667,7 +676,25 @@ extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
   return xbf ? launch_linear<true, false, false>(*d, st) : launch_linear<false, false, false>(*d, st);
 }
 
+int check_ffn_x3(const hftt_ffn_desc* d, int mode, const char* what) {
+  HFTT_REQUIRE(d->mode == mode, "%s: descriptor mode %d", what, d->mode);
+  HFTT_REQUIRE(d->M > 0 && d->d == 256, "%s: needs d == 256 (got M=%d d=%d)", what, d->M, d->d);
+  HFTT_REQUIRE((long)d->M * d->p < (1L << 33), "%s: M*p too large for the 32-bit dropout pair index", what);
+  HFTT_REQUIRE(d->x != nullptr && d->w != nullptr && d->y != nullptr, "%s: null operand", what);
+  HFTT_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && (d->h_out == nullptr || d->ldh % 4 == 0) && (d->residual == nullptr || d->ldr % 4 == 0) && (d->gate == nullptr || d->ldg % 4 == 0),
+               "%s: rows must be 16-byte aligned", what);
+  HFTT_REQUIRE((((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->w | (uintptr_t)d->h_out | (uintptr_t)d->gate | (uintptr_t)d->residual | (uintptr_t)d->pre_ln_out) & 15) == 0,
+               "%s: operands must be 16-byte aligned", what);
+  HFTT_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "%s: drop_p out of range", what);
+  return 0;
+}
+
 extern "C" int hftt_ffn_res_ln_fwd(const hftt_ffn_desc* d, void* stream) {
+  if (d != nullptr && (d->flags & (HFTT_SL_X3_F16 | HFTT_SL_X3_BF16))) {
+    if (int rc = check_ffn_x3(d, 0, "ffn_res_ln_fwd")) return rc;
+    HFTT_REQUIRE(d->ln_gamma != nullptr && d->ln_beta != nullptr && d->ldy == 256, "ffn_res_ln_fwd: needs gamma, beta and ldy == 256");
+    return hftt_x3_strip_mlp(*d, reinterpret_cast<hipStream_t>(stream));
+  }
   if (int rc = check_ffn(d, 0, "ffn_res_ln_fwd")) return rc;
   HFTT_REQUIRE(d->ln_gamma != nullptr && d->ln_beta != nullptr && d->ldy == 256, "ffn_res_ln_fwd: needs gamma, beta and ldy == 256");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -677,6 +704,11 @@ extern "C" int hftt_ffn_res_ln_fwd(const hftt_ffn_desc* d, void* stream) {
 }
 
 extern "C" int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream) {
+  if (d != nullptr && (d->flags & (HFTT_SL_X3_F16 | HFTT_SL_X3_BF16))) {
+    if (int rc = check_ffn_x3(d, 1, "ffn_bwd_dx")) return rc;
+    HFTT_REQUIRE(d->gate != nullptr && d->h_out != nullptr, "ffn_bwd_dx: needs the stored hidden (gate) and the dh output");
+    return hftt_x3_strip_mlp(*d, reinterpret_cast<hipStream_t>(stream));
+  }
   if (int rc = check_ffn(d, 1, "ffn_bwd_dx")) return rc;
   HFTT_REQUIRE(d->gate != nullptr && d->ldg % 8 == 0 && ((uintptr_t)d->gate & 15) == 0, "ffn_bwd_dx: needs the stored hidden (bf16, 16-byte aligned rows)");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -5,3 +5,5 @@
 #include "../../include/hftt_hip.h"
 int hftt_x3_attn_fwd(const hftt_attn_desc& d, hipStream_t st);      // x3_attn.hip
 int hftt_x3_attn_bwd(const hftt_attn_desc& d, hipStream_t st);
+int hftt_x3_strip_linear(const hftt_strip_desc& d, hipStream_t st);  // x3_strip.hip
+int hftt_x3_strip_mlp(const hftt_ffn_desc& d, hipStream_t st);

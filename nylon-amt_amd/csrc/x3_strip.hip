@@ -1,0 +1,783 @@
+// Strip kernels of the split-operand ("x3") precision mode (gfx950): the nn.Linear layers whose width is a multiple of 256 and the fused
+// position-wise feed-forward block, fp32 tensors in HBM, every product in three MFMA passes on 16-bit halves (x3_common.h).
+// Contract: include/hftt_hip.h (hftt_strip_linear / hftt_ffn_res_ln_fwd / hftt_ffn_bwd_dx with HFTT_SL_X3_F16 or HFTT_SL_X3_BF16).
+//
+// Geometry as in strip_gemm2.hip: one persistent workgroup per CU, 4 waves (one per SIMD, up to 512 registers), a wave owns a strip of 32
+// tokens and keeps it in registers as the MFMA B operand for the whole block; the weights are the A operand, pre-packed in consumption
+// order (hftt_x3_strip_pack) and streamed L2 -> LDS by LDS-DMA through a 4 x 16 KB ring, one s_barrier per slot.  What is different:
+//   * a strip chunk (8 features of the lane's token) lives in 8 registers either as 8 raw fp32 values or, after conversion, as its hi
+//     and lo halves (4 + 4 registers): conversion happens in place one slot before the chunk's first use, and as soon as a chunk has fed
+//     its last MFMA of the block its registers receive the next block's values (two 16-byte loads) -- a rolling prefetch with no second
+//     register set, so strip (128) + accumulators (128) leave room for everything else;
+//   * a ring slot holds the hi and lo fragments of 8 output tiles for ONE k chunk: 16 fragments = 24 MFMAs per wave (lo.hi, hi.lo, hi.hi
+//     per tile), i.e. 1.5 MFMAs per kilobyte read from LDS and per kilobyte streamed from L2 against 1.0 in the bf16 kernels;
+//   * results leave from the epilogue directly (fp32, 16 bytes per lane).
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+#include "hftt_common.h"
+#include "x3_common.h"
+#include "hftt_host.h"
+#include "x3_internal.h"
+#include "../../include/hftt_hip.h"
+
+namespace {
+
+#include "strip_pipe.h"
+
+__host__ __device__ inline int x3_i_of_c(int c) { const int g = c & 15, hh = c >> 4; return (g & 3) + 8 * (g >> 2) + 4 * hh; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight packing: one thread per 16-byte destination chunk pair (8 consecutive k of one logical row -> hi fragment piece + lo fragment piece)
+// Fragment (tile, chunk, plane), 64 lanes x 8 halves: lane (i = lane & 31, hk = lane >> 5) holds, for chunk = 2*pt + u,
+//   Wl[32*tile + c(i)][32*pt + 16*hk + 8*u + 0..7]   (c(i) as in the bf16 strip pack: accumulator register g of a lane = feature 16h + g).
+// Slots of 16 fragments.  order 0 ("linear"): slot = (tile >> 3) * (K / 16) + chunk, fragment = 2 * (tile & 7) + plane;
+// order 1 ("tile-major", K == 256): slot = 2 * tile + (chunk >> 3), fragment = 2 * (chunk & 7) + plane.
+// Stream position of a slot: slot_offset + slot_stride * (slot >> 1) + (slot & 1)   (slots come in pairs; the fused FFN interleaves pairs).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void x3_strip_pack_kernel(const float* __restrict__ params, unsigned short* __restrict__ dst,
+                                                            const hftt_strip_pack_entry* __restrict__ table) {
+  const hftt_strip_pack_entry e = table[blockIdx.y];
+  const int nrows = e.transpose ? e.cols : e.rows;
+  const int nk = e.transpose ? e.rows : e.cols;
+  const int kch = nk >> 3;
+  const long total = (long)nrows * kch;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int nl = (int)(t / kch), kc = (int)(t - (long)nl * kch);
+    const int n = e.n0 + nl, k = e.k0 + kc * 8;
+    float v[8];
+    const float* src = params + e.src_off;
+    if (e.transpose) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = src[(long)(kc * 8 + q) * e.src_ld + nl];
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(src + (long)nl * e.src_ld + kc * 8);
+      const float4 b = *reinterpret_cast<const float4*>(src + (long)nl * e.src_ld + kc * 8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    const int tile = n >> 5, i = x3_i_of_c(n & 31);
+    // feature k of the logical row sits at chunk 2*pt + u with pt = k >> 5, lane half hk = (k >> 4) & 1, u = (k >> 3) & 1
+    const int pt = k >> 5, hk2 = (k >> 4) & 1, u = (k >> 3) & 1;
+    const int ch = 2 * pt + u;
+    long slot, frag;
+    if (e.order == 0) { slot = (long)(tile >> 3) * (e.K >> 4) + ch; frag = 2 * (tile & 7); }
+    else { slot = 2 * tile + (ch >> 3); frag = 2 * (ch & 7); }
+    const long pos = e.slot_offset + (long)e.slot_stride * (slot >> 1) + (slot & 1);
+    const long off = (pos * 16 + frag) * 512 + (hk2 * 32 + i) * 8;
+    bf16x8 hi, lo;
+    x3_split8<E>(v, hi, lo);
+    *reinterpret_cast<bf16x8*>(dst + e.dst_off + off) = hi;
+    *reinterpret_cast<bf16x8*>(dst + e.dst_off + off + 512) = lo;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------------
+// the weight ring: stream fetched three slots ahead and ALWAYS (past the workgroup's last slot it wraps to the head: three harmless
+// extra slots, drained before the kernel ends), so "at least eight vector-memory instructions were issued after the fill of the slot
+// about to be consumed" holds at every slot boundary and the wait is the constant s_waitcnt vmcnt(8) (see strip_gemm2.hip).
+struct XPipe {
+  const unsigned short* w;
+  int S;                        // slots per block
+  int fill_pos;
+  unsigned ring;
+  int wave, lane;
+  bool nofill, nobar;           // timing experiments only (HFTT_X3_DEBUG bits 0 / 1): results are garbage
+  __device__ __forceinline__ const unsigned short* src_of(int pos) const { return w + ((long)pos * 16 + wave * 4) * 512 + lane * 8; }
+  __device__ __forceinline__ void advance() { fill_pos = (fill_pos + 1 == S) ? 0 : fill_pos + 1; }
+  template <int BUF>
+  __device__ __forceinline__ void fill() {
+    glds16x4(src_of(fill_pos), ring + (unsigned)BUF * SLOT_BYTES + (unsigned)wave * 4096u);
+    advance();
+  }
+  __device__ __forceinline__ void begin_slot() {
+    if (!nobar) { HFTT_WAITVM(8); __builtin_amdgcn_s_barrier(); }
+  }
+  template <int BUF>
+  __device__ __forceinline__ void refill() {      // BUF: the slot being consumed; the refill goes to (BUF + 3) % 4
+    if (!nofill) glds16x4(src_of(fill_pos), ring + (unsigned)((BUF + FILL_AHEAD) & (NSLOT - 1)) * SLOT_BYTES + (unsigned)wave * 4096u);
+    advance();
+  }
+  __device__ __forceinline__ void drain() { HFTT_WAITVM(0); }
+};
+
+// a strip chunk: 8 features of the lane's token in 8 registers -- raw fp32 (a = first four, b = last four) or converted (a = hi, b = lo)
+struct XChunk { u4v a, b; };
+__device__ __forceinline__ void chunk_load(XChunk& c, const float* p) {
+  c.a = *reinterpret_cast<const u4v*>(p);
+  c.b = *reinterpret_cast<const u4v*>(p + 4);
+}
+template <int E>
+__device__ __forceinline__ void chunk_convert(XChunk& c) {
+  const float v[8] = {__uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
+                      __uint_as_float(c.b.x), __uint_as_float(c.b.y), __uint_as_float(c.b.z), __uint_as_float(c.b.w)};
+  bf16x8 hi, lo;
+  x3_split8<E>(v, hi, lo);
+  c.a = __builtin_bit_cast(u4v, hi); c.b = __builtin_bit_cast(u4v, lo);
+}
+// hi + lo of a converted chunk back to fp32 (the residual of the fused FFN: the block input itself, to 2^-22)
+template <int E>
+__device__ __forceinline__ void chunk_values(const XChunk& c, float* v) {
+  const unsigned h[4] = {c.a.x, c.a.y, c.a.z, c.a.w}, l[4] = {c.b.x, c.b.y, c.b.z, c.b.w};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    float h0, h1, l0, l1;
+    X3<E>::unpk(h[q], h0, h1); X3<E>::unpk(l[q], l0, l1);
+    v[2 * q] = h0 + l0; v[2 * q + 1] = h1 + l1;
+  }
+}
+// element offset, inside the lane's row view (row + 16 * h), of chunk ch = 2 * pt + u: features 32 * pt + 8 * u + [0, 8) of the lane half
+__device__ __forceinline__ int chunk_off(int ch) { return (ch >> 1) * 32 + (ch & 1) * 8; }
+
+// One ring slot against ONE strip chunk: fragments 2t (hi) and 2t + 1 (lo) of output tile t -> acc[t] += lo.x_hi + hi.x_lo + hi.x_hi.
+// Four fragment reads are in flight ahead of the MFMAs; side(i) (i = 0 .. 23) is called behind MFMA i, so the slot's memory and
+// conversion work sits in program order BETWEEN the MFMAs (a wave alone on its SIMD issues in order).
+template <int E, typename G>
+__device__ __forceinline__ void x3_slot_tiles(const unsigned char* slot, const XChunk& x, f32x16 (&acc)[8], G&& side) {
+  bf16x8 fr[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) fr[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
+  const bf16x8 xh = __builtin_bit_cast(bf16x8, x.a), xl = __builtin_bit_cast(bf16x8, x.b);
+  static_for<8>([&](auto t_c) __attribute__((always_inline)) {
+    constexpr int t = decltype(t_c)::value;
+    acc[t] = X3<E>::mma(fr[2 * t + 1], xh, acc[t]);
+    side(std::integral_constant<int, 3 * t>{});
+    if (2 * t + 4 < 16) fr[2 * t + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 4) * 1024);
+    acc[t] = X3<E>::mma(fr[2 * t], xl, acc[t]);
+    side(std::integral_constant<int, 3 * t + 1>{});
+    if (2 * t + 5 < 16) fr[2 * t + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 5) * 1024);
+    acc[t] = X3<E>::mma(fr[2 * t], xh, acc[t]);
+    side(std::integral_constant<int, 3 * t + 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+// One ring slot against EIGHT strip chunks (tile-major fc_1 half tile): fragments 2q (hi), 2q + 1 (lo) of chunk x[q] -> one accumulator
+template <int E, int OFF, typename G>
+__device__ __forceinline__ void x3_slot_chunks(const unsigned char* slot, const XChunk (&x)[16], f32x16& acc, G&& side) {
+  bf16x8 fr[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) fr[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
+  static_for<8>([&](auto q_c) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_c)::value;
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, x[OFF + q].a), xl = __builtin_bit_cast(bf16x8, x[OFF + q].b);
+    acc = X3<E>::mma(fr[2 * q + 1], xh, acc);
+    side(std::integral_constant<int, 3 * q>{});
+    if (2 * q + 4 < 16) fr[2 * q + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 4) * 1024);
+    acc = X3<E>::mma(fr[2 * q], xl, acc);
+    side(std::integral_constant<int, 3 * q + 1>{});
+    if (2 * q + 5 < 16) fr[2 * q + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 5) * 1024);
+    acc = X3<E>::mma(fr[2 * q], xh, acc);
+    side(std::integral_constant<int, 3 * q + 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+__device__ __forceinline__ void load16f(const float* p, float* v) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const float4 t = reinterpret_cast<const float4*>(p)[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+}
+__device__ __forceinline__ void store16f(float* p, const float* v) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// A wave's 32 x 32 fp32 tile (lane (j, h): token j, columns 16h .. 16h+15 in v) -> global memory as WHOLE 128-byte row segments: 16 rows at a
+// time through a wave-private LDS patch (16 rows x 36 floats), read back with 8 lanes per row, so one store instruction writes 8 complete
+// lines.  Stored straight from the accumulator layout an instruction scatters 64 16-byte pieces over 32 rows, and a CU's store path then
+// moves ~7 bytes per clock (MI355X_MICROARCH.md, store-issue bound): the fp32 results of the QKV projection cost 210 us of its 510 us that
+// way (HFTT_X3_DEBUG=16).  LDS operations of one wave execute in order, so the patch needs no barrier.
+constexpr int STG_RS = 36;                            // floats per staged row (144 B: the 16-byte row pieces of 8 rows fall on 8 different bank quads)
+constexpr int STG_BYTES_PER_WAVE = 16 * STG_RS * 4;
+__device__ __forceinline__ void tile_store_rows(float* stage, const float* v, int j, int h, int lane, float* gtile, long ld, bool ok) {
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    if ((j >> 4) == half) {
+      float* w = stage + (j & 15) * STG_RS + 16 * h;
+#pragma unroll
+      for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(w)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int r = (lane >> 3) + 8 * k;
+      const float4 t = *reinterpret_cast<const float4*>(stage + r * STG_RS + (lane & 7) * 4);
+      if (ok) *reinterpret_cast<float4*>(gtile + (long)(half * 16 + r) * ld + (lane & 7) * 4) = t;
+    }
+  }
+}
+
+// LayerNorm over the 256 features of the lane's token (lane: 128 of them in acc, partner lane ^ 32 the rest), fp32 out
+__device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_lds, const float* beta_lds, int h, float* mean_out, float* rstd_out,
+                                           long tok, bool ok, float* pre_row, float* y_row) {
+  float s = 0.f;
+#pragma unroll
+  for (int ot = 0; ot < 8; ot++)
+#pragma unroll
+    for (int q = 0; q < 16; q++) s += acc[ot][q];
+  const float mean = xor32_sum(s) * (1.0f / 256.0f);
+  float qs = 0.f;
+#pragma unroll
+  for (int ot = 0; ot < 8; ot++)
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const float dlt = acc[ot][q] - mean; qs += dlt * dlt; }
+  const float rstd = 1.0f / sqrtf(xor32_sum(qs) * (1.0f / 256.0f) + 1e-5f);
+  if (ok && h == 0) {
+    if (mean_out != nullptr) mean_out[tok] = mean;
+    if (rstd_out != nullptr) rstd_out[tok] = rstd;
+  }
+#pragma unroll
+  for (int ot = 0; ot < 8; ot++) {
+    float v[16], ga[16], be[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = acc[ot][q];
+    if (pre_row != nullptr && ok) store16f(pre_row + ot * 32, v);
+    lds16f(gamma_lds + ot * 32 + 16 * h, ga);
+    lds16f(beta_lds + ot * 32 + 16 * h, be);
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = (v[q] - mean) * rstd * ga[q] + be[q];
+    if (ok) store16f(y_row + ot * 32, v);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C = epi(x . Wl^T + bias), fp32 tensors, K = 256 * KCH, N = 256 * PASSES; LN: N == 256 with dropout / residual / LayerNorm
+// ---------------------------------------------------------------------------------------------------------------------
+template <int E, bool LN, int PASSES, int KCH, bool HR>
+__global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  constexpr int STEPS = PASSES * KCH;               // 16-slot steps per block
+  const long nblk = ((long)g.M + 127) / 128;
+  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // bias[N] | gamma[256] | beta[256]
+  const float* xb = reinterpret_cast<const float*>(g.x);
+  float* cb = reinterpret_cast<float*>(g.C);
+  float* preb = reinterpret_cast<float*>(g.pre_ln_out);
+  const float* rb = reinterpret_cast<const float*>(g.residual);
+  const bool relu = g.flags & HFTT_SL_RELU;
+
+  XPipe P;
+  P.w = g.w; P.S = STEPS * 16; P.fill_pos = 0;
+  P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
+  P.wave = wave; P.lane = lane;
+  P.nofill = g.pad & 1; P.nobar = g.pad & 2;
+  const bool dbg_nostore = g.pad & 16, dbg_noload = g.pad & 32, dbg_noconv = g.pad & 64;
+
+  auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
+
+  for (int i = tid; i < g.N; i += 256) prm[i] = g.bias != nullptr ? g.bias[i] : 0.f;
+  if (LN) { prm[g.N + tid] = g.ln_gamma[tid]; prm[g.N + 256 + tid] = g.ln_beta[tid]; }
+  XChunk xr[16];
+  {
+    const float* p0 = xb + tok_of(blockIdx.x) * g.ldx + 16 * h;
+#pragma unroll
+    for (int c = 0; c < 16; c++) chunk_load(xr[c], p0 + chunk_off(c));
+  }
+  P.fill<0>(); P.fill<1>(); P.fill<2>();
+  static_assert(FILL_AHEAD == 3, "prologue fills");
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();                       // the parameter rows in LDS are read (by every wave) before the first slot's barrier
+  chunk_convert<E>(xr[0]);
+
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = hftt_keep_scale(g.drop_p);
+  const unsigned char* abase = smem + lane * 16;
+
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int hb = h;                                       // opaque per iteration (LICM would hoist per-tile column arithmetic out of the loop: spills)
+    asm volatile("" : "+v"(hb));
+    const long tok = blk * 128 + wave * 32 + j;
+    const bool wave_ok = (blk * 128 + wave * 32) < g.M;          // M % 32 == 0 (host check)
+    const long tokc = tok_of(blk);
+    const long nxt = blk + gridDim.x;
+    const float* xrow = xb + tokc * g.ldx + 16 * hb;
+    const float* xrow_next = xb + (nxt < nblk ? tok_of(nxt) : tokc) * g.ldx + 16 * hb;      // (past the last block: a harmless re-read)
+    const long rrow = g.res_mod > 0 ? (long)((unsigned)tokc % (unsigned)g.res_mod) : tokc;
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    const float* prm_b = prm + zero;                  // (keeps the LDS parameter reads inside the iteration)
+    for (int pass = 0; pass < PASSES; pass++) {
+      f32x16 acc[8];
+#pragma unroll
+      for (int ot = 0; ot < 8; ot++) {                // accumulators start from the bias
+        float b[16];
+        lds16f(prm_b + pass * 256 + ot * 32 + 16 * hb, b);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[ot][q] = b[q];
+      }
+      for (int kc = 0; kc < KCH; kc++) {
+        // the chunk set in the registers at this step is k chunk kc; as a chunk is consumed its registers receive the same chunk position
+        // of the NEXT step's set (next k chunk, or k chunk 0 of the next pass / block).  KCH == 1: the set is re-used by every pass of
+        // the block and only replaced (by the next block's) during the last pass; conversion only in pass 0.
+        const bool last_step = (pass == PASSES - 1) && (kc == KCH - 1);
+        const bool reload = ((KCH > 1) || last_step) && !dbg_noload;
+        const bool convert = ((KCH > 1) || (pass == 0)) && !dbg_noconv;
+        const float* nsrc = last_step ? xrow_next : (xrow + ((kc + 1 == KCH) ? 0 : kc + 1) * 256);
+        static_for<16>([&](auto c_c) __attribute__((always_inline)) {
+          constexpr int c = decltype(c_c)::value;
+          constexpr int BUF = c & 3;
+          P.begin_slot();
+          x3_slot_tiles<E>(abase + BUF * SLOT_BYTES, xr[c], acc, [&](auto i_c) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_c)::value;
+            if (i == 1) P.template refill<BUF>();
+            if (i == 5 && c > 0) { if (reload) chunk_load(xr[c - 1], nsrc + chunk_off(c - 1)); }
+            if (i == 9 && c < 15) { if (convert) chunk_convert<E>(xr[c + 1]); }
+          });
+        });
+        // the last chunk of the set is replaced here, and chunk 0 of the next set converted (its load is 15 slots old)
+        if (reload) chunk_load(xr[15], nsrc + chunk_off(15));
+        if (((KCH > 1) || last_step) && !dbg_noconv) chunk_convert<E>(xr[0]);
+      }
+      // ---------------- epilogue of this pass ----------------
+      const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;
+      float* crow = cb + tok * g.ldc + pass * 256 + 16 * hb;
+      const float* rrow_p = rb + (HR ? rrow * g.ldr + pass * 256 + 16 * hb : 0);
+      float rnext[16];
+      if (HR) load16f(rrow_p, rnext);
+#pragma unroll
+      for (int ot = 0; ot < 8; ot++) {
+        const int col0 = pass * 256 + ot * 32 + 16 * hb;
+        float v[16], r[16];
+        if (HR) {
+#pragma unroll
+          for (int q = 0; q < 16; q++) r[q] = rnext[q];
+          if (ot < 7) load16f(rrow_p + (ot + 1) * 32, rnext);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          float t = acc[ot][q];
+          if (!LN && relu) t = fmaxf(t, 0.f);
+          v[q] = t * g.out_scale;
+        }
+        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + (col0 >> 2), thr, inv_keep);
+        if (HR) {
+#pragma unroll
+          for (int q = 0; q < 16; q++) v[q] += r[q];
+        }
+        if (LN) {
+#pragma unroll
+          for (int q = 0; q < 16; q++) acc[ot][q] = v[q];
+        } else if (wave_ok && !dbg_nostore) {
+          store16f(crow + ot * 32, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (LN) {
+        x3_ln_rows(acc, prm_b + g.N, prm_b + g.N + 256, hb, g.ln_mean, g.ln_rstd, tok, wave_ok,
+                   preb != nullptr ? preb + tok * g.ldc + 16 * hb : nullptr, crow);
+      }
+    }
+  }
+  P.drain();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C = epi(x . Wl^T + bias) for K == 256 without LayerNorm, output-tile-major ("N-outer"): one 32-column output tile at a time against the
+// whole resident strip (two ring slots of a tile-major pack), so a wave carries ONE accumulator tile (16 registers) instead of eight, a
+// tile's 64 bytes per lane leave as soon as its 48 MFMAs are done -- stores spread evenly over the block instead of one burst per pass --
+// and the kernel fits 256 registers: TWO workgroups per CU (each with its own ring) run free of each other, one's epilogue, conversions and
+// strip loads under the other's MFMAs.  (The K-outer form above, one wave per SIMD, ran MFMA, loads and stores strictly one after the
+// other: QKV at 262,144 tokens 560 us = 250 us of MFMA + 240 us of stores + 120 us of loads, HFTT_X3_DEBUG.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int E, int NT, bool HR>
+__global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_desc g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const long nblk = ((long)g.M + 127) / 128;
+  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // bias[N] | four wave-private store patches
+  float* stage = reinterpret_cast<float*>(smem + RING_BYTES + 4 * NT * 32 + wave * STG_BYTES_PER_WAVE);
+  const float* xb = reinterpret_cast<const float*>(g.x);
+  float* cb = reinterpret_cast<float*>(g.C);
+  const float* rb = reinterpret_cast<const float*>(g.residual);
+  const bool relu = g.flags & HFTT_SL_RELU;
+
+  XPipe P;
+  P.w = g.w; P.S = 2 * NT; P.fill_pos = 0;
+  P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
+  P.wave = wave; P.lane = lane;
+  P.nofill = g.pad & 1; P.nobar = g.pad & 2;
+  const bool dbg_nostore = g.pad & 16;
+
+  auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
+  for (int i = tid; i < g.N; i += 256) prm[i] = g.bias != nullptr ? g.bias[i] : 0.f;
+  XChunk xr[16];
+  {
+    const float* p0 = xb + tok_of(blockIdx.x) * g.ldx + 16 * h;
+#pragma unroll
+    for (int c = 0; c < 16; c++) chunk_load(xr[c], p0 + chunk_off(c));
+  }
+  P.fill<0>(); P.fill<1>(); P.fill<2>();
+  static_assert(FILL_AHEAD == 3, "prologue fills");
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = hftt_keep_scale(g.drop_p);
+  const unsigned char* abase = smem + lane * 16;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int hb = h;
+    asm volatile("" : "+v"(hb));
+    const long tok = blk * 128 + wave * 32 + j;
+    const bool wave_ok = (blk * 128 + wave * 32) < g.M;
+    const long tokc = tok_of(blk);
+    const long nxt = blk + gridDim.x;
+    const float* xrow_next = xb + (nxt < nblk ? tok_of(nxt) : tokc) * g.ldx + 16 * hb;
+    const long rrow = g.res_mod > 0 ? (long)((unsigned)tokc % (unsigned)g.res_mod) : tokc;
+    const float* rrow_p = rb + (HR ? rrow * g.ldr + 16 * hb : 0);
+    float* cwave = cb + (blk * 128 + wave * 32) * g.ldc;        // row 0 of this wave's strip
+    const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    const float* prm_b = prm + zero;
+#pragma unroll
+    for (int c = 0; c < 16; c++) chunk_convert<E>(xr[c]);       // this block's strip (loaded during the previous block's last tile)
+
+    // a run-time loop over tile PAIRS (the ring buffers repeat every two tiles): fully unrolled, hipcc forms every tile's store / residual
+    // address up front and spills them
+    for (int tp = 0; tp < NT / 2; tp++)
+    static_for<2>([&](auto hf_c) __attribute__((always_inline)) {
+      constexpr int half = decltype(hf_c)::value;
+      constexpr int BA = (2 * half) & 3, BB = (2 * half + 1) & 3;
+      const int t = 2 * tp + half;
+      const bool LAST = (t == NT - 1);
+      f32x16 hacc;
+      {
+        float b[16];
+        lds16f(prm_b + t * 32 + 16 * hb, b);
+#pragma unroll
+        for (int q = 0; q < 16; q++) hacc[q] = b[q];
+      }
+      float r[16];
+      P.begin_slot();
+      x3_slot_chunks<E, 0>(abase + BA * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<BA>();
+        if (i == 4 && HR) load16f(rrow_p + t * 32, r);
+        // last tile of the block: a chunk that has fed its three MFMAs takes the next block's values
+        if (LAST && i % 3 == 2) chunk_load(xr[i / 3], xrow_next + chunk_off(i / 3));
+      });
+      P.begin_slot();
+      x3_slot_chunks<E, 8>(abase + BB * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<BB>();
+        if (LAST && i % 3 == 2) chunk_load(xr[8 + i / 3], xrow_next + chunk_off(8 + i / 3));
+      });
+      // ---- this tile's epilogue ----
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        float a = hacc[q];
+        if (relu) a = fmaxf(a, 0.f);
+        v[q] = a * g.out_scale;
+      }
+      if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + ((t * 32 + 16 * hb) >> 2), thr, inv_keep);
+      if (HR) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] += r[q];
+      }
+      tile_store_rows(stage, v, j, hb, lane, cwave + t * 32, g.ldc, wave_ok && !dbg_nostore);
+    });
+  }
+  P.drain();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fused two-GEMM block, d = 256, p = 32 * PT: mode 0 = FFN forward + residual + LayerNorm (fp16 halves), mode 1 = dX half of its
+// backward (bf16 halves).  Stream per hidden tile t: two slots of the first matrix (tile-major: k chunks 0-7, 8-15), then two slots of
+// the second (K-slice t: u = 0, 1).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE, int PT>
+__global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
+  constexpr int E = (MODE == 0) ? X3_F16 : X3_BF16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  constexpr int p = PT * 32;
+  const long nblk = ((long)g.M + 127) / 128;
+  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // b1[p] | b2[256] | gamma[256] | beta[256]
+  const float* xb = reinterpret_cast<const float*>(g.x);
+  float* yb = reinterpret_cast<float*>(g.y);
+  float* preb = reinterpret_cast<float*>(g.pre_ln_out);
+  const float* rb = reinterpret_cast<const float*>(g.residual);
+  float* hob = reinterpret_cast<float*>(g.h_out);
+  const float* gtb = reinterpret_cast<const float*>(g.gate);
+  const bool has_res = (MODE == 1) && g.residual != nullptr;
+
+  XPipe P;
+  P.w = g.w; P.S = 4 * PT; P.fill_pos = 0;
+  P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
+  P.wave = wave; P.lane = lane;
+  P.nofill = g.pad & 1; P.nobar = g.pad & 2;
+
+  auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
+
+  for (int i = tid; i < p; i += 256) prm[i] = (MODE == 0 && g.b1 != nullptr) ? g.b1[i] : 0.f;
+  prm[p + tid] = (MODE == 0 && g.b2 != nullptr) ? g.b2[tid] : 0.f;
+  if (MODE == 0) { prm[p + 256 + tid] = g.ln_gamma[tid]; prm[p + 512 + tid] = g.ln_beta[tid]; }
+
+  XChunk xr[16];
+  {
+    const float* p0 = xb + tok_of(blockIdx.x) * g.ldx + 16 * h;
+#pragma unroll
+    for (int c = 0; c < 16; c++) chunk_load(xr[c], p0 + chunk_off(c));
+  }
+  P.fill<0>(); P.fill<1>(); P.fill<2>();
+  static_assert(FILL_AHEAD == 3, "prologue fills");
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = hftt_keep_scale(g.drop_p);
+  const unsigned char* abase = smem + lane * 16;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int hb = h;
+    asm volatile("" : "+v"(hb));
+    const long tok = blk * 128 + wave * 32 + j;
+    const bool wave_ok = (blk * 128 + wave * 32) < g.M;
+    const long tokc = tok_of(blk);
+    const long nxt = blk + gridDim.x;
+    const float* xrow_next = xb + (nxt < nblk ? tok_of(nxt) : tokc) * g.ldx + 16 * hb;
+    const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)p) >> 2;
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    const float* prm_b = prm + zero;
+    // this block's strip: loaded by the previous block's epilogue (or the prologue), converted here
+#pragma unroll
+    for (int c = 0; c < 16; c++) chunk_convert<E>(xr[c]);
+
+    f32x16 yacc[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ot++) {
+      float b[16];
+      lds16f(prm_b + p + ot * 32 + 16 * hb, b);
+#pragma unroll
+      for (int q = 0; q < 16; q++) yacc[ot][q] = b[q];
+    }
+    float gnext[16];                                  // mode 1: stored hidden (the gate) of the next tile
+    if (MODE == 1) load16f(gtb + tokc * g.ldg + 16 * hb, gnext);
+
+    // (a run-time loop: every hidden tile uses ring buffers 0..3 in order, and the body is ~100 MFMAs -- unrolled 16 times the kernel was
+    // 14,000 instructions, far beyond the instruction cache)
+    for (int t = 0; t < PT; t++) {
+      // ---- first GEMM, hidden tile t: the whole strip against two slots ----
+      f32x16 hacc;
+      {
+        float b[16];
+        lds16f(prm_b + t * 32 + 16 * hb, b);
+#pragma unroll
+        for (int q = 0; q < 16; q++) hacc[q] = b[q];
+      }
+      float gcur[16];
+      if (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) gcur[q] = gnext[q];
+      }
+      P.begin_slot();
+      if (!(g.pad & 256))
+      x3_slot_chunks<E, 0>(abase + 0 * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<0>();
+        if (i == 6 && MODE == 1 && t + 1 < PT) load16f(gtb + tokc * g.ldg + (t + 1) * 32 + 16 * hb, gnext);
+      });
+      P.begin_slot();
+      if (!(g.pad & 256))
+      x3_slot_chunks<E, 8>(abase + 1 * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<1>();
+      });
+      // ---- middle epilogue: the lane's 16 hidden features of tile t become the B operand of the second GEMM ----
+      float v[16];
+      const int hcol0 = t * 32 + 16 * hb;
+      if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = fmaxf(hacc[q], 0.f);
+        if (g.drop_p > 0.f && !(g.pad & 128)) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 2), thr, inv_keep);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = gcur[q] > 0.f ? hacc[q] * g.gate_scale : 0.f;
+      }
+      XChunk hf[2];
+      {
+        bf16x8 hi, lo;
+        x3_split8<E>(v, hi, lo);
+        hf[0].a = __builtin_bit_cast(u4v, hi); hf[0].b = __builtin_bit_cast(u4v, lo);
+        x3_split8<E>(v + 8, hi, lo);
+        hf[1].a = __builtin_bit_cast(u4v, hi); hf[1].b = __builtin_bit_cast(u4v, lo);
+      }
+      const bool st_h = hob != nullptr && wave_ok && !(g.pad & 16);
+      float* hp = hob + tok * g.ldh + hcol0;
+      // ---- second GEMM, K-slice t (u = 0, 1); the hidden tile's stores ride behind the first MFMAs ----
+      P.begin_slot();
+      if (!(g.pad & 512))
+      x3_slot_tiles<E>(abase + 2 * SLOT_BYTES, hf[0], yacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<2>();
+        if (i == 4 && st_h) { reinterpret_cast<float4*>(hp)[0] = make_float4(v[0], v[1], v[2], v[3]); reinterpret_cast<float4*>(hp)[1] = make_float4(v[4], v[5], v[6], v[7]); }
+        if (i == 8 && st_h) { reinterpret_cast<float4*>(hp)[2] = make_float4(v[8], v[9], v[10], v[11]); reinterpret_cast<float4*>(hp)[3] = make_float4(v[12], v[13], v[14], v[15]); }
+      });
+      P.begin_slot();
+      if (!(g.pad & 512))
+      x3_slot_tiles<E>(abase + 3 * SLOT_BYTES, hf[1], yacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<3>();
+      });
+    }
+
+    // ---------------- final epilogue of the block ----------------
+    const uint64_t rowq = ((uint64_t)tok * 256ull) >> 2;
+    float* yrow = yb + tok * g.ldy + 16 * hb;
+    const float* rrow_p = rb + (has_res ? tokc * g.ldr + 16 * hb : 0);
+#pragma unroll
+    for (int ot = 0; ot < 8; ot++) {
+      const int col0 = ot * 32 + 16 * hb;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) v[q] = yacc[ot][q];
+      if (MODE == 0 && g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_o, rowq + (col0 >> 2), thr, inv_keep);
+      if (MODE == 0) {                                // residual = the block input, still in the strip registers (hi + lo)
+        float r[16];
+        chunk_values<E>(xr[2 * ot], r); chunk_values<E>(xr[2 * ot + 1], r + 8);
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] += r[q];
+      } else if (has_res) {
+        float r[16];
+        load16f(rrow_p + ot * 32, r);
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] += r[q];
+      }
+      // these two chunks have fed their last use of the block: their registers take the next block's values
+      chunk_load(xr[2 * ot], xrow_next + chunk_off(2 * ot));
+      chunk_load(xr[2 * ot + 1], xrow_next + chunk_off(2 * ot + 1));
+      if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) yacc[ot][q] = v[q];
+      } else if (wave_ok) {
+        store16f(yrow + ot * 32, v);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 0) {
+      x3_ln_rows(yacc, prm_b + p + 256, prm_b + p + 512, hb, g.ln_mean, g.ln_rstd, tok, wave_ok,
+                 preb != nullptr ? preb + tok * g.ldy + 16 * hb : nullptr, yrow);
+    }
+  }
+  P.drain();
+}
+
+int n_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    n = prop.multiProcessorCount;
+  }
+  return n;
+}
+template <typename K>
+int set_lds(K kernel, int lds, const char* what) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) { hftt_set_error("%s: hipFuncSetAttribute(%d B LDS) failed: %s", what, lds, hipGetErrorString(e)); return 2; }
+  return 0;
+}
+template <int E, bool LN, int PASSES, int KCH, bool HR>
+int launch_xl(const hftt_strip_desc& d, hipStream_t st) {
+  const int lds = RING_BYTES + 4 * (d.N + 512);
+  static int attr = 0;
+  if (lds > attr) { if (int rc = set_lds(x3_linear_kernel<E, LN, PASSES, KCH, HR>, lds, "x3_strip_linear")) return rc; attr = lds; }
+  const int cus = n_cus();
+  if (cus <= 0) { hftt_set_error("x3_strip_linear: device query failed"); return 2; }
+  const long nblk = ((long)d.M + 127) / 128;
+  hipLaunchKernelGGL((x3_linear_kernel<E, LN, PASSES, KCH, HR>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  HFTT_CHECK_LAUNCH("x3_strip_linear");
+  return 0;
+}
+template <int E, int NT, bool HR>
+int launch_xn(const hftt_strip_desc& d, hipStream_t st) {
+  const int lds = RING_BYTES + 4 * d.N + 4 * STG_BYTES_PER_WAVE;
+  static int attr = 0;
+  if (lds > attr) { if (int rc = set_lds(x3_linear_n_kernel<E, NT, HR>, lds, "x3_strip_linear")) return rc; attr = lds; }
+  const int cus = n_cus();
+  if (cus <= 0) { hftt_set_error("x3_strip_linear: device query failed"); return 2; }
+  const long nblk = ((long)d.M + 127) / 128;
+  hipLaunchKernelGGL((x3_linear_n_kernel<E, NT, HR>), dim3((unsigned)(nblk < 2 * cus ? nblk : 2 * cus)), dim3(256), lds, st, d);
+  HFTT_CHECK_LAUNCH("x3_strip_linear");
+  return 0;
+}
+template <int MODE>
+int launch_xm(const hftt_ffn_desc& d, hipStream_t st) {
+  const int lds = RING_BYTES + 4 * (d.p + 768);
+  static int attr = 0;
+  if (lds > attr) { if (int rc = set_lds(x3_mlp_kernel<MODE, 16>, lds, "x3_strip_mlp")) return rc; attr = lds; }
+  const int cus = n_cus();
+  if (cus <= 0) { hftt_set_error("x3_strip_mlp: device query failed"); return 2; }
+  const long nblk = ((long)d.M + 127) / 128;
+  hipLaunchKernelGGL((x3_mlp_kernel<MODE, 16>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  HFTT_CHECK_LAUNCH("x3_strip_mlp");
+  return 0;
+}
+
+template <int E>
+int dispatch_xl(const hftt_strip_desc& d, hipStream_t st) {
+  const int passes = d.N / 256, kch = d.K / 256;
+  const bool hr = d.residual != nullptr;
+#define HFTT_XL(LN_, P_, K_) return hr ? launch_xl<E, LN_, P_, K_, true>(d, st) : launch_xl<E, LN_, P_, K_, false>(d, st)
+  if (d.ln_gamma != nullptr) {
+    if (kch == 1) HFTT_XL(true, 1, 1);
+    if (kch == 2) HFTT_XL(true, 1, 2);
+    hftt_set_error("x3_strip_linear: the LayerNorm form covers K = 256 / 512 (got %d)", d.K);
+    return 1;
+  }
+  // K == 256 without LayerNorm: the output-tile-major kernel (tile-major pack, two workgroups per CU)
+  if (kch == 1 && passes == 1) return hr ? launch_xn<E, 8, true>(d, st) : launch_xn<E, 8, false>(d, st);
+  if (kch == 1 && passes == 2) return hr ? launch_xn<E, 16, true>(d, st) : launch_xn<E, 16, false>(d, st);
+  if (kch == 1 && passes == 3) return hr ? launch_xn<E, 24, true>(d, st) : launch_xn<E, 24, false>(d, st);
+  if (kch == 2 && passes == 1) HFTT_XL(false, 1, 2);
+  if (kch == 3 && passes == 1) HFTT_XL(false, 1, 3);
+#undef HFTT_XL
+  hftt_set_error("x3_strip_linear: shape N=%d K=%d is not covered (N/256 x K/256 in {1x1, 2x1, 3x1, 1x2, 1x3})", d.N, d.K);
+  return 1;
+}
+
+}  // namespace
+
+// HFTT_X3_DEBUG (timing experiments, results garbage): 1 no ring fills, 2 no slot waits / barriers, 16 no result stores, 32 no strip reloads,
+// 64 no strip conversion; fused block: 128 no hidden dropout, 256 no first-GEMM MFMAs, 512 no second-GEMM MFMAs
+static int x3_debug() { static const int v = [] { const char* e = getenv("HFTT_X3_DEBUG"); return e ? atoi(e) : 0; }(); return v; }
+
+int hftt_x3_strip_linear(const hftt_strip_desc& d0, hipStream_t st) {
+  hftt_strip_desc d = d0;
+  d.pad = x3_debug();
+  HFTT_REQUIRE(d.K % 256 == 0 && d.N % 256 == 0 && d.M % 32 == 0, "x3_strip_linear: needs K %% 256 == 0, N %% 256 == 0, M %% 32 == 0 (M=%d N=%d K=%d)", d.M, d.N, d.K);
+  HFTT_REQUIRE(d.gate == nullptr, "x3_strip_linear: no gate form (the fused block hftt_ffn_bwd_dx carries the gate)");
+  HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_linear: tensors are fp32 in the split modes");
+  HFTT_REQUIRE(d.ldx % 4 == 0 && d.ldc % 4 == 0 && (d.residual == nullptr || d.ldr % 4 == 0), "x3_strip_linear: rows must be 16-byte aligned");
+  return (d.flags & HFTT_SL_X3_BF16) ? dispatch_xl<X3_BF16>(d, st) : dispatch_xl<X3_F16>(d, st);
+}
+
+int hftt_x3_strip_mlp(const hftt_ffn_desc& d0, hipStream_t st) {
+  hftt_ffn_desc d = d0;
+  d.pad = x3_debug();
+  HFTT_REQUIRE(d.p == 512 && d.M % 32 == 0, "x3_strip_mlp: needs p == 512 and M %% 32 == 0 (M=%d p=%d)", d.M, d.p);
+  HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_mlp: tensors are fp32 in the split modes");
+  HFTT_REQUIRE(d.mode == 1 || d.residual == nullptr, "x3_strip_mlp: the forward block's residual is its input");
+  HFTT_REQUIRE(((d.flags & HFTT_SL_X3_BF16) != 0) == (d.mode == 1), "x3_strip_mlp: mode 0 takes fp16 halves (HFTT_SL_X3_F16), mode 1 bf16 halves");
+  return d.mode == 0 ? launch_xm<0>(d, st) : launch_xm<1>(d, st);
+}
+
+extern "C" int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_pack_entry* table_dev, int n_entries, int elem, void* stream) {
+  HFTT_REQUIRE(params != nullptr && wstrip != nullptr && table_dev != nullptr && n_entries > 0, "x3_strip_pack: null argument");
+  HFTT_REQUIRE(((uintptr_t)wstrip & 15) == 0 && ((uintptr_t)params & 15) == 0, "x3_strip_pack: buffers must be 16-byte aligned");
+  HFTT_REQUIRE(elem == X3_F16 || elem == X3_BF16, "x3_strip_pack: elem must be 2 (fp16 halves) or 4 (bf16 halves)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (elem == X3_F16) hipLaunchKernelGGL(x3_strip_pack_kernel<X3_F16>, dim3(32, (unsigned)n_entries), dim3(256), 0, st, params, wstrip, table_dev);
+  else hipLaunchKernelGGL(x3_strip_pack_kernel<X3_BF16>, dim3(32, (unsigned)n_entries), dim3(256), 0, st, params, wstrip, table_dev);
+  HFTT_CHECK_LAUNCH("x3_strip_pack");
+  return 0;
+}

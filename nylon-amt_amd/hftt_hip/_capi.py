@@ -114,6 +114,7 @@ class FfnDesc(C.Structure):
 
 
 SL_X_BF16, SL_C_BF16, SL_RES_BF16, SL_RELU = 1, 2, 4, 8
+SL_X3_F16, SL_X3_BF16 = 16, 32               # split-operand forms of the strip kernels (fp32 tensors; fp16 / bf16 hi + lo halves)
 TE_X_BF16, TE_Y_BF16, TE_M_BF16 = 1, 2, 4          # hftt_time_embed_fwd / _bwd io_flags
 
 
@@ -144,6 +145,7 @@ SIGNATURES = {
     'hftt_prep_weights_x3': (C.c_int, [c_f32p, c_u16p, c_u16p, c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
     'hftt_gemm_nt': (C.c_int, [C.POINTER(GemmNtDesc), C.c_void_p]),
     'hftt_strip_pack': (C.c_int, [c_f32p, c_u16p, C.c_void_p, C.c_int, C.c_void_p]),
+    'hftt_x3_strip_pack': (C.c_int, [c_f32p, c_u16p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'hftt_strip_linear': (C.c_int, [C.POINTER(StripDesc), C.c_void_p]),
     'hftt_ffn_res_ln_fwd': (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
     'hftt_ffn_bwd_dx': (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),

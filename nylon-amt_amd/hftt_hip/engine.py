@@ -23,7 +23,7 @@ import torch
 
 from . import _capi
 from ._capi import (AttnDesc, FfnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, check, lib)
+                    SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
 
 # precision -> the descriptors' `npass` code (include/hftt_hip.h): 'x3' = split fp16 on forward products (2) and split bf16 on products with a
 # gradient operand (4): three bf16-rate MFMA passes per product, fp32 tensors in HBM, outputs within 1e-3 of the reference (measured 1e-4)
@@ -115,7 +115,10 @@ class HfttEngine:
         self.sb = (self.npass == 1) and getattr(self, 'store_bf16_opt', True)
         # strip kernels (csrc/strip_gemm.hip): bf16 mode at the paper's width.  Then the WHOLE activation stream between kernels is
         # bf16 (residual stream, pre-LayerNorm sums, hidden), fp32 lives only inside a kernel (accumulators, LayerNorm statistics).
-        self.strip = self.sb and getattr(self, 'strip_opt', True) and self.d == 256 and self.p % 64 == 0
+        self.strip = getattr(self, 'strip_opt', True) and self.d == 256 and ((self.sb and self.p % 64 == 0) or (self.npass == 2 and self.p == 512))
+        # bfs: the bf16 activation / gradient STREAM of the bf16 strip plans.  The x3 strip plans run the same launch sequence on fp32 tensors.
+        self.bfs = self.strip and self.sb
+        self.x3 = self.npass == 2
         self._prepared_frozen = False
         if getattr(self, '_bound', None) is not None:
             self._build_prep()
@@ -234,28 +237,37 @@ class HfttEngine:
         sl = _Flat()
         sentries = []
 
+        x3 = self.npass == 2
+        sentries_t = []                              # x3: the transposed (backward) matrices are packed as bf16 halves, the others as fp16 halves
+
         def spack(key, parts, Ktot, transpose=False, order=0, stride=1, offset=0, base=None, numel=None):
-            """parts: (parameter name, n0, k0) blocks of the logical [N, Ktot] matrix; returns the stream's element offset."""
+            """parts: (parameter name, n0, k0) blocks of the logical [N, Ktot] matrix; returns the stream's element offset.
+            x3: every fragment is a (hi, lo) pair -- twice the elements; slots come in pairs (stream position = offset + stride * (slot >> 1) +
+            (slot & 1)), so a plain stream has stride 2 and the fused block's two matrices stride 4 with offsets 0 / 2."""
+            if x3:
+                numel = None if numel is None else 2 * numel
+                stride, offset = 2 * stride, 2 * offset
             if base is None:
                 base = sl.add(key, numel, 512)
                 W['s.' + key] = base
             for name, n0, k0 in parts:
                 rows, cols = self.pshape[name]
-                sentries.append((self.poff[name], base, rows, cols, cols, 1 if transpose else 0, n0, k0, Ktot, order, stride, offset))
+                (sentries_t if (x3 and transpose) else sentries).append((self.poff[name], base, rows, cols, cols, 1 if transpose else 0, n0, k0, Ktot, order, stride, offset))
             return base
 
         def strip_attn(pre, key, cross):
             wq, wk, wv, wo = (pre + n + '.weight' for n in ('fc_q', 'fc_k', 'fc_v', 'fc_o'))
+            tm = 1 if x3 else 0                       # x3: the K == 256 linears without LayerNorm take the tile-major pack (csrc/x3_strip.hip)
             if cross:
-                spack(key + '.q', [(wq, 0, 0)], d, numel=d * d)
-                spack(key + '.kv', [(wk, 0, 0), (wv, d, 0)], d, numel=2 * d * d)
-                spack(key + '.q_t', [(wq, 0, 0)], d, transpose=True, numel=d * d)
+                spack(key + '.q', [(wq, 0, 0)], d, order=tm, numel=d * d)
+                spack(key + '.kv', [(wk, 0, 0), (wv, d, 0)], d, order=tm, numel=2 * d * d)
+                spack(key + '.q_t', [(wq, 0, 0)], d, transpose=True, order=tm, numel=d * d)
                 spack(key + '.kv_t', [(wk, 0, 0), (wv, 0, d)], 2 * d, transpose=True, numel=2 * d * d)
             else:
-                spack(key + '.qkv', [(wq, 0, 0), (wk, d, 0), (wv, 2 * d, 0)], d, numel=3 * d * d)
+                spack(key + '.qkv', [(wq, 0, 0), (wk, d, 0), (wv, 2 * d, 0)], d, order=tm, numel=3 * d * d)
                 spack(key + '.qkv_t', [(wq, 0, 0), (wk, 0, d), (wv, 0, 2 * d)], 3 * d, transpose=True, numel=3 * d * d)
             spack(key + '.o', [(wo, 0, 0)], d, numel=d * d)
-            spack(key + '.o_t', [(wo, 0, 0)], d, transpose=True, numel=d * d)
+            spack(key + '.o_t', [(wo, 0, 0)], d, transpose=True, order=tm, numel=d * d)
 
         def strip_ffn(pre, key):
             w1, w2 = pre + 'fc_1.weight', pre + 'fc_2.weight'          # [p, d], [d, p]
@@ -290,7 +302,7 @@ class HfttEngine:
                     strip_attn(pre + 'encoder_attention.', key + '.ca', True)
                 strip_ffn(pre + 'positionwise_feedforward.', key)
         heads('time', 'heads_t')
-        if self.strip:                               # bf16 copy of the note position table: the (broadcast) residual of decoder layer zero
+        if self.bfs:                                 # bf16 copy of the note position table: the (broadcast) residual of decoder layer zero
             off = wl.add('dec_pos_bf', self.N * d, 64)
             W['dec_pos_bf'] = off
             entries.append((self.poff['decoder_spec2midi.pos_embedding_freq.weight'], off, self.N, d, d, d, 0))
@@ -309,11 +321,14 @@ class HfttEngine:
         self._wl_regions = sorted((off, name) for name, off in wl.items.items())      # matrix planes by element offset
         self._wp_used, self._prep_built_for = set(), -1
         self._set_prep_table(entries)
-        self.n_spack = len(sentries)
+        self.n_spack, self.n_spack_t = len(sentries), len(sentries_t)
         if sentries:
             self.wstrip = torch.zeros(_align(sl.off, 512), dtype=torch.int16, device=self.device)
             arr2 = (StripPackEntry * len(sentries))(*[StripPackEntry(*e) for e in sentries])
             self.spack_table = torch.frombuffer(bytearray(bytes(arr2)), dtype=torch.uint8).to(self.device)
+        if sentries_t:
+            arr3 = (StripPackEntry * len(sentries_t))(*[StripPackEntry(*e) for e in sentries_t])
+            self.spack_table_t = torch.frombuffer(bytearray(bytes(arr3)), dtype=torch.uint8).to(self.device)
         # embed-fold scratch (dWeff, dbeff)
         self.dweff = torch.zeros(self.d * self.Kp, dtype=torch.float32, device=self.device)
         self.dbeff = torch.zeros(self.d, dtype=torch.float32, device=self.device)
@@ -389,7 +404,11 @@ class HfttEngine:
                                              self.fprep.data_ptr(), self.prep_table.data_ptr(), self.n_prep, stream), 'prep_weights')
         check(self.lib.hftt_embed_fold_fwd(C.byref(self.fold), stream), 'embed_fold_fwd')
         if self.strip and self.n_spack:
-            check(self.lib.hftt_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, stream), 'strip_pack')
+            if self.x3:
+                check(self.lib.hftt_x3_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, 2, stream), 'x3_strip_pack')
+                check(self.lib.hftt_x3_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table_t.data_ptr(), self.n_spack_t, 4, stream), 'x3_strip_pack')
+            else:
+                check(self.lib.hftt_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, stream), 'strip_pack')
         self._prepared_frozen = self.frozen_weights
 
     # ------------------------------------------------------------------ plan building helpers
@@ -412,7 +431,7 @@ class HfttEngine:
 
     def _abuf(self, ws, name, *shape):
         """activation-stream tensor: bf16 when the strip kernels run (bf16 residual stream), fp32 otherwise"""
-        return self._buf(ws, name, *shape, dtype=torch.bfloat16 if self.strip else torch.float32)
+        return self._buf(ws, name, *shape, dtype=torch.bfloat16 if self.bfs else torch.float32)
 
     def _nt(self, plan, ws, M, N, K, A, lda, W, bias, Cp, ldc, act=0, out_scale=1.0, add_table=0, add_mod=0,
             gate=0, ldg=0, gate_scale=1.0, drop_site=0, residual=0, ldr=0, res_mod=0, ln=None, a_bf=False, c_bf=False, gate_bf=False, res_bf=False):
@@ -474,7 +493,11 @@ class HfttEngine:
         """hftt_strip_linear plan entry (bf16 mode, N % 256 == 0): C = epi(x . Wl^T + bias), Wl = strip pack `wkey`."""
         dsc = StripDesc()
         dsc.M, dsc.N, dsc.K = M, N, K
-        dsc.flags = (SL_X_BF16 if x_bf else 0) | (SL_C_BF16 if c_bf else 0) | (SL_RES_BF16 if (residual and res_bf) else 0) | (SL_RELU if relu else 0)
+        if self.x3:                                  # fp32 tensors, fp16 halves on forward products, bf16 halves where a gradient is an operand
+            x_bf = c_bf = res_bf = False
+            dsc.flags = (SL_X3_BF16 if self._in_backward else SL_X3_F16) | (SL_RELU if relu else 0)
+        else:
+            dsc.flags = (SL_X_BF16 if x_bf else 0) | (SL_C_BF16 if c_bf else 0) | (SL_RES_BF16 if (residual and res_bf) else 0) | (SL_RELU if relu else 0)
         dsc.x, dsc.ldx, dsc.w, dsc.bias = x, ldx, self.Ws(wkey), bias
         dsc.C, dsc.ldc, dsc.out_scale = Cp, ldc, out_scale
         if isinstance(gate_scale, tuple):
@@ -491,7 +514,7 @@ class HfttEngine:
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
         tf = lambda v: 'true' if v else 'false'
-        nbytes = (2 if x_bf else 4) * M * K + (2 if c_bf else 4) * M * N * (2 if pre_saved else 1) + 2 * N * K \
+        nbytes = (2 if x_bf else 4) * M * K + (2 if c_bf else 4) * M * N * (2 if pre_saved else 1) + (4 if self.x3 else 2) * N * K \
             + ((2 if res_bf else 4) * M * N if residual else 0) + (2 * M * N if gate else 0)
         # kernel symbol as rocprofv3 prints it (the C side picks the pipelined form by the rule mirrored here: strip_gemm2.hip hftt_strip_linear2_try)
         passes, kch = N // 256, K // 256
@@ -499,6 +522,10 @@ class HfttEngine:
               and ((ln is not None and kch <= 3) or (ln is None and (kch, passes) in ((1, 1), (1, 2), (1, 3), (2, 1), (3, 1)))))
         kname = ('strip_linear2_kernel<%s, %d, %d, %s>' % (tf(ln is not None), 1 if ln is not None else passes, kch, tf(bool(residual)))) if v2 \
             else 'strip_linear_kernel<%s, %s, %s>' % (tf(x_bf), tf(c_bf), tf(ln is not None))
+        if self.x3:
+            kname = 'x3_linear_kernel<%d, %s, %d, %d, %s>' % (4 if self._in_backward else 2, tf(ln is not None), passes, kch, tf(bool(residual)))
+            if ln is None and kch == 1:
+                kname = 'x3_linear_n_kernel<%d, %d, %s>' % (4 if self._in_backward else 2, N // 32, tf(bool(residual)))
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_strip_linear, (C.byref(dsc),), 'strip_linear', meta))
         return dsc
@@ -508,7 +535,7 @@ class HfttEngine:
         d, p = self.d, self.p
         dsc = FfnDesc()
         dsc.M, dsc.d, dsc.p, dsc.mode = M, d, p, mode
-        dsc.flags = SL_X_BF16 | SL_C_BF16 | SL_RES_BF16
+        dsc.flags = (SL_X3_F16 if mode == 0 else SL_X3_BF16) if self.x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)
         dsc.x, dsc.ldx, dsc.w = x, d, self.Ws(wkey)
         dsc.b1, dsc.b2 = b1, b2
         dsc.h_out, dsc.ldh = h_out, p
@@ -527,9 +554,10 @@ class HfttEngine:
         if mode == 0 and (site_h or site_o):
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
-        nbytes = 2.0 * M * d * (2 + (1 if pre_saved else 0) + (1 if residual else 0)) + (2.0 * M * p if h_out else 0) + (2.0 * M * p if gate else 0) + 4.0 * d * p
+        esz = 4.0 if self.x3 else 2.0
+        nbytes = esz * M * d * (2 + (1 if pre_saved else 0) + (1 if residual else 0)) + (esz * M * p if h_out else 0) + (esz * M * p if gate else 0) + 2 * esz * d * p
         v2 = os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and p == 512 and M % 32 == 0 and not (mode == 0 and residual)
-        meta = {'kernel': ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>') % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
+        meta = {'kernel': ('x3_mlp_kernel<%d, 16>' if self.x3 else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>')) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
                 'shape': (M, d, p), 'saves': bool(h_out or pre_saved)}
         plan.append((self.lib.hftt_ffn_res_ln_fwd if mode == 0 else self.lib.hftt_ffn_bwd_dx, (C.byref(dsc),), 'ffn_fwd' if mode == 0 else 'ffn_bwd_dx', meta))
         return dsc
@@ -602,7 +630,7 @@ class HfttEngine:
         return dsc
 
     def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta, drop_bf=True, dy_bf=False, dr_bf=False):
-        r_bf = self.strip                           # the strip forward kernels save the pre-LayerNorm sum as bf16
+        r_bf = self.bfs                             # the bf16 strip forward kernels save the pre-LayerNorm sum as bf16
         n_wg = self.lib.hftt_ln_bwd_wgs(M)
         ws['ln_need'] = max(ws.get('ln_need', 0), n_wg * 2 * self.d * 4)
         dsc = LnBwdDesc()
@@ -715,7 +743,8 @@ class HfttEngine:
         Se, Sn, BT, BN = B * T * F, B * T * N, B * T, B * N
         plan = []
         ws['sites'] = {}
-        st = self.strip
+        st = self.strip                              # strip kernels (bf16 or x3)
+        bs = self.bfs                                # ... on a bf16 activation stream
         spec = self._buf(ws, 'spec', B, F, self.W)
         win = self._buf(ws, 'win', Se, self.Kp)
         x0 = self._abuf(ws, 'x0', Se, d)
@@ -724,7 +753,7 @@ class HfttEngine:
         s_emb = self._new_site()
         ws['sites']['embed'] = s_emb
         self._nt(plan, ws, Se, d, self.Kp, win.data_ptr(), self.Kp, self.Wp('embed'), self.Fp('embed_b'), x0.data_ptr(), d,
-                 out_scale=math.sqrt(d), add_table=self.P(e + 'pos_embedding_freq.weight'), add_mod=F, drop_site=s_emb, c_bf=st)
+                 out_scale=math.sqrt(d), add_table=self.P(e + 'pos_embedding_freq.weight'), add_mod=F, drop_site=s_emb, c_bf=bs)
         x = x0.data_ptr()
         ws['enc_in'] = [x]
         for i in range(self.Le):
@@ -776,7 +805,7 @@ class HfttEngine:
             else:
                 self._nt(plan, ws, N, d, d, pos_dec, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), q0.data_ptr(), d, c_bf=True)
                 qaddr, qss = q0.data_ptr(), 0
-                res, res_mod = (self.wbf.data_ptr() + 2 * self.Woff['dec_pos_bf'] if st else pos_dec), N
+                res, res_mod = (self.wbf.data_ptr() + 2 * self.Woff['dec_pos_bf'] if bs else pos_dec), N
             ckv = self._buf(ws, tag + '.ckv', Se, 2 * d, half=True)
             cctx = self._buf(ws, tag + '.cctx', Sn, d, half=True)
             clse = self._buf(ws, tag + '.clse', BT * H * N * 2)
@@ -803,20 +832,20 @@ class HfttEngine:
             ws['dec_out'].append(trg)
         # ---------------- heads A ----------------
         logits_f = self._buf(ws, 'logits_f', Sn, self.NHp)
-        self._nt(plan, ws, Sn, self.NH, d, trg, d, self.Wp('heads_f'), self.Fp('heads_f_b'), logits_f.data_ptr(), self.NHp, a_bf=st)
+        self._nt(plan, ws, Sn, self.NH, d, trg, d, self.Wp('heads_f'), self.Fp('heads_f_b'), logits_f.data_ptr(), self.NHp, a_bf=bs)
         plan.append(('heads', (logits_f.data_ptr(), 0), 'heads_split', None))
         # ---------------- decoder, time axis ----------------
         y0 = self._abuf(ws, 'y0', Sn, d)
         s_t = self._new_site()
         ws['sites']['time_embed'] = s_t
-        plan.append(('time_embed', (trg, self.P(dd + 'pos_embedding_time.weight'), y0.data_ptr(), s_t, 3 if st else 0), 'time_embed_fwd', None))
+        plan.append(('time_embed', (trg, self.P(dd + 'pos_embedding_time.weight'), y0.data_ptr(), s_t, 3 if bs else 0), 'time_embed_fwd', None))
         y = y0.data_ptr()
         ws['time_in'] = [y]
         for i in range(self.Ld):
             y = self._enc_layer_fwd(plan, ws, f'time{i}', f'time{i}', f'{dd}layers_time.{i}.', Sn, BN, T, H, y, save=save)
             ws['time_in'].append(y)
         logits_t = self._buf(ws, 'logits_t', Sn, self.NHp)
-        self._nt(plan, ws, Sn, self.NH, d, y, d, self.Wp('heads_t'), self.Fp('heads_t_b'), logits_t.data_ptr(), self.NHp, a_bf=st)
+        self._nt(plan, ws, Sn, self.NH, d, y, d, self.Wp('heads_t'), self.Fp('heads_t_b'), logits_t.data_ptr(), self.NHp, a_bf=bs)
         plan.append(('heads', (logits_t.data_ptr(), 1), 'heads_split', None))
         ws['fwd' if save else 'fwd_inf'] = plan
         ws['enc'] = enc
@@ -890,9 +919,10 @@ class HfttEngine:
         self._tn(plan, ws, S, d, d, dbr, d, b[tag + '.ctx'].data_ptr(), d, [(0, d, self.G(pa + 'fc_o.weight'), self.G(pa + 'fc_o.bias'))], dy_bf=True, x_bf=True)
         self._sl(plan, ws, S, d, d, dbr, d, key + '.sa.o_t', 0, Gx, d)
         qkv = b[tag + '.qkv'].data_ptr()
-        self._attn(plan, ws, True, n_seq, H, L, L, qkv, L * 3 * d, 3 * d, qkv + 2 * d, L * 3 * d, 3 * d, qkv + 4 * d, L * 3 * d, 3 * d,
+        hz = 2 if self.sb else 4
+        self._attn(plan, ws, True, n_seq, H, L, L, qkv, L * 3 * d, 3 * d, qkv + hz * d, L * 3 * d, 3 * d, qkv + 2 * hz * d, L * 3 * d, 3 * d,
                    b[tag + '.ctx'].data_ptr(), L * d, d, b[tag + '.lse'].data_ptr(), drop_site=sa, dout=Gx,
-                   dq=Gq, dqss=L * 3 * d, lddq=3 * d, dk=Gq + 2 * d, dkss=L * 3 * d, lddk=3 * d, dv=Gq + 4 * d, dvss=L * 3 * d, lddv=3 * d,
+                   dq=Gq, dqss=L * 3 * d, lddq=3 * d, dk=Gq + hz * d, dkss=L * 3 * d, lddk=3 * d, dv=Gq + 2 * hz * d, dvss=L * 3 * d, lddv=3 * d,
                    flags=1 | 2 | 4 | 8 | 16)
         self._tn(plan, ws, S, 3 * d, d, Gq, 3 * d, x_in, d,
                  [(0, d, self.G(pa + 'fc_q.weight'), self.G(pa + 'fc_q.bias')), (d, d, self.G(pa + 'fc_k.weight'), self.G(pa + 'fc_k.bias')),
@@ -942,16 +972,17 @@ class HfttEngine:
         # (K=512: 253 -> 284 us, K=768: 324 -> 366 us) -- net zero, so it is OFF by default (HFTT_BF16_GRAD=1 enables) until the
         # row pass handles 8 columns per lane for bf16 residual / C.
         # (needs the A-stationary GEMM on every encoder dX: d % 256 == 0, K = ff and 3d <= 768, >= 256 bin tokens)
-        st = self.strip                              # strip mode: the whole gradient stream is bf16
+        st = self.strip                              # strip kernels; bs: on the bf16 stream (then the whole gradient stream is bf16)
+        bs = self.bfs
         egb = (not st and self.sb and os.environ.get('HFTT_BF16_GRAD', '0') == '1' and d % 256 == 0 and max(p, 3 * d) <= 768 and Se >= 256)
-        ws['bf16_grad'] = bool(egb or st)
+        ws['bf16_grad'] = bool(egb or bs)
         # gradient scratch: note-token sized and bin-token sized sets
         nGA = self._abuf(ws, 'g.nA', Sn, d).data_ptr(); nGB = self._abuf(ws, 'g.nB', Sn, d).data_ptr()
         hz = 2 if self.sb else 4
         nGC = self._buf(ws, 'g.nC', Sn, d, half=True).data_ptr(); nGD = self._abuf(ws, 'g.nD', Sn, d).data_ptr()
         nGh = self._buf(ws, 'g.nh', Sn, p, half=True).data_ptr(); nGq = self._buf(ws, 'g.nq', Sn, 3 * d, half=True).data_ptr()
         nGx = self._buf(ws, 'g.nx', Sn, d, half=True).data_ptr()
-        q1f = self._buf(ws, 'g.q1f', Sn, d).data_ptr() if st else 0          # layer zero's per-sequence dq stays fp32 (summed over sequences)
+        q1f = self._buf(ws, 'g.q1f', Sn, d).data_ptr() if bs else 0          # layer zero's per-sequence dq stays fp32 (summed over sequences)
         eGA = self._abuf(ws, 'g.eA', Se, d).data_ptr(); eGB = self._abuf(ws, 'g.eB', Se, d).data_ptr()
         eGC = self._buf(ws, 'g.eC', Se, d, half=True).data_ptr()
         eGh = self._buf(ws, 'g.eh', Se, p, half=True).data_ptr(); eGq = self._buf(ws, 'g.eq', Se, 3 * d, half=True).data_ptr()
@@ -975,7 +1006,7 @@ class HfttEngine:
         plan.append(('heads_bwd', ('B', dlog, 1), 'heads_split_bwd', None))
         y_last = ws['time_in'][-1]
         self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, y_last, d, head_segs('time'), x_bf=self.strip)
-        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_t_t'), 0, nGA, d, c_bf=st)
+        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_t_t'), 0, nGA, d, c_bf=bs)
         Gn = (nGA, nGB, nGC, nGh, nGq, nGx)
         for i in reversed(range(self.Ld)):
             if st:
@@ -986,9 +1017,9 @@ class HfttEngine:
         plan.append(('heads_bwd', ('A', dlog, 0), 'heads_split_bwd', None))
         f_last = ws['dec_out'][-1]
         self._tn(plan, ws, Sn, self.NHp, d, dlog, self.NHp, f_last, d, head_segs('freq'), x_bf=self.strip)
-        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_f_t'), 0, nGD, d, c_bf=st)
-        plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed'], 7 if st else 0), 'time_embed_bwd', None))
-        plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws, 1 if st else 0), 'colsum', None))
+        self._nt(plan, ws, Sn, d, self.NHp, dlog, self.NHp, self.Wp('heads_f_t'), 0, nGD, d, c_bf=bs)
+        plan.append(('time_embed_bwd', (nGA, nGD, nGB if use_drop else 0, ws['sites']['time_embed'], 7 if bs else 0), 'time_embed_bwd', None))
+        plan.append(('colsum', (nGB if use_drop else nGA, BN, T * d, T * d, self.G(dd + 'pos_embedding_time.weight'), 0.0, cs_ws, 1 if bs else 0), 'colsum', None))
         # gradient buckets in the order they become final (flat ranges are contiguous: state_dict order is encoder,
         # frequency decoder + heads A, time decoder + heads B): (plan length when final, flat lo, flat hi)
         o_dec, o_time, o_end = self.poff[dd + 'pos_embedding_freq.weight'], self.poff[dd + 'pos_embedding_time.weight'], self.flat_grads.numel()
@@ -997,7 +1028,7 @@ class HfttEngine:
         #      the encoder-output gradient accumulates in eGA ----
         A, Bf, Cf, Q1 = nGD, nGB, nGC, nGA
         Gd = (A, Bf, Cf, nGh, nGq, nGx)
-        dbr, dbr_bf = (Cf, True) if use_drop else (Bf, st)
+        dbr, dbr_bf = (Cf, True) if use_drop else (Bf, bs)
         first_enc_grad = True
         enc = ws['enc']
         for j in reversed(range(self.Ld)):
@@ -1025,7 +1056,7 @@ class HfttEngine:
             # dq (per sequence) -> Q1 ; dk,dv -> eGq viewed as [Se, 2d]
             # per-sequence dq stays fp32 (layer zero sums it over sequences with the fp32 colsum); dk, dv are "half" tensors
             # strip mode: dq of the layers with their own query projection is a GEMM operand only -> bf16; layer zero keeps fp32 (q1f)
-            dq_buf = Q1 if not st else (Q1 if j > 0 else q1f)
+            dq_buf = Q1 if not bs else (Q1 if j > 0 else q1f)
             self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
                        b[tag + '.cctx'].data_ptr(), N * d, d, b[tag + '.clse'].data_ptr(), drop_site=c_a, dout=nGx,
                        dq=dq_buf, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + hz * d, dvss=F * 2 * d, lddv=2 * d,
@@ -1074,8 +1105,8 @@ class HfttEngine:
             else:
                 # layer zero: query = fc_q(pos_embedding_freq) shared by all sequences, residual = pos_embedding_freq
                 gpos = self.G(dd + 'pos_embedding_freq.weight')
-                plan.append(('colsum', (Bf, BT, N * d, N * d, gpos, 0.0, cs_ws, 1 if st else 0), 'colsum', None))       # residual path (undropped dr)
-                plan.append(('colsum', (q1f if st else Q1, BT, N * d, N * d, dq0s, 0.0, cs_ws, 0), 'colsum', None))     # sum of per-sequence dq
+                plan.append(('colsum', (Bf, BT, N * d, N * d, gpos, 0.0, cs_ws, 1 if bs else 0), 'colsum', None))       # residual path (undropped dr)
+                plan.append(('colsum', (q1f if bs else Q1, BT, N * d, N * d, dq0s, 0.0, cs_ws, 0), 'colsum', None))     # sum of per-sequence dq
                 self._tn(plan, ws, N, d, d, dq0s, d, self.P(dd + 'pos_embedding_freq.weight'), d,
                          [(0, d, self.G(pc + 'fc_q.weight'), self.G(pc + 'fc_q.bias'))])
                 self._nt(plan, ws, N, d, d, dq0s, d, self.Wp(tag + '.ca.q_t'), 0, gpos, d, residual=gpos, ldr=d)
@@ -1089,8 +1120,8 @@ class HfttEngine:
             self._enc_layer_bwd(plan, ws, f'enc{i}', f'enc{i}', f'{e}layers_freq.{i}.', Se, BT, F, self.He, ws['enc_in'][i], Ge,
                                 in_bf=egb, gbf=egb, out_bf=(egb and i > 0))     # the embedding stage below reads fp32
         # ---- embedding ----
-        plan.append(('dropout_bwd', (eGA, Se * d, ws['sites']['embed'], 1 if st else 0), 'dropout_bwd', None))
-        plan.append(('colsum', (eGA, BT, F * d, F * d, self.G(e + 'pos_embedding_freq.weight'), 0.0, cs_ws, 1 if st else 0), 'colsum', None))
+        plan.append(('dropout_bwd', (eGA, Se * d, ws['sites']['embed'], 1 if bs else 0), 'dropout_bwd', None))
+        plan.append(('colsum', (eGA, BT, F * d, F * d, self.G(e + 'pos_embedding_freq.weight'), 0.0, cs_ws, 1 if bs else 0), 'colsum', None))
         self._tn(plan, ws, Se, d, self.Kp, eGA, d, b['win'].data_ptr(), self.Kp, [(0, d, self.dweff.data_ptr(), self.dbeff.data_ptr())],
                  out_scale=math.sqrt(d), dy_bf=st)
         plan.append((self.lib.hftt_embed_fold_bwd, (C.byref(self.fold),), 'embed_fold_bwd', None))

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, check, lib)
+                    SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
 
 
 def _stream(dev):
@@ -132,16 +132,45 @@ def ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
     return out
 
 
+def x3_strip_pack(w: torch.Tensor, elem=2, transpose=False, order=0, out=None, slot_stride=2, slot_offset=0):
+    """fp32 [rows, cols] -> split-operand strip stream of the logical matrix Wl = w (or w.T): (hi, lo) fragment pairs of fp16 (elem 2)
+    or bf16 (elem 4) halves, 2 * Wl.numel() int16 elements (or written into `out` at the given pair stride / offset)."""
+    _need_cuda(w)
+    w = w.contiguous().float()
+    rows, cols = w.shape
+    K = rows if transpose else cols
+    if out is None:
+        out = torch.zeros(2 * w.numel() * (slot_stride // 2), dtype=torch.int16, device=w.device)
+    table, n = strip_pack_table([(0, 0, rows, cols, cols, 1 if transpose else 0, 0, 0, K, order, slot_stride, slot_offset)], w.device)
+    check(lib().hftt_x3_strip_pack(w.data_ptr(), out.data_ptr(), table.data_ptr(), n, elem, _stream(w.device)), 'x3_strip_pack')
+    return out
+
+
+def x3_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
+    """Interleaved split-operand stream of the fused FFN: per hidden tile two slots of the first matrix, then two of the second."""
+    out = torch.zeros(2 * (w1.numel() + w2.numel()), dtype=torch.int16, device=w1.device)
+    if not backward:
+        x3_strip_pack(w1, 2, False, 1, out, 4, 0)
+        x3_strip_pack(w2, 2, False, 0, out, 4, 2)
+    else:
+        x3_strip_pack(w2, 4, True, 1, out, 4, 0)
+        x3_strip_pack(w1, 4, True, 0, out, 4, 2)
+    return out
+
+
 def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, drop_seed=0,
-                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True):
-    """C = epi(x @ Wl.T + bias) with Wl given as its strip pack.  ln = (gamma, beta) -> (C, pre_ln, mean, rstd)."""
+                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0):
+    """C = epi(x @ Wl.T + bias) with Wl given as its strip pack.  ln = (gamma, beta) -> (C, pre_ln, mean, rstd).
+    x3 = 2 / 4: the split-operand form (fp32 tensors, wpack from x3_strip_pack with the same element type)."""
     _need_cuda(x, wpack)
     M, K = x.shape
+    if x3:
+        out_dtype = torch.float32
     Cout = torch.empty(M, N, device=x.device, dtype=out_dtype)
     d = StripDesc()
     d.M, d.N, d.K = M, N, K
     d.flags = (SL_X_BF16 if x.dtype == BF16 else 0) | (SL_C_BF16 if out_dtype == BF16 else 0) | (SL_RELU if relu else 0) \
-        | (SL_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0)
+        | (SL_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0) | (SL_X3_F16 if x3 == 2 else 0) | (SL_X3_BF16 if x3 == 4 else 0)
     d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc, d.out_scale, d.gate_scale = Cout.data_ptr(), N, out_scale, gate_scale
@@ -162,16 +191,18 @@ def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, g
     return (Cout,) + extra if extra else Cout
 
 
-def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_o=0, seed=0, save_hidden=True, save_pre=True, residual=None):
-    """Fused FFN block: y = LN(x + drop(fc_2(drop(relu(fc_1 x))))) -> (y, hidden | None, pre_ln | None, mean, rstd); all bf16."""
+def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_o=0, seed=0, save_hidden=True, save_pre=True, residual=None, x3=False):
+    """Fused FFN block: y = LN(x + drop(fc_2(drop(relu(fc_1 x))))) -> (y, hidden | None, pre_ln | None, mean, rstd); all bf16
+    (x3: all fp32, wpack from x3_ffn_pack)."""
     _need_cuda(x, wpack)
     M, dm = x.shape
-    y = torch.empty(M, dm, device=x.device, dtype=BF16)
-    hid = torch.empty(M, p, device=x.device, dtype=BF16) if save_hidden else None
-    pre = torch.empty(M, dm, device=x.device, dtype=BF16) if save_pre else None
+    dt = torch.float32 if x3 else BF16
+    y = torch.empty(M, dm, device=x.device, dtype=dt)
+    hid = torch.empty(M, p, device=x.device, dtype=dt) if save_hidden else None
+    pre = torch.empty(M, dm, device=x.device, dtype=dt) if save_pre else None
     mean = torch.empty(M, device=x.device); rstd = torch.empty(M, device=x.device)
     d = FfnDesc()
-    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, SL_X_BF16 | SL_C_BF16 | SL_RES_BF16, 0
+    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, (SL_X3_F16 if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 0
     d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
     d.b1, d.b2 = b1.data_ptr(), b2.data_ptr()
     if save_hidden:
@@ -187,14 +218,15 @@ def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_
     return y, hid, pre, mean, rstd
 
 
-def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None):
-    """dh = (hidden > 0) * (dy @ fc_2.weight) * gate_scale;  dx = dh @ fc_1.weight (+ residual) -> (dx, dh); all bf16."""
+def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False):
+    """dh = (hidden > 0) * (dy @ fc_2.weight) * gate_scale;  dx = dh @ fc_1.weight (+ residual) -> (dx, dh); all bf16 (x3: all fp32)."""
     _need_cuda(dy, wpack_bwd, hidden)
     M, dm = dy.shape
-    dx = torch.empty(M, dm, device=dy.device, dtype=BF16)
-    dh = torch.empty(M, p, device=dy.device, dtype=BF16)
+    dt = torch.float32 if x3 else BF16
+    dx = torch.empty(M, dm, device=dy.device, dtype=dt)
+    dh = torch.empty(M, p, device=dy.device, dtype=dt)
     d = FfnDesc()
-    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, SL_X_BF16 | SL_C_BF16 | SL_RES_BF16, 1
+    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, (SL_X3_BF16 if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 1
     d.x, d.ldx, d.w = dy.data_ptr(), dy.stride(0), wpack_bwd.data_ptr()
     d.h_out, d.ldh = dh.data_ptr(), p
     d.gate, d.ldg, d.gate_scale = hidden.data_ptr(), hidden.stride(0), gate_scale

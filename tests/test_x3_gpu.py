@@ -171,7 +171,7 @@ def test_attention_fwd_bwd(dev, n, H, Lq, Lk, dh, qk_scale):
     assert max_err(probs, p_ref) < ptol
     assert abs(probs.sum(-1).mean().item() - 1.0) < 1e-4
     assert rel_err(out, o_ref) < 2 * ptol
-    assert max_err(lse[..., 0] - torch.log(lse[..., 1]), lse_ref) < 1e-4 + 2e-7 * lmax
+    assert max_err(lse[..., 0] - torch.log(lse[..., 1]), lse_ref) < 1e-4 + 4e-7 * lmax
     dq, dk, dv = ops.attn_bwd(dq_, dk_, dv_, out, lse, do.to(dev), H, npass=2)
     gtol = 2e-4 + 3 * ptol
     if qk_scale == 1.0:
@@ -206,3 +206,79 @@ def test_attention_shared_query_and_dropout(dev):
     assert rel_err(dq.sum(0, keepdim=True), q64.grad) < 3e-4
     assert rel_err(dk, k64.grad) < 3e-4
     assert rel_err(dv, v64.grad) < 3e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# strip kernels of the x3 mode (csrc/x3_strip.hip): token strips as (hi, lo) register pairs, split weight fragments through the ring
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('elem', [2, 4])
+@pytest.mark.parametrize('M,N,K', [(384, 256, 256), (1056, 768, 256), (640, 512, 256), (416, 256, 512), (992, 256, 768), (40000, 768, 256)])
+def test_strip_linear(dev, M, N, K, elem):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    wp = ops.x3_strip_pack(W.to(dev), elem, order=1 if K == 256 else 0)      # K == 256 without LayerNorm: the tile-major kernel
+    ref = x.double() @ W.double().T + b.double()
+    out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), x3=elem)
+    assert rel_err(out, ref) < TOL[elem]
+    out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), relu=True, out_scale=0.5, residual=res.to(dev), x3=elem)
+    assert rel_err(out, torch.relu(ref) * 0.5 + res.double()) < TOL[elem]
+    p, site, seed = 0.1, 3, 4242
+    mask = keep_mask_t(seed, site, (M, N), p).double()
+    out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res[:7].contiguous().to(dev), res_mod=7, x3=elem)
+    assert rel_err(out, ref * mask * keep_scale(p) + res.double()[torch.arange(M) % 7]) < TOL[elem]
+
+
+@pytest.mark.parametrize('elem', [2, 4])
+@pytest.mark.parametrize('K', [256, 512])
+def test_strip_linear_layernorm(dev, K, elem):
+    ops = _ops()
+    M, N = 1120, 256
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) * 3.0; gam = torch.randn(N, generator=g); bet = torch.randn(N, generator=g)
+    p, site, seed = 0.1, 11, 99
+    mask = keep_mask_t(seed, site, (M, N), p).double()
+    wp = ops.x3_strip_pack(W.to(dev), elem)
+    out, pre, mean, rstd = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res.to(dev),
+                                            ln=(gam.to(dev), bet.to(dev)), x3=elem)
+    r = (x.double() @ W.double().T + b.double()) * mask * keep_scale(p) + res.double()
+    assert rel_err(pre, r) < TOL[elem]
+    assert rel_err(out, F.layer_norm(r, (N,), gam.double(), bet.double(), 1e-5)) < 1e-4
+    assert rel_err(mean, r.mean(1)) < 1e-4
+    assert rel_err(rstd, 1.0 / torch.sqrt(r.var(1, unbiased=False) + 1e-5)) < 1e-4
+    out2 = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res.to(dev),
+                            ln=(gam.to(dev), bet.to(dev)), save_pre=False, x3=elem)
+    assert max_err(out2[0], out) == 0.0
+
+
+@pytest.mark.parametrize('M', [256, 4000 * 32 // 32 * 1 + 96, 33024])
+def test_fused_ffn_forward_and_dx(dev, M):
+    ops = _ops()
+    d, pf = 256, 512
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, d, generator=g); W1 = torch.randn(pf, d, generator=g) / 16.0; W2 = torch.randn(d, pf, generator=g) / 22.0
+    b1 = torch.randn(pf, generator=g) * 0.3; b2 = torch.randn(d, generator=g) * 0.3; gam = torch.randn(d, generator=g); bet = torch.randn(d, generator=g)
+    p, sh, so, seed = 0.1, 21, 22, 777
+    wf = ops.x3_ffn_pack(W1.to(dev), W2.to(dev))
+    y, hid, pre, mean, rstd = ops.ffn_res_ln_fwd(x.to(dev), wf, pf, b1.to(dev), b2.to(dev), gam.to(dev), bet.to(dev), drop_p=p, site_h=sh, site_o=so, seed=seed, x3=True)
+    h = torch.relu(x.double() @ W1.double().T + b1.double()) * keep_mask_t(seed, sh, (M, pf), p).double() * keep_scale(p)
+    o = (h @ W2.double().T + b2.double()) * keep_mask_t(seed, so, (M, d), p).double() * keep_scale(p)
+    r = x.double() + o
+    assert rel_err(hid, h) < 4e-6
+    assert rel_err(pre, r) < 4e-6
+    assert rel_err(y, F.layer_norm(r, (d,), gam.double(), bet.double(), 1e-5)) < 1e-4
+    assert rel_err(mean, r.mean(1)) < 1e-4
+    # inference form: nothing saved, same result
+    y2 = ops.ffn_res_ln_fwd(x.to(dev), wf, pf, b1.to(dev), b2.to(dev), gam.to(dev), bet.to(dev), drop_p=p, site_h=sh, site_o=so, seed=seed,
+                            save_hidden=False, save_pre=False, x3=True)[0]
+    assert max_err(y2, y) == 0.0
+    # dX half of the backward (gradient-sized dy)
+    dy = torch.randn(M, d, generator=g) * 1e-5; res = torch.randn(M, d, generator=g) * 1e-5
+    wb = ops.x3_ffn_pack(W1.to(dev), W2.to(dev), backward=True)
+    dx, dh = ops.ffn_bwd_dx(dy.to(dev), wb, pf, hid, gate_scale=1.25, residual=res.to(dev), x3=True)
+    # (the gate is the DEVICE's stored hidden: a pre-activation within rounding of zero may fall on either side of the ReLU)
+    dh_ref = torch.where(hid.cpu().double() > 0, (dy.double() @ W2.double()) * 1.25, torch.zeros((), dtype=torch.float64))
+    assert rel_err(dh, dh_ref) < 6e-5
+    assert rel_err(dx, dh_ref @ W1.double() + res.double()) < 6e-5
