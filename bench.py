@@ -7,8 +7,14 @@ is already resident in HBM.  One JSON line on rank 0 (see the driver contract in
 objects: "roofline" (dominant kernel; per-launch HIP events in a profiling pass of its own AFTER the timed region, which itself runs
 without any instrumentation) and "cpu_baseline" (the CPU oracle = a port of the reference algorithm, timed on the host cores, rank 0 at
 N=1 only); plus "roofline_ffn" (the fused feed-forward block hftt_ffn_res_ln_fwd on the inference plan, against the MFMA roofline),
-"inference_clips_per_s", "parity_mode" (throughput of the 1e-3 mode and the error of the benchmarked mode against it) and
-"compat_path_clips_per_s" (the reference's training loop unchanged: torch.optim.Adam + nn criteria + loss.backward()).
+"inference_clips_per_s", "bf16_mode" / "fp32_mfma_mode" (throughput of the other two precision modes and the output differences between
+them and the benchmarked one), "compat_path_clips_per_s" (the reference's training loop unchanged: torch.optim.Adam + nn criteria +
+loss.backward()) and, under N > 1, "collective" (backend, ranks and the all-gathered device list the all-reduce really saw).
+
+Precision modes.  The benchmarked default is "x3": every product in three bf16-rate MFMA passes on split operands
+(fp16 hi + lo forward, bf16 hi + lo where a gradient is an operand), fp32 tensors in HBM -- the mode whose outputs meet north_star's 1e-3
+against the reference (measured 1.2e-4 on the reference-generated paper-size fixture).  "bf16" is the single-pass throughput mode (outputs
+3e-2 off), "parity" the exact-fp32-MFMA mode of round 1.
 
 Launch: python bench.py --gpus 1 --steps 20 --warmup 5
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -106,8 +112,6 @@ def cpu_baseline(cfg, micro=2, accum=4, timed_steps=2):
     warms the allocator, then `timed_steps` whole steps are timed."""
     from oracle import hftt_oracle as O       # the ONLY use of oracle/ in this file: the reported CPU baseline
     physical, model_name = host_cpu()
-    threads = min(physical, 32)          # the oracle's many small ops stop scaling (and then regress) beyond a few dozen threads
-    torch.set_num_threads(threads)
     ocfg = O.HfttConfig(**cfg._asdict())
     model = build_model(cfg, 1234, 0.1, 'cpu')
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
@@ -121,7 +125,20 @@ def cpu_baseline(cfg, micro=2, accum=4, timed_steps=2):
         out = O.model_forward(sd, x, ocfg, p=0.1, training=True)
         (O.spec2midi_loss(out, *labels) / accum).backward()
 
+    # thread count: one untimed micro-batch warms the allocator, then one micro-batch is timed at 32 / 64 / all physical cores and the
+    # fastest setting runs the timed steps (the oracle's many small ops stop scaling -- and then regress -- beyond a few dozen threads)
+    torch.set_num_threads(min(physical, 32))
     micro_batch(0)
+    sweep = {}
+    for th in sorted({min(physical, 32), min(physical, 64), physical}):
+        torch.set_num_threads(th)
+        for t in sd.values():
+            t.grad = None
+        t0 = time.time()
+        micro_batch(0)
+        sweep[th] = time.time() - t0
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     times = []
     for step in range(1, timed_steps + 1):
         t0 = time.time()
@@ -134,9 +151,10 @@ def cpu_baseline(cfg, micro=2, accum=4, timed_steps=2):
         times.append(time.time() - t0)
     clips = micro * accum
     return {'value': clips * len(times) / sum(times), 'unit': 'clips/s', 'cores': threads, 'kind': 'port', 'cpu_model': model_name,
-            'host_physical_cores': physical,
+            'host_physical_cores': physical, 'thread_sweep_s_per_micro_batch': {str(k): round(v, 2) for k, v in sweep.items()},
             'sample': 'paper-size hFT, fp32, dropout 0.1, batch %d as %d micro-batches of %d clips with gradient accumulation: 1 warm-up '
-                      'micro-batch + %d timed steps of forward+loss+backward+Adam (%s s) with the pure-PyTorch CPU oracle on %d threads'
+                      'micro-batch + %d timed steps of forward+loss+backward+Adam (%s s) with the pure-PyTorch CPU oracle on %d threads (the fastest of a '
+                      '32 / 64 / all-physical-cores sweep over one micro-batch each)'
                       % (clips, accum, micro, len(times), ' / '.join('%.1f' % t for t in times), threads)}
 
 
@@ -175,7 +193,7 @@ def pmc_busy(kernel_key, kind='bench'):
         return None
 
 
-def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench'):
+def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench', mfma_passes=1):
     """roofline object of one kernel symbol from the profiling pass: ALGORITHMIC flops / bytes of its launches (engine plan meta, DESIGN.md
     section 5) over the measured launch durations; the bound is the side of the ridge its arithmetic intensity falls on."""
     ai = v['flops'] / max(v['bytes'], 1.0)
@@ -189,6 +207,10 @@ def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench'):
     # (PMC figures are per-launch averages over ALL launches of the kernel symbol in the profiled command: `kind` picks the training step's
     # files or the inference plan's)
     traffic, src = pmc_traffic_bytes(key, kind)
+    if mfma_passes != 1:
+        # split-operand mode: `achieved` counts ALGORITHMIC flops (one multiply-add per product of the reference's arithmetic); the matrix
+        # pipe executes `mfma_passes` bf16-rate passes per product, so its own utilisation is mfma_passes x that
+        roof.update({'mfma_passes': mfma_passes, 'matrix_pipe_tflops': mfma_passes * tf, 'matrix_pipe_frac_of_bf16_peak': mfma_passes * tf / PEAK_BF16_TFLOPS})
     roof.update({'traffic': traffic, 'traffic_source': src, 'mfma_busy': pmc_busy(key, kind), 'kernel': key,
                  'launches_per_step': v['launches'] / steps, 'avg_launch_ms': v['ms'] / v['launches'],
                  'share_of_step_device_time': v['ms'] / max(total_ms, 1e-9), 'arithmetic_intensity': ai,
@@ -222,7 +244,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='clips per GPU')
     ap.add_argument('--config', default='paper', choices=['paper', 'tiny'])
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'x3', 'parity'])
+    ap.add_argument('--precision', default='x3', choices=['x3', 'bf16', 'parity'])
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--data', default='synthetic', choices=['synthetic', 'store'],
                     help="'store': every step gathers its clips from a device-resident MAESTRO-format store (the gather is inside the step)")
@@ -259,6 +281,15 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
+
+    collective = None
+    if world > 1 or force_ddp:
+        # what the collective really saw: every rank reports (rank, local rank, device index, device name, uuid) through an object all-gather
+        props = torch.cuda.get_device_properties(dev)
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': dev_index, 'name': props.name, 'uuid': str(getattr(props, 'uuid', ''))}
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, mine)
+        collective = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'devices': seen}
 
     cfg = CONFIGS[args.config]
     B = args.batch
@@ -345,6 +376,7 @@ def main():
     if rank == 0:
         value = B * world * args.steps / dt
         peak_tf = PEAK_F32_TFLOPS if args.precision == 'parity' else PEAK_BF16_TFLOPS
+        passes = 3 if args.precision == 'x3' else 1
         roof = roof_ffn = kernels = None
         extras = {}
         if prof is not None:
@@ -354,7 +386,7 @@ def main():
             # its event interval is not one kernel's duration and would not match rocprofv3's per-kernel average)
             single = {k: v for k, v in summ.items() if not k.startswith('gemm_tn') and v['flops'] > 0}
             key, dom = max(single.items(), key=lambda kv: kv[1]['ms'])
-            roof = roofline_object(key, dom, psteps, peak_tf, total_ms)
+            roof = roofline_object(key, dom, psteps, peak_tf, total_ms, mfma_passes=passes)
             top = sorted(summ.items(), key=lambda kv: -kv[1]['ms'])[:14]
             kernels = [{'kernel': k, 'ms_per_step': v['ms'] / psteps, 'launches_per_step': v['launches'] / psteps,
                         'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else None,
@@ -372,50 +404,70 @@ def main():
                                           for (k, sh), e in big]
         if world == 1 and not args.no_extras:
             x0, lab0 = batch(0)
-            # ---- inference plan (model.eval(): nothing saved for a backward) at the same batch
-            model.eval()
-            model.hftt_freeze_weights(True)            # what model.amt.AMT does: a transcriber's weights are constant
-            with torch.no_grad():
-                t_inf = timed(lambda i: model(batch(i)[0]), 10, warm=2)
-                post_bf = [t.clone() for k, t in enumerate(model(x0)) if k in (0, 1, 2, 5, 6, 7)]
-                extras['inference_clips_per_s'] = B / t_inf
-                if not args.no_profile:
-                    prof = LaunchProfiler()
-                    ts.engine.profiler = prof
-                    for i in range(3):
-                        model(batch(i)[0])
-                        prof.step_done()
-                    ts.engine.profiler = None
-                    s_inf = prof.summary()
-                    tot_inf = sum(v['ms'] for v in s_inf.values())
-                    # hftt_ffn_res_ln_fwd: the fused position-wise feed-forward block on the inference plan, where it saves nothing
-                    # and its arithmetic intensity is on the MFMA side of the ridge
-                    ffn = {k: v for k, v in s_inf.items() if k.startswith('strip_mlp') and v['meta'] and v['meta'][0]['shape'][0] >= 200000}
-                    if ffn:
-                        k_ffn, v_ffn = max(ffn.items(), key=lambda kv: kv[1]['ms'])
-                        # the launches at S_e only (the encoder's; the decoder runs the same kernel on 3x fewer tokens)
-                        sel = [(m_, t_) for m_, t_ in zip(v_ffn['meta'], prof.samples[k_ffn]['ms']) if m_['shape'][0] >= 200000]
-                        v_sel = {'launches': len(sel), 'ms': sum(t_ for _, t_ in sel), 'flops': sum(m_['flops'] for m_, _ in sel),
-                                 'bytes': sum(m_['bytes'] for m_, _ in sel), 'stalls': 0}
-                        roof_ffn = roofline_object(k_ffn, v_sel, 3, peak_tf, tot_inf, kind='inference')
-                        roof_ffn['entry_point'] = 'hftt_ffn_res_ln_fwd'
-                        roof_ffn['plan'] = 'inference (no hidden / pre-LN stores), tokens per launch %d' % sel[0][0]['shape'][0]
-            model.hftt_freeze_weights(False)
-            # ---- the 1e-3 parity mode on the same clips: throughput of its training step and the error of the benchmarked mode against it
-            if args.precision == 'bf16':
-                model.hftt_precision = 'parity'
+
+            def inference_leg(precision):
+                """inference plan (model.eval(): nothing saved for a backward) at the same batch: clips/s, the six posteriors of batch 0 and the
+                roofline object of the fused feed-forward block hftt_ffn_res_ln_fwd at S_e tokens"""
+                model.hftt_precision = precision
+                model.eval()
+                model.hftt_freeze_weights(True)            # what model.amt.AMT does: a transcriber's weights are constant
+                out = {}
                 with torch.no_grad():
-                    post_par = [t for k, t in enumerate(model(x0)) if k in (0, 1, 2, 5, 6, 7)]
-                err = max(float((a - b).abs().max()) for a, b in zip(post_bf, post_par))
+                    t_inf = timed(lambda i: model(batch(i)[0]), 10, warm=2)
+                    out['post'] = [t.clone() for k, t in enumerate(model(x0)) if k in (0, 1, 2, 5, 6, 7)]
+                    out['logits'] = [t.clone() for k, t in enumerate(model(x0)) if k in (3, 8)]
+                    out['clips_per_s'] = B / t_inf
+                    if not args.no_profile and precision != 'parity':
+                        pr = LaunchProfiler()
+                        eng = model.hftt_engine()
+                        eng.profiler = pr
+                        for i in range(3):
+                            model(batch(i)[0])
+                            pr.step_done()
+                        eng.profiler = None
+                        s_inf = pr.summary()
+                        tot_inf = sum(v['ms'] for v in s_inf.values())
+                        ffn = {k: v for k, v in s_inf.items() if ('_mlp' in k) and v['meta'] and v['meta'][0]['shape'][0] >= 200000}
+                        if ffn:
+                            k_ffn, v_ffn = max(ffn.items(), key=lambda kv: kv[1]['ms'])
+                            sel = [(m_, t_) for m_, t_ in zip(v_ffn['meta'], pr.samples[k_ffn]['ms']) if m_['shape'][0] >= 200000]
+                            v_sel = {'launches': len(sel), 'ms': sum(t_ for _, t_ in sel), 'flops': sum(m_['flops'] for m_, _ in sel),
+                                     'bytes': sum(m_['bytes'] for m_, _ in sel), 'stalls': 0}
+                            rf = roofline_object(k_ffn, v_sel, 3, PEAK_BF16_TFLOPS, tot_inf, kind='inference', mfma_passes=3 if precision == 'x3' else 1)
+                            rf['entry_point'] = 'hftt_ffn_res_ln_fwd'
+                            rf['precision_mode'] = precision
+                            rf['plan'] = 'inference (no hidden / pre-LN stores), tokens per launch %d' % sel[0][0]['shape'][0]
+                            out['roofline_ffn'] = rf
+                model.hftt_freeze_weights(False)
+                return out
+
+            def train_leg(precision):
+                model.hftt_precision = precision
                 model.train()
-                ts_par = TrainStep(model, lr=1e-4, optimizer=ts.opt)
-                t_par = timed(lambda i: ts_par(batch(i)[0], *batch(i)[1]), 3, warm=1)
-                extras['parity_mode'] = {'clips_per_s': B / t_par, 'max_abs_err': err,
-                                         'what': 'training step in precision mode "parity" (exact-fp32 MFMA, <= 1e-3 of the reference); max_abs_err = '
-                                                 'largest difference of the six posteriors between the benchmarked bf16 mode and the parity mode, same '
-                                                 'clips, eval forward'}
-                model.hftt_precision = args.precision
-                del ts_par
+                ts_m = TrainStep(model, lr=1e-4, optimizer=ts.opt)
+                t_m = timed(lambda i: ts_m(batch(i)[0], *batch(i)[1]), 3 if precision == 'parity' else 6, warm=1)
+                del ts_m
+                return B / t_m
+
+            inf = {args.precision: inference_leg(args.precision)}
+            extras['inference_clips_per_s'] = inf[args.precision]['clips_per_s']
+            roof_ffn = inf[args.precision].get('roofline_ffn')
+            others = [m for m in ('x3', 'bf16', 'parity') if m != args.precision and not (args.config != 'paper' and m == 'parity')]
+            for m in others:
+                inf[m] = inference_leg(m)
+
+            def diff(a, b, what):
+                return max(float((x - y).abs().max()) for x, y in zip(inf[a][what], inf[b][what]))
+            for m in others:
+                key = {'bf16': 'bf16_mode', 'x3': 'x3_mode', 'parity': 'fp32_mfma_mode'}[m]
+                extras[key] = {'clips_per_s': train_leg(m), 'inference_clips_per_s': inf[m]['clips_per_s'],
+                               'max_abs_diff_posteriors_vs_benchmarked_mode': diff(m, args.precision, 'post'),
+                               'max_abs_diff_velocity_logits_vs_benchmarked_mode': diff(m, args.precision, 'logits'),
+                               'what': 'training step / eval forward in precision mode "%s" on the same clips; differences of the six posteriors and '
+                                       'the two velocity-logit tensors against the benchmarked mode "%s" (eval forward)' % (m, args.precision)}
+                if 'roofline_ffn' in inf[m]:
+                    extras[key]['roofline_ffn'] = inf[m]['roofline_ffn']
+            model.hftt_precision = args.precision
             # ---- compatibility path: the reference's loop unchanged (torch.optim.Adam, 8 nn criteria, loss.backward()) through training.train
             import torch.nn as nn
             from training import train as T
@@ -432,7 +484,8 @@ def main():
         result = {
             'metric': 'training clips/sec (128-frame x 256-bin)', 'value': value, 'unit': 'clips/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {'x3': 'f16x3 (split fp16 / bf16 operands, three bf16-rate MFMA passes, fp32 accumulate and storage)', 'bf16': 'bf16', 'parity': 'f32'}[args.precision],
             'data': 'synthetic' if args.data == 'synthetic' else 'synthetic (MAESTRO-format store resident in HBM, clips gathered inside the step)',
             'config': {'workload': '%s-size hFT-Transformer training step (d=%d, ff=%d, %d+%d layers, %d heads), batch %d clips/GPU, '
                                    'dropout %.2f, forward+loss+backward+Adam' % (args.config, cfg.hid_dim, cfg.pf_dim, cfg.enc_layer, cfg.dec_layer,
@@ -444,6 +497,7 @@ def main():
             'roofline': roof,
             'roofline_ffn': roof_ffn,
             'kernels': kernels,
+            'collective': collective,
         }
         result.update(extras)
         if world == 1 and not args.no_cpu_baseline:

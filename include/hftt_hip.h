@@ -247,7 +247,9 @@ typedef struct {
   const float* k; int64_t k_seq_stride; int64_t ldk;
   const float* v; int64_t v_seq_stride; int64_t ldv;
   float* out; int64_t o_seq_stride; int64_t ldo;
-  float* lse;                 /* [n_seq, n_heads, Lq, 2]: row max of the scaled scores, 1 / sum(exp(score - max)) */
+  float* lse;                 /* [n_seq, n_heads, Lq, 2]: (row max, 1 / sum(exp(score - max))); the max is of the scaled scores when
+                                 npass == 3 and of the RAW Q.K^T (before the 1/sqrt(dh)) when npass is 1 or 2 -- an opaque pair between
+                                 a forward and the backward of the SAME npass */
   float* probs;               /* [n_seq, n_heads, Lq, Lk] or NULL */
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   /* backward only */

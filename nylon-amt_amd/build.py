@@ -14,10 +14,15 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libhftt_hip.so')
-SOURCES = ['capi.cpp', 'gemm_nt.hip', 'strip_gemm.hip', 'strip_gemm2.hip', 'strip_gemm3.hip', 'strip_gemm4.hip', 'strip_gemm5.hip', 'gemm_tn.hip', 'attn_fwd.hip', 'attn_fwd8.hip', 'attn_bwd.hip', 'x3_attn.hip', 'x3_strip.hip', 'elementwise.hip', 'logmel.hip']
+SOURCES = ['capi.cpp', 'gemm_nt.hip', 'strip_gemm.hip', 'strip_gemm2.hip', 'gemm_tn.hip', 'attn_fwd.hip', 'attn_fwd8.hip', 'attn_bwd.hip', 'x3_attn.hip', 'x3_strip.hip', 'elementwise.hip', 'logmel.hip']
 HEADERS = [os.path.join(CSRC, 'hftt_common.h'), os.path.join(CSRC, 'hftt_host.h'), os.path.join(CSRC, 'strip_internal.h'), os.path.join(CSRC, 'strip_pipe.h'), os.path.join(CSRC, 'x3_common.h'), os.path.join(CSRC, 'x3_internal.h'),
            os.path.join(HERE, '..', 'include', 'hftt_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
+# HFTT_BUILD_EXPERIMENTS=1: also build csrc/experiments/ (three alternative schedules of the bf16 strip tiling, each measured slower than
+# the shipped one: DESIGN.md section 4) and let HFTT_STRIP_V3 / V4 / V5 select them; the default library does not carry them
+if os.environ.get('HFTT_BUILD_EXPERIMENTS') == '1':
+    SOURCES += ['experiments/strip_gemm3.hip', 'experiments/strip_gemm4.hip', 'experiments/strip_gemm5.hip']
+    FLAGS += ['-DHFTT_STRIP_EXPERIMENTS']
 
 
 def _hipcc():
@@ -35,7 +40,7 @@ def _stale(target, deps):
 
 
 def _compile(src):
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+    obj = os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + ('.x.o' if 'HFTT_STRIP_EXPERIMENTS' in ' '.join(FLAGS) else '.o'))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
         cmd = [_hipcc()] + FLAGS + ['-x', 'hip', '-c', path, '-o', obj]

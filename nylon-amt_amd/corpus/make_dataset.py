@@ -16,20 +16,43 @@ def assemble_store(features, labels, config):
     nf = [max(f.shape[0], len(l['mpe'])) for f, l in zip(features, labels)]         # make_dataset.py:52
     total = cin['margin_b'] + sum(n + gap for n in nf)
     zero_value = np.log(cf['log_offset']) if cf['log_offset'] > 0.0 else cf['log_offset']
-    feature = np.full([total, cf['mel_bins']], zero_value, dtype=np.float32)
+    # make_dataset.py:100-116: with input.max_value > 0 the features are scaled to (x - min) / (max - min) and the padding is ZERO;
+    # otherwise (the shipped config: max_value 0) raw features and log(log_offset) padding
+    scaled = cin.get('max_value', 0.0) > 0.0
+    if scaled:
+        feature = np.zeros([total, cf['mel_bins']], dtype=np.float32)
+    else:
+        feature = np.full([total, cf['mel_bins']], zero_value, dtype=np.float32)
     lab = {'onset': np.zeros([total, cm['num_note']], np.float32), 'offset': np.zeros([total, cm['num_note']], np.float32),
            'mpe': np.zeros([total, cm['num_note']], bool), 'velocity': np.zeros([total, cm['num_note']], np.int8)}
     idx = np.zeros(sum(nf), dtype=np.int32)
     loc_i, loc_d = 0, cin['margin_b']
     for f, l, n in zip(features, labels, nf):
         idx[loc_i:loc_i + n] = np.arange(loc_d, loc_d + n)
-        feature[loc_d:loc_d + f.shape[0]] = f
+        feature[loc_d:loc_d + f.shape[0]] = ((f - cin['min_value']) / (cin['max_value'] - cin['min_value'])) if scaled else f
         for k in lab:
             lab[k][loc_d:loc_d + len(l[k])] = l[k]
         loc_i += n
         loc_d += n + gap
     return {'feature': feature, 'label_onset': lab['onset'], 'label_offset': lab['offset'], 'label_mpe': lab['mpe'],
             'label_velocity': lab['velocity'], 'idx': idx}
+
+
+def prepare_config(config, max_value=0.0):
+    """What the reference's make_dataset.py __main__ sets BEFORE assembling (:274-278): input.max_value from the command line and
+    input.min_value = log(log_offset) as a float32 (or log_offset itself when that is not positive).  In place; returns config."""
+    config['input']['max_value'] = max_value
+    lo = config['feature']['log_offset']
+    config['input']['min_value'] = np.log(lo).astype(np.float32) if lo > 0.0 else lo
+    return config
+
+
+def finalize_config(config):
+    """... and what it writes into the config file AFTER assembling (:305-306): min_value as a plain float, feature.n_bins = mel_bins --
+    the two keys model/amt.py:70-73 reads when it pads a feature array.  In place; returns config."""
+    config['input']['min_value'] = float(config['input']['min_value'])
+    config['feature']['n_bins'] = config['feature']['mel_bins']
+    return config
 
 
 def synth_file(n_frames, config, rng):

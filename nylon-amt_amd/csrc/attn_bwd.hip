@@ -260,7 +260,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         dot = group_sum<QSLOT>(dot);
         if (cs == 0) {
           delta_s[row] = dot;
-          lse_s[row] = HB ? pl[u].x * LOG2E : pl[u].x;      // HB: the forward's m2 = max * log2e (same rounding as attn_fwd.hip)
+          lse_s[row] = pl[u].x;                             // HB: the RAW row maximum (attn_fwd.hip); else the maximum of the scaled scores
           inv_s[row] = pl[u].y;
         }
       }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
         for (int e = 0; e < 4; e++) {
           const int r = 4 * j4 + e;
           float p;
-          if (HB) p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -rs_m[e])) * rs_i[e];
+          if (HB) p = __builtin_amdgcn_exp2f((sacc[r] - rs_m[e]) * c2) * rs_i[e];
           else {
             const float arg = sacc[r] * scale - rs_m[e];
             p = (F32 ? expf(arg) : __expf(arg)) * rs_i[e];

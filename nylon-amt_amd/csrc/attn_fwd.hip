@@ -202,9 +202,10 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
           sacc[kt] = mfma32(lds_read_b128(Ks16 + (kt * 32 + lr) * RSK + 16 * s + 8 * lh), qh[s], sacc[kt]);
     }
     // ---- softmax over keys (register-local + one cross-half exchange) ----
-    // HB: the maximum is taken over the RAW scores (scale > 0 keeps the order) and the scale is folded with log2(e) into the one FMA
-    // in front of v_exp_f32:  p = 2^(s*c2 - m2), c2 = scale*log2e, m2 = (max*scale)*log2e.  The backward forms m2 from the stored max with
-    // the same two roundings, so it recomputes bitwise the same P.
+    // HB: the maximum is taken over the RAW scores (scale > 0 keeps the order), subtracted from them EXACTLY (the maximum element gives 0 and
+    // p = 1 whatever the magnitude of the scores: a rounded `s*c2 - m2` is off by ulp(m2), which at |scores| ~ 1e9 -- seen in training --
+    // is > 126 and underflows the whole row), and the scale is folded with log2(e) into the multiply in front of v_exp_f32:
+    // p = 2^((s - max) * c2), c2 = scale*log2e.  lse[0] holds that RAW maximum in this mode; the backward recomputes bitwise the same P.
     constexpr float LOG2E = 1.4426950408889634f;
     const float c2 = scale * LOG2E;
     // 4*lh as a value the optimiser cannot see through: every per-register key number below is then (compile-time constant + lh4) formed
@@ -226,16 +227,14 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
     mx = xor32_max(mx);
-    if (HB) mx *= scale;                              // the row maximum in natural units (what lse[0] holds in every mode)
     }
     float sum = 0.f;
     if (!ABL(g, 4)) {
-    const float m2 = mx * LOG2E;
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const float p = HB ? __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c2, -m2)) : (F32 ? expf(sacc[kt][r] - mx) : __expf(sacc[kt][r] - mx));
+        const float p = HB ? __builtin_amdgcn_exp2f((sacc[kt][r] - mx) * c2) : (F32 ? expf(sacc[kt][r] - mx) : __expf(sacc[kt][r] - mx));
         sacc[kt][r] = p;
         sum += p;
       }

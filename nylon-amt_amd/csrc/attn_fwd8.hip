@@ -6,7 +6,7 @@
 // the stores of a workgroup run one after the other (ablation, tools/ablate_attn.sh: the parts add up to the whole) and one partner wave
 // cannot cover them.  Here the row is walked tile by tile (32 keys = 16 accumulator registers), twice:
 //   pass A   S tile = K . Q^T -> row maximum only;
-//   pass B   S tile again -> p = 2^(s*c2 - m2) (the FINAL maximum, so no rescaling) -> row sum, dropout -> P tile . V accumulated.
+//   pass B   S tile again -> p = 2^((s - max)*c2) (the FINAL maximum, so no rescaling) -> row sum, dropout -> P tile . V accumulated.
 // 32 more MFMAs per query block (QK^T twice), but a wave fits 128 registers: 8 waves per workgroup, one query block each, two
 // workgroups per CU = FOUR waves per SIMD.  The row normalisation 1/sum is known only at the end and lives in the lane of its QUERY,
 // while the output accumulators hold a query per REGISTER row: it crosses through 128 bytes of LDS per wave.
@@ -107,8 +107,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const hftt_attn_desc 
 #pragma unroll
     for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[r]);
   }
-  mx = xor32_max(mx) * scale;                          // natural units (what lse[0] holds in every kernel of the family)
-  const float m2 = mx * LOG2E;
+  mx = xor32_max(mx);                                  // the RAW maximum (what lse[0] holds in the bf16 / x3 kernels: attn_fwd.hip)
 
   // ---- pass B: probabilities, row sum, dropout, P . V
   const long prow = (((long)seq * g.n_heads + head) * Lq + qrow) * (long)Lk;
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const hftt_attn_desc 
     scores(kt, s);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -m2));
+      const float p = __builtin_amdgcn_exp2f((s[r] - mx) * c2);
       s[r] = p;
       sum += p;
     }

@@ -18,14 +18,14 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
-#include "hftt_common.h"
-#include "hftt_host.h"
-#include "strip_internal.h"
-#include "../../include/hftt_hip.h"
+#include "../hftt_common.h"
+#include "../hftt_host.h"
+#include "../strip_internal.h"
+#include "../../../include/hftt_hip.h"
 
 namespace {
 
-#include "strip_pipe.h"
+#include "../strip_pipe.h"
 
 constexpr int XBUF_BYTES = 128 * 512;                // [token][256 features] bf16, rows rotated: one 256-feature chunk of a 128-token block
 

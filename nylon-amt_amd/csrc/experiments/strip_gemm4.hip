@@ -32,14 +32,14 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
-#include "hftt_common.h"
-#include "hftt_host.h"
-#include "strip_internal.h"
-#include "../../include/hftt_hip.h"
+#include "../hftt_common.h"
+#include "../hftt_host.h"
+#include "../strip_internal.h"
+#include "../../../include/hftt_hip.h"
 
 namespace {
 
-#include "strip_pipe.h"
+#include "../strip_pipe.h"
 
 constexpr int XBUF_BYTES = 65536;                   // 4 strips x 16 pieces x (64 lanes x 16 B)
 constexpr int STG_BYTES = 16384;                    // 4 strips x 2 entries x 2 pieces x 1 KB

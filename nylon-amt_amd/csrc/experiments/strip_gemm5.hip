@@ -29,14 +29,14 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
-#include "hftt_common.h"
-#include "hftt_host.h"
-#include "strip_internal.h"
-#include "../../include/hftt_hip.h"
+#include "../hftt_common.h"
+#include "../hftt_host.h"
+#include "../strip_internal.h"
+#include "../../../include/hftt_hip.h"
 
 namespace {
 
-#include "strip_pipe.h"
+#include "../strip_pipe.h"
 
 // 16 fragments -> 32 MFMAs: mfma_f(f, a) multiplies fragment f into both strips; six reads up front, one behind every fragment, the
 // slot's share of the memory work (side(f)) in program order between the MFMAs (see slot_mfmas_mix)

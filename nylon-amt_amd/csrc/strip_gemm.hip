@@ -659,13 +659,16 @@ extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
     HFTT_REQUIRE(d->gate == nullptr && !(d->flags & HFTT_SL_RELU), "strip_linear: gate / ReLU cannot be combined with LayerNorm");
     HFTT_REQUIRE(d->pre_ln_out == nullptr || ((uintptr_t)d->pre_ln_out & 15) == 0, "strip_linear: pre_ln_out alignment");
   }
-  {                                                   // persistent software-pipelined forms where they apply (strip_gemm3.hip, then strip_gemm2.hip)
-    int rc = hftt_strip_linear5_try(*d, st);
+  {                                                   // the persistent software-pipelined form where it applies (strip_gemm2.hip)
+    int rc;
+#ifdef HFTT_STRIP_EXPERIMENTS                         // csrc/experiments/: three measured-slower forms of the same tiling, opt-in builds only
+    rc = hftt_strip_linear5_try(*d, st);
     if (rc >= 0) return rc;
     rc = hftt_strip_linear4_try(*d, st);
     if (rc >= 0) return rc;
     rc = hftt_strip_linear3_try(*d, st);
     if (rc >= 0) return rc;
+#endif
     rc = hftt_strip_linear2_try(*d, st);
     if (rc >= 0) return rc;
   }

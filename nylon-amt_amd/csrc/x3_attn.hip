@@ -33,10 +33,14 @@ struct XfCfg {
   static constexpr int LDS_BYTES = (2 * K_PL + 2 * V_PL) * 2;
 };
 
-template <int KT, int DH>
-__global__ __launch_bounds__(256, 1) void x3_attn_fwd_kernel(const hftt_attn_desc g) {
+// NW waves per workgroup, one 32-query block per wave at a time: 8 waves for the long key axes (KT = 8: K + V take 147 KB of LDS, so one
+// workgroup per CU -- two waves per SIMD then let one wave's softmax run under the other's MFMAs, and the staging phase has twice the
+// threads), 4 otherwise
+template <int KT, int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void x3_attn_fwd_kernel(const hftt_attn_desc g) {
   using Cfg = XfCfg<KT, DH>;
   constexpr int E = X3_F16;
+  constexpr int NTHR = NW * 64;
   constexpr int RSK = Cfg::RSK, RSV = Cfg::RSV, LKP = Cfg::LKP, K_PL = Cfg::K_PL, V_PL = Cfg::V_PL;
   constexpr int KS = DH / 16, NT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -55,20 +59,23 @@ __global__ __launch_bounds__(256, 1) void x3_attn_fwd_kernel(const hftt_attn_des
     const long vofs = (long)seq * g.v_seq_stride + head * DH;
     constexpr int F4R = DH / 4;
     constexpr int TOTAL = LKP * F4R;
-    constexpr int UB = (TOTAL / 256) < 8 ? (TOTAL / 256) : 8;     // TOTAL is a multiple of 256 for every (KT, DH)
-    for (int base = 0; base < TOTAL; base += 256 * UB) {
+    constexpr int PER = (TOTAL + NTHR - 1) / NTHR;
+    constexpr int UB = PER < 8 ? PER : 8;
+    for (int base = 0; base < TOTAL; base += NTHR * UB) {
       float4 kf[UB], vf[UB];
 #pragma unroll
       for (int u = 0; u < UB; u++) {
-        const int i = base + tid + 256 * u;
-        const int key = i / F4R, c4 = i % F4R;
+        const int i = base + tid + NTHR * u;
+        const int ic = i < TOTAL ? i : TOTAL - 1;
+        const int key = ic / F4R, c4 = ic % F4R;
         const int kc = key < Lk ? key : Lk - 1;       // clamped address: loads stay unconditional
         kf[u] = *reinterpret_cast<const float4*>(g.k + kofs + (long)kc * g.ldk + c4 * 4);
         vf[u] = *reinterpret_cast<const float4*>(g.v + vofs + (long)kc * g.ldv + c4 * 4);
       }
 #pragma unroll
       for (int u = 0; u < UB; u++) {
-        const int i = base + tid + 256 * u;
+        const int i = base + tid + NTHR * u;
+        if (i >= TOTAL) continue;
         const int key = i / F4R, c4 = i % F4R;
         if (key >= Lk) { kf[u] = make_float4(0.f, 0.f, 0.f, 0.f); vf[u] = kf[u]; }
         uint2 hi, lo;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void x3_attn_fwd_kernel(const hftt_attn_des
   const uint64_t hk = hftt_hash_key(g.drop_seed, g.drop_site);
   const bool quad_ok = (Lk & 3) == 0 && (((uint64_t)g.n_seq * (uint64_t)g.n_heads * (uint64_t)Lq * (uint64_t)Lk) >> 34) == 0;
 
-  for (int qb = wave; qb < nqb; qb += 4) {
+  for (int qb = wave; qb < nqb; qb += NW) {
     const int qrow = qb * 32 + lr;                     // this lane's query (as the B-operand column)
     const int qrow_c = qrow < Lq ? qrow : Lq - 1;
     const float* qp = g.q + (long)seq * g.q_seq_stride + (long)qrow_c * g.ldq + head * DH + 8 * lh;
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void x3_attn_fwd_kernel(const hftt_attn_des
         const unsigned short* p = Ks + (kt * 32 + lr) * RSK + 16 * s + 8 * lh;
         sacc[kt] = x3_mma<E>(lds_read_b128(p), lds_read_b128(p + K_PL), qh[s], ql[s], sacc[kt]);
       }
-    // ---- softmax over keys: p = 2^(s*c2 - m2), c2 = scale*log2e, m2 = (max*scale)*log2e (the backward forms m2 with the same roundings) ----
+    // ---- softmax over keys: p = 2^((s - max) * c2), c2 = scale*log2e; the RAW maximum is subtracted exactly and stored (attn_fwd.hip) ----
     int lh4 = 4 * lh;
     asm volatile("" : "+v"(lh4));                      // opaque: keeps the per-register key numbers out of LICM's reach (spills)
     float mx = -INFINITY;
@@ -133,14 +140,13 @@ __global__ __launch_bounds__(256, 1) void x3_attn_fwd_kernel(const hftt_attn_des
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
-    mx = xor32_max(mx) * scale;                        // the row maximum in natural units (what lse[0] holds in every mode)
-    const float m2 = mx * LOG2E;
+    mx = xor32_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c2, -m2));
+        const float p = __builtin_amdgcn_exp2f((sacc[kt][r] - mx) * c2);
         sacc[kt][r] = p;
         sum += p;
       }
@@ -232,13 +238,14 @@ __global__ __launch_bounds__(256, 1) void x3_attn_fwd_kernel(const hftt_attn_des
 template <int KT, int DH>
 int launch_xf(const hftt_attn_desc& d, hipStream_t st) {
   using Cfg = XfCfg<KT, DH>;
+  constexpr int NW = (KT == 8) ? 8 : 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3_attn_fwd_kernel<KT, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3_attn_fwd_kernel<KT, DH, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) { hftt_set_error("x3_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((x3_attn_fwd_kernel<KT, DH>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(256), Cfg::LDS_BYTES, st, d);
+  hipLaunchKernelGGL((x3_attn_fwd_kernel<KT, DH, NW>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(NW * 64), Cfg::LDS_BYTES, st, d);
   HFTT_CHECK_LAUNCH("x3_attn_fwd");
   return 0;
 }
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         dot = group_sum<F4R>(dot);
         if (cs == 0) {
           delta_s[row] = dot;
-          lse_s[row] = pl[u].x * LOG2E;                 // the forward's m2 = max * log2e (same rounding as the forward)
+          lse_s[row] = pl[u].x;                         // the RAW row maximum the forward subtracted
           inv_s[row] = pl[u].y;
         }
       }
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int r = 4 * j4 + e;
-          float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -rs_m[e])) * rs_i[e];
+          float p = __builtin_amdgcn_exp2f((sacc[r] - rs_m[e]) * c2) * rs_i[e];
           if (!key_ok) p = 0.f;
           float pd = p, dp = pacc[r];
           if (DROP) {

@@ -209,7 +209,7 @@ __device__ __forceinline__ void tile_store_rows(float* stage, const float* v, in
 
 // LayerNorm over the 256 features of the lane's token (lane: 128 of them in acc, partner lane ^ 32 the rest), fp32 out
 __device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_lds, const float* beta_lds, int h, float* mean_out, float* rstd_out,
-                                           long tok, bool ok, float* pre_row, float* y_row) {
+                                           long tok, bool ok, float* stage, int j, int lane, float* pre_wave, float* y_wave, long ld) {
   float s = 0.f;
 #pragma unroll
   for (int ot = 0; ot < 8; ot++)
@@ -231,12 +231,12 @@ __device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_
     float v[16], ga[16], be[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = acc[ot][q];
-    if (pre_row != nullptr && ok) store16f(pre_row + ot * 32, v);
+    if (pre_wave != nullptr) tile_store_rows(stage, v, j, h, lane, pre_wave + ot * 32, ld, ok);      // (wave-uniform pointer test)
     lds16f(gamma_lds + ot * 32 + 16 * h, ga);
     lds16f(beta_lds + ot * 32 + 16 * h, be);
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = (v[q] - mean) * rstd * ga[q] + be[q];
-    if (ok) store16f(y_row + ot * 32, v);
+    tile_store_rows(stage, v, j, h, lane, y_wave + ot * 32, ld, ok);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
   const int j = lane & 31, h = lane >> 5;
   constexpr int STEPS = PASSES * KCH;               // 16-slot steps per block
   const long nblk = ((long)g.M + 127) / 128;
-  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // bias[N] | gamma[256] | beta[256]
+  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // bias[N] | gamma[256] | beta[256] | four wave-private store patches
+  float* stage = reinterpret_cast<float*>(smem + RING_BYTES + 4 * (PASSES * 256 + 512) + wave * STG_BYTES_PER_WAVE);
   const float* xb = reinterpret_cast<const float*>(g.x);
   float* cb = reinterpret_cast<float*>(g.C);
   float* preb = reinterpret_cast<float*>(g.pre_ln_out);
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
       }
       // ---------------- epilogue of this pass ----------------
       const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;
-      float* crow = cb + tok * g.ldc + pass * 256 + 16 * hb;
+      float* cwave = cb + (blk * 128 + wave * 32) * g.ldc + pass * 256;      // row 0 of this wave's strip, this pass's columns
       const float* rrow_p = rb + (HR ? rrow * g.ldr + pass * 256 + 16 * hb : 0);
       float rnext[16];
       if (HR) load16f(rrow_p, rnext);
@@ -360,14 +361,14 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
         if (LN) {
 #pragma unroll
           for (int q = 0; q < 16; q++) acc[ot][q] = v[q];
-        } else if (wave_ok && !dbg_nostore) {
-          store16f(crow + ot * 32, v);
+        } else {
+          tile_store_rows(stage, v, j, hb, lane, cwave + ot * 32, g.ldc, wave_ok && !dbg_nostore);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (LN) {
-        x3_ln_rows(acc, prm_b + g.N, prm_b + g.N + 256, hb, g.ln_mean, g.ln_rstd, tok, wave_ok,
-                   preb != nullptr ? preb + tok * g.ldc + 16 * hb : nullptr, crow);
+        x3_ln_rows(acc, prm_b + g.N, prm_b + g.N + 256, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, stage, j, lane,
+                   preb != nullptr ? preb + (blk * 128 + wave * 32) * g.ldc : nullptr, cwave, g.ldc);
       }
     }
   }
@@ -500,7 +501,8 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
   const int j = lane & 31, h = lane >> 5;
   constexpr int p = PT * 32;
   const long nblk = ((long)g.M + 127) / 128;
-  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // b1[p] | b2[256] | gamma[256] | beta[256]
+  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // b1[p] | b2[256] | gamma[256] | beta[256] | four wave-private store patches
+  float* stage = reinterpret_cast<float*>(smem + RING_BYTES + 4 * (PT * 32 + 768) + wave * STG_BYTES_PER_WAVE);
   const float* xb = reinterpret_cast<const float*>(g.x);
   float* yb = reinterpret_cast<float*>(g.y);
   float* preb = reinterpret_cast<float*>(g.pre_ln_out);
@@ -610,16 +612,15 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
         x3_split8<E>(v + 8, hi, lo);
         hf[1].a = __builtin_bit_cast(u4v, hi); hf[1].b = __builtin_bit_cast(u4v, lo);
       }
-      const bool st_h = hob != nullptr && wave_ok && !(g.pad & 16);
-      float* hp = hob + tok * g.ldh + hcol0;
+      const bool st_h = hob != nullptr;                                     // (wave-uniform)
+      float* hwave = hob + (blk * 128 + wave * 32) * g.ldh + t * 32;          // row 0 of this wave's strip, this hidden tile's columns
       // ---- second GEMM, K-slice t (u = 0, 1); the hidden tile's stores ride behind the first MFMAs ----
       P.begin_slot();
       if (!(g.pad & 512))
       x3_slot_tiles<E>(abase + 2 * SLOT_BYTES, hf[0], yacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<2>();
-        if (i == 4 && st_h) { reinterpret_cast<float4*>(hp)[0] = make_float4(v[0], v[1], v[2], v[3]); reinterpret_cast<float4*>(hp)[1] = make_float4(v[4], v[5], v[6], v[7]); }
-        if (i == 8 && st_h) { reinterpret_cast<float4*>(hp)[2] = make_float4(v[8], v[9], v[10], v[11]); reinterpret_cast<float4*>(hp)[3] = make_float4(v[12], v[13], v[14], v[15]); }
+        if (i == 4 && st_h) tile_store_rows(stage, v, j, hb, lane, hwave, g.ldh, wave_ok && !(g.pad & 16));
       });
       P.begin_slot();
       if (!(g.pad & 512))
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
 
     // ---------------- final epilogue of the block ----------------
     const uint64_t rowq = ((uint64_t)tok * 256ull) >> 2;
-    float* yrow = yb + tok * g.ldy + 16 * hb;
+    float* ywave = yb + (blk * 128 + wave * 32) * g.ldy;
     const float* rrow_p = rb + (has_res ? tokc * g.ldr + 16 * hb : 0);
 #pragma unroll
     for (int ot = 0; ot < 8; ot++) {
@@ -657,14 +658,14 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       if (MODE == 0) {
 #pragma unroll
         for (int q = 0; q < 16; q++) yacc[ot][q] = v[q];
-      } else if (wave_ok) {
-        store16f(yrow + ot * 32, v);
+      } else {
+        tile_store_rows(stage, v, j, hb, lane, ywave + ot * 32, g.ldy, wave_ok);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE == 0) {
-      x3_ln_rows(yacc, prm_b + p + 256, prm_b + p + 512, hb, g.ln_mean, g.ln_rstd, tok, wave_ok,
-                 preb != nullptr ? preb + tok * g.ldy + 16 * hb : nullptr, yrow);
+      x3_ln_rows(yacc, prm_b + p + 256, prm_b + p + 512, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, stage, j, lane,
+                 preb != nullptr ? preb + (blk * 128 + wave * 32) * g.ldy : nullptr, ywave, g.ldy);
     }
   }
   P.drain();
@@ -688,7 +689,7 @@ int set_lds(K kernel, int lds, const char* what) {
 }
 template <int E, bool LN, int PASSES, int KCH, bool HR>
 int launch_xl(const hftt_strip_desc& d, hipStream_t st) {
-  const int lds = RING_BYTES + 4 * (d.N + 512);
+  const int lds = RING_BYTES + 4 * (PASSES * 256 + 512) + 4 * STG_BYTES_PER_WAVE;
   static int attr = 0;
   if (lds > attr) { if (int rc = set_lds(x3_linear_kernel<E, LN, PASSES, KCH, HR>, lds, "x3_strip_linear")) return rc; attr = lds; }
   const int cus = n_cus();
@@ -712,7 +713,7 @@ int launch_xn(const hftt_strip_desc& d, hipStream_t st) {
 }
 template <int MODE>
 int launch_xm(const hftt_ffn_desc& d, hipStream_t st) {
-  const int lds = RING_BYTES + 4 * (d.p + 768);
+  const int lds = RING_BYTES + 4 * (d.p + 768) + 4 * STG_BYTES_PER_WAVE;
   static int attr = 0;
   if (lds > attr) { if (int rc = set_lds(x3_mlp_kernel<MODE, 16>, lds, "x3_strip_mlp")) return rc; attr = lds; }
   const int cus = n_cus();

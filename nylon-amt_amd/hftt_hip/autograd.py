@@ -31,10 +31,23 @@ class HfttModelFunction(torch.autograd.Function):
                 buf.zero_()
             else:
                 buf.copy_(g.reshape(buf.shape))
-        eng.backward(ctx.B, ctx.generation)
         # The reference loop calls optimizer.zero_grad() every step (train.py:89; set_to_none since torch 2.0), so p.grad is None here
-        # and autograd simply adopts what it is handed: views of the flat gradient buffer, no 22 MB copy per step.  If a caller keeps
-        # gradients across backward passes (accumulation), the views would be summed into themselves -- then, and only then, copy.
-        alias_ok = all(p.grad is None for p in ctx.params)
-        grads = eng.grad_views(None if alias_ok else eng.flat_grads.clone())
+        # and autograd simply adopts what it is handed: views of the flat gradient buffer, no 22 MB copy per step.
+        # A caller that KEEPS gradients across backward passes (accumulation, zero_grad(set_to_none=False)) may be holding exactly those
+        # views from an earlier pass: the engine's backward overwrites the flat buffer, i.e. the held gradients, before autograd adds the
+        # new ones into them (the result would be 2 * g2 instead of g1 + g2).  Then the old contents are put back and the new gradients
+        # are handed over as a copy.
+        flat = eng.flat_grads
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        held = [p for p in ctx.params if p.grad is not None]
+        aliased = any(lo <= p.grad.data_ptr() < hi for p in held)
+        old = flat.clone() if aliased else None
+        eng.backward(ctx.B, ctx.generation)
+        if not held:
+            grads = eng.grad_views(None)
+        else:
+            new = flat.clone()
+            if aliased:
+                flat.copy_(old)
+            grads = eng.grad_views(new)
         return (None, None, None) + tuple(grads)

@@ -621,7 +621,7 @@ class HfttEngine:
             hb = 'true' if (flags & 7) == 7 else 'false'
             long_rows = (hb == 'true' and dh == 64 and self.npass == 1 and 128 < Lk <= 256 and 128 < Lq <= 256 and not probs
                          and os.environ.get('HFTT_ATTN_FWD8', '1')[:1] != '0')                   # csrc/attn_fwd8.hip: hftt_attn_fwd8_try
-            meta = {'kernel': 'attn_fwd8_kernel' if long_rows else (('x3_attn_fwd_kernel<%d, %d>' % (kt, dh)) if self.npass == 2 else
+            meta = {'kernel': 'attn_fwd8_kernel' if long_rows else (('x3_attn_fwd_kernel<%d, %d, %d>' % (kt, dh, 8 if kt == 8 else 4)) if self.npass == 2 else
                                                                      'attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb)), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
                     # q, k, v, out + the row statistics (max, 1/sum) + the attention map where it is a model output (fp32, mandatory)
                     'bytes': qkv_bytes + eo * n_seq * Lq * self.d + 8.0 * n_seq * H * Lq + (4.0 * n_seq * H * Lq * Lk if probs else 0.0),

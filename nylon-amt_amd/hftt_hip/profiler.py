@@ -52,8 +52,14 @@ class LaunchProfiler:
             self.step_done()
         out = {}
         for key, d in self.samples.items():
-            med = statistics.median(d['ms'])
-            fixed = [med if (t > 3.0 * med and t > med + 0.05) else t for t in d['ms']]
+            # host-stall filter: an interval far above the median OF ITS OWN SHAPE is a stalled host, not a long kernel (one symbol serves
+            # launches of very different size -- S_e and S_n tokens, 256 x 256 and 88 x 88 attention -- so the median is taken per shape)
+            shapes = [tuple(m.get('shape', ())) for m in d['meta']] if len(d['meta']) == len(d['ms']) else [()] * len(d['ms'])
+            by_shape = {}
+            for sh, t in zip(shapes, d['ms']):
+                by_shape.setdefault(sh, []).append(t)
+            meds = {sh: statistics.median(v) for sh, v in by_shape.items()}
+            fixed = [meds[sh] if (t > 3.0 * meds[sh] and t > meds[sh] + 0.05) else t for sh, t in zip(shapes, d['ms'])]
             out[key] = {'launches': len(fixed), 'ms': sum(fixed), 'flops': d['flops'], 'bytes': d['bytes'],
                         'stalls': sum(1 for a, b in zip(fixed, d['ms']) if a != b), 'meta': d['meta']}
         return out

@@ -78,6 +78,10 @@ class FusedAdam(torch.optim.Optimizer):
                 self.step_count = int(old[p]['step'])
             st['step'] = torch.tensor(float(self.step_count))
             st['exp_avg'], st['exp_avg_sq'] = m, v
+        ctr = getattr(self, '_pending_counter', None)
+        if ctr is not None:                       # a checkpoint loaded before any engine existed: resume its dropout stream position
+            engine.step_counter = int(ctr)
+            self._pending_counter = None
 
     def _find_engine(self):
         if self._model is not None:
@@ -114,12 +118,18 @@ class FusedAdam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)          # torch's layout: state tensors are fresh copies, param_groups restored
         steps = [int(s['step']) for s in self.state.values() if 'step' in s]
         self.step_count = max(steps) if steps else 0
+        for g in self.param_groups:                  # what the fused kernel does not implement must not be dropped silently
+            if g.get('weight_decay', 0) != 0 or g.get('amsgrad', False) or g.get('maximize', False):
+                raise HfttError('FusedAdam: the loaded state asks for weight_decay / amsgrad / maximize, which the fused Adam kernel does not do '
+                                '(reference: optim.Adam(model.parameters(), lr), m_training.py:146)')
         eng, self.engine, self.exp_avg = self.engine, None, None
+        self._pending_counter = None
         if eng is not None:
             self.attach(eng)                         # copy the loaded moments into the flat buffers
             if ctr is not None:
-                eng.step_counter = int(ctr)
-        self._pending_counter = ctr
+                eng.step_counter = int(ctr)          # applied now: a TrainStep built later must not rewind the dropout stream again
+        else:
+            self._pending_counter = ctr              # no engine yet: applied when one is attached (attach / TrainStep)
 
 
 class TrainStep:

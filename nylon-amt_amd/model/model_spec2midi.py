@@ -36,14 +36,16 @@ class Model_SPEC2MIDI(nn.Module):
         super().__init__()
         self.encoder_spec2midi = encoder
         self.decoder_spec2midi = decoder
-        self.hftt_precision = os.environ.get('HFTT_PRECISION', 'parity')   # 'parity' (exact-fp32 MFMA, <= 1e-3 of the reference) or 'bf16' (throughput mode)
+        # 'x3' (default: split fp16 / bf16 operands in three bf16-rate MFMA passes, fp32 tensors -- outputs within 1e-3 of the reference,
+        # measured 1e-4), 'bf16' (single-pass throughput mode, ~3e-2) or 'parity' (exact-fp32 MFMA, the round-1 form of the 1e-3 mode)
+        self.hftt_precision = os.environ.get('HFTT_PRECISION', 'x3')
         self.hftt_seed = 1234
 
     def __setstate__(self, state):
         """A checkpoint written by the REFERENCE (pickle.dump(model), m_training.py:372-373; amt.py:24-25 loads it) unpickles into these
         classes by module path; it carries the reference's attributes only, so the engine settings get their defaults here."""
         super().__setstate__(state)
-        self.__dict__.setdefault('hftt_precision', os.environ.get('HFTT_PRECISION', 'parity'))
+        self.__dict__.setdefault('hftt_precision', os.environ.get('HFTT_PRECISION', 'x3'))
         self.__dict__.setdefault('hftt_seed', 1234)
 
     # ---- engine management -------------------------------------------------------------------

@@ -101,8 +101,17 @@ def train(model, iterator, optimizer,
             print('(5) loss:' + str(loss.size()))
             print(loss)
         loss.backward()
-        if sync is not None:                       # p.grad are views of the flat gradient buffer: one all-reduce, then the mean
-            flat = model.hftt_engine().flat_grads
+        if sync is not None:                       # one all-reduce of the flat gradient buffer, then the mean
+            eng = model.hftt_engine()
+            flat = eng.flat_grads
+            # p.grad are normally views of the flat buffer (autograd adopts what HfttModelFunction.backward hands it).  Where that is not so
+            # (gradients kept across steps, a hook that re-created p.grad) the reduced buffer would never reach the optimizer and the ranks
+            # would drift apart silently: bring such gradients into the buffer and point p.grad at it.
+            base = flat.data_ptr()
+            for _, p, o, n in eng._bound:
+                if p.grad is not None and p.grad.data_ptr() != base + 4 * o:
+                    flat[o:o + n].copy_(p.grad.reshape(-1))
+                    p.grad = flat[o:o + n].view(p.shape)
             sync.begin_step()
             flat.mul_(sync(flat))
         optimizer.step()

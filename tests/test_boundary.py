@@ -108,3 +108,20 @@ def test_bench_measured_leg_is_oracle_free_and_configs_match():
     x, lab = bench.synthetic_batch(bench.CONFIGS['tiny'], 2, 1, 'cpu')
     assert x.shape == (2, 256, 192) and x.min() >= -18.420681 - 1e-6 and x.max() <= 6.0
     assert [t.shape for t in lab] == [(2, 128, 88)] * 4 and lab[3].dtype == torch.int64 and int(lab[3].max()) < 128
+
+
+@pytest.mark.parametrize('p', [0.1, 0.25, 0.5, 0.3])
+def test_dropout_is_unbiased(p):
+    """nn.Dropout's contract (model_spec2midi.py:95, 348, 376): E[dropout(x)] = x.  The device generator keeps an element with probability
+    thr / 256 (8-bit threshold) and scales the kept ones by 256 / thr (csrc/hftt_common.h: hftt_keep_scale), NOT by 1 / (1 - p): the mean
+    of keep * scale over many elements is 1 to sampling noise for every p (with 1 / (1 - p) it was 0.9983 at p = 0.1)."""
+    import numpy as np
+    n = 1 << 22
+    keep = util.keep_mask(0x1234ABCD, 7, np.arange(n, dtype=np.uint64), p)
+    sc = util.keep_scale(p)
+    mean = float(keep.mean()) * sc
+    assert abs(mean - 1.0) < 1e-3, (p, mean)
+    thr = round(256.0 / sc)
+    assert abs(sc * thr - 256.0) < 1e-3 and abs(thr / 256.0 - (1.0 - p)) <= 0.5 / 256 + 1e-9
+    from hftt_hip.engine import keep_scale
+    assert keep_scale(p) == sc and keep_scale(0.0) == 1.0

@@ -45,6 +45,34 @@ def test_dataset_assembly_reproduces_the_fixture_store():
     assert np.all(store['feature'][:4] == np.float32(np.log(1e-8)))                                 # padding value :105-113
 
 
+@pytest.mark.parametrize('tag', ['raw', 'scaled'])
+def test_assemble_store_equals_the_reference_make_dataset(tag):
+    """corpus.make_dataset.assemble_store against the arrays the REFERENCE's make_dataset (corpus/make_dataset.py:11-239) wrote for the same
+    per-file features / labels (tests/golden/make_golden_r3.py ran it): concatenation, padding, idx, a label track longer / shorter than
+    its feature array, and both feature branches (:100-116: raw + log(log_offset) padding, or scaled by max_value + zero padding); plus the
+    two config keys its __main__ writes back (:274-278, :305-306)."""
+    import copy
+    from corpus.make_dataset import assemble_store, prepare_config, finalize_config
+    g = np.load(os.path.join(G, 'store.npz'))
+    cfg = {'feature': {'mel_bins': 16, 'log_offset': 1e-8, 'sr': 16000, 'hop_sample': 256},
+           'input': {'margin_b': 4, 'margin_f': 4, 'num_frame': 8},
+           'midi': {'note_min': 21, 'num_note': 6, 'num_velocity': 8}}
+    cfg = prepare_config(copy.deepcopy(cfg), float(g[tag + '.max_value']))
+    n_files = len([k for k in g.files if k.startswith('in.') and k.endswith('.feature')])
+    feats = [g['in.%d.feature' % i] for i in range(n_files)]
+    labels = [{k: g['in.%d.%s' % (i, k)] for k in ('onset', 'offset', 'mpe', 'velocity')} for i in range(n_files)]
+    store = assemble_store(feats, labels, cfg)
+    for mine, theirs in (('idx', 'idx'), ('feature', 'feature'), ('label_mpe', 'label_mpe'), ('label_onset', 'label_onset'),
+                         ('label_offset', 'label_offset'), ('label_velocity', 'label_velocity')):
+        ref = g['%s.%s' % (tag, theirs)]
+        assert store[mine].shape == ref.shape and store[mine].dtype == ref.dtype, (mine, store[mine].dtype, ref.dtype)
+        assert np.array_equal(store[mine], ref), mine
+    finalize_config(cfg)
+    assert isinstance(cfg['input']['min_value'], float) and cfg['input']['min_value'] == float(g[tag + '.min_value'])
+    assert cfg['feature']['n_bins'] == int(g[tag + '.n_bins']) == cfg['feature']['mel_bins']
+    assert cfg['input']['max_value'] == float(g[tag + '.max_value'])
+
+
 @pytest.mark.parametrize('n_slice', [1, 4])
 def test_mydataset_equals_the_reference_class(tmp_path, n_slice):
     MyDataset, _, synth_store = _mods()
@@ -94,7 +122,7 @@ def test_reference_pickle_loads_into_this_model():
         model = pickle.load(f)
     assert type(model) is M.Model_SPEC2MIDI and type(model.encoder_spec2midi.layers_freq[0]) is M.EncoderLayer
     assert model.hftt_config() == cfg
-    assert model.hftt_precision in ('parity', 'bf16') and model.training is False
+    assert model.hftt_precision in ('x3', 'parity', 'bf16') and model.training is False
     sd = model.state_dict()
     keys = [k[3:] for k in g.files if k.startswith('sd.')]
     assert sorted(sd.keys()) == sorted(keys)

@@ -119,7 +119,8 @@ def test_attention_fwd_bwd(dev, n, H, Lq, Lk, dh, npass):
     assert max_err(probs, p_ref) < (2e-6 if npass == 3 else 2e-2)
     assert abs(probs.sum(-1).mean().item() - 1.0) < 1e-4
     assert rel_err(out, o_ref) < tol * 2
-    assert max_err(lse[..., 0] - torch.log(lse[..., 1]), lse_ref) < (1e-4 if npass == 3 else 5e-2)
+    mscale = 1.0 if npass == 3 else 1.0 / math.sqrt(d // H)        # include/hftt_hip.h: the bf16 kernels keep the RAW row maximum
+    assert max_err(lse[..., 0] * mscale - torch.log(lse[..., 1]), lse_ref) < (1e-4 if npass == 3 else 5e-2)
     dq, dk, dv = ops.attn_bwd(dq_, dk_, dv_, out, lse, do.to(dev), H, npass=npass)
     assert rel_err(dq, q64.grad) < tol * 4
     assert rel_err(dk, k64.grad) < tol * 4

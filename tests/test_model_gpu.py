@@ -588,3 +588,39 @@ def test_frozen_weights_prepare_once_and_follow_explicit_changes(dev):
     assert not torch.equal(d[0], c[0])
     for u, v in zip(d, e):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize('precision', ['x3', 'parity'])
+def test_gradient_accumulation_over_two_backwards(dev, precision):
+    """Two loss.backward() calls WITHOUT zeroing in between (the autograd / compatibility path): p.grad must hold g1 + g2.  After the first
+    backward p.grad is a view of the engine's flat gradient buffer, which the second backward overwrites before autograd accumulates --
+    hftt_hip/autograd.py puts the held gradients back and hands the new ones over as a copy."""
+    cfg, B = MINI, 2
+    model = util.build_model(cfg, 31)
+    util.perturb(model, 32)
+    sd = util.sd_cpu(model)
+    x1 = O.synth_spec(B, cfg, salt=3) * 0.5; x2 = O.synth_spec(B, cfg, salt=4) * 0.5
+    l1 = O.synth_labels(B, cfg, salt=5); l2 = O.synth_labels(B, cfg, salt=6)
+    _, _, g1 = _oracle_run(sd, cfg, x1, l1)
+    _, _, g2 = _oracle_run(sd, cfg, x2, l2)
+    model = model.to(dev)
+    model.hftt_precision = precision
+    model.train()
+    for x, l in ((x1, l1), (x2, l2)):
+        O.spec2midi_loss(model(x.to(dev)), *_to_dev(l, dev)).backward()
+    tol = 3e-3 if precision == 'x3' else 2e-3
+    for name, p in model.named_parameters():
+        ref = g1[name] + g2[name]
+        scale = max(ref.abs().max().item(), 1e-6)
+        if ref.abs().max().item() < 1e-7:
+            continue
+        assert max_err(p.grad, ref) / scale < tol, (name, max_err(p.grad, ref) / scale)
+        single = max_err(p.grad, g2[name] * 2) / scale          # what the aliasing bug produced
+        assert single > 10 * tol or max_err(g1[name], g2[name]) / scale < 20 * tol, name
+    # zero_grad(set_to_none=False) keeps the views; a further backward then yields exactly that pass's gradients
+    model.zero_grad(set_to_none=False)
+    O.spec2midi_loss(model(x1.to(dev)), *_to_dev(l1, dev)).backward()
+    for name, p in model.named_parameters():
+        scale = max(g1[name].abs().max().item(), 1e-6)
+        if g1[name].abs().max().item() >= 1e-7:
+            assert max_err(p.grad, g1[name]) / scale < tol, name

@@ -221,6 +221,54 @@ def test_reference_dat_resume_then_one_step_equals_torch_adam(dev):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # data parallel: two real processes, one engine each (both on cuda:0 of the one-GPU box), gloo as the transport
+def _ddp_compat_worker(rank, world, port, tmp):
+    """The reference's loop unchanged (torch.optim.Adam -> the autograd / compatibility path of training.train) under world 2, with the
+    optimizer told to KEEP gradient tensors across steps (zero_grad(set_to_none=False)): p.grad then is a tensor of its own, not a view of
+    the engine's flat gradient buffer, and the reduced buffer must still be what the optimizer steps on."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import functools
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from training import train as T
+    from training.dataset import MyDataset, DeviceClipStore
+    from corpus.make_dataset import synth_store
+    dev = torch.device('cuda:0')
+    cfg = MINI
+    conf = _ds_config(cfg)
+    store = synth_store(conf, [70, 45], seed=11)
+    ds = MyDataset.from_arrays(store['feature'], store['label_onset'], store['label_offset'], store['label_mpe'], store['label_velocity'],
+                               store['idx'], conf, 4)
+    clips = DeviceClipStore(ds, dev)
+    model = util.build_model(cfg, 100 + rank, dropout=0.0).to(dev)            # different init per rank: the broadcast must fix it
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt.zero_grad = functools.partial(opt.zero_grad, set_to_none=False)
+    for p in model.parameters():                                               # gradients that exist before the first backward
+        p.grad = torch.zeros_like(p)
+    crits = [nn.BCELoss(), nn.BCELoss(), nn.BCELoss(), nn.CrossEntropyLoss(), nn.BCELoss(), nn.BCELoss(), nn.BCELoss(), nn.CrossEntropyLoss()]
+    loader = clips.loader(2, rank=rank, world=world)
+    losses = [T.train(model, loader, opt, *crits, 1.0, 1.0, dev, False) for _ in range(2)]
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])                                        # the ranks stay in lockstep
+    if rank == 0:
+        torch.save({'flat': flat, 'losses': losses}, os.path.join(tmp, 'ddp_compat.pt'))
+    dist.destroy_process_group()
+
+
+def test_two_process_compat_path_stays_in_lockstep(dev, tmp_path):
+    """... and equals the fast path's result on the same shards (FusedAdam + fused loss): same losses, same parameters to Adam's noise."""
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_ddp_compat_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, port + 1, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / 'ddp_compat.pt', weights_only=False)
+    b = torch.load(tmp_path / 'ddp.pt', weights_only=False)
+    for x, y in zip(a['losses'], b['losses']):
+        assert abs(x - y) < 1e-4 * abs(y), (a['losses'], b['losses'])
+    assert (a['flat'] - b['flat']).abs().mean().item() < 2e-5
+
+
 def _ddp_worker(rank, world, port, tmp):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -330,3 +378,19 @@ def test_two_process_inference_scatter_equals_one_engine(dev, tmp_path):
         for k in range(8):
             assert r['o%d' % k].dtype == one[k].dtype and np.array_equal(r['o%d' % k], one[k]), (rank, k)
             assert np.array_equal(r['s%d' % k], one_s[k]), (rank, 's', k)
+
+
+def test_one_rank_rccl_rehearsal_of_the_bench_ddp_branch(dev):
+    """bench.py's N > 1 branch -- init_process_group('nccl') = RCCL, parameter broadcast, the three bucket all-reduces on the side stream,
+    the barriers, the all-gathered device list in the JSON line -- with a ONE-rank group on the one GPU of this box (the multi-GPU node
+    only exists at the driver's round end)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HFTT_BENCH_FORCE_DDP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(39500 + (os.getpid() % 2000)))
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, 'bench.py'), '--config', 'tiny', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-extras', '--no-profile'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['value'] > 0 and line['n_gpus'] == 1
+    assert line['collective'] == {'backend': 'nccl', 'ranks': 1, 'devices': line['collective']['devices']} and len(line['collective']['devices']) == 1

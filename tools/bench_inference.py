@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Inference plan only (model.eval() forward of the paper-size model, batch 8, bf16 mode): the command the inference-side rocprofv3 passes
+"""Inference plan only (model.eval() forward, default: paper-size model, batch 8, x3 mode): the command the inference-side rocprofv3 passes
 of tools/profile_bench.sh wrap.  Prints clips/s."""
 import argparse
 import os
@@ -14,11 +14,13 @@ import bench   # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--batch', type=int, default=8)
+ap.add_argument('--precision', default='x3', choices=['x3', 'bf16', 'parity'])
+ap.add_argument('--config', default='paper', choices=['paper', 'tiny'])
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
-cfg = bench.CONFIGS['paper']
+cfg = bench.CONFIGS[args.config]
 model = bench.build_model(cfg, 1234, 0.1, dev)
-model.hftt_precision = 'bf16'
+model.hftt_precision = args.precision
 model.eval()
 model.hftt_freeze_weights(True)
 x, _ = bench.synthetic_batch(cfg, args.batch, 1234, dev)
