@@ -247,9 +247,10 @@ typedef struct {
   const float* k; int64_t k_seq_stride; int64_t ldk;
   const float* v; int64_t v_seq_stride; int64_t ldv;
   float* out; int64_t o_seq_stride; int64_t ldo;
-  float* lse;                 /* [n_seq, n_heads, Lq, 2]: (row max, 1 / sum(exp(score - max))); the max is of the scaled scores when
-                                 npass == 3 and of the RAW Q.K^T (before the 1/sqrt(dh)) when npass is 1 or 2 -- an opaque pair between
-                                 a forward and the backward of the SAME npass */
+  float* lse;                 /* [n_seq, n_heads, Lq, 2]: (row max, 1 / sum(exp(score - max))); the max is of the scaled scores, except
+                                 in the npass == 2 kernels and the npass == 1 kernels with q, k, v AND out stored as bf16, which keep the
+                                 max of the RAW Q.K^T (before the 1/sqrt(dh)) -- an opaque pair between a forward and the backward of
+                                 the SAME npass and storage flags */
   float* probs;               /* [n_seq, n_heads, Lq, Lk] or NULL */
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   /* backward only */

@@ -136,6 +136,28 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
       }
     }
   }
+  // ---- bf16 forms: the dQ image holds K - mean_key(K).  dQ_i = sum_j dS_ij k_j and sum_j dS_ij = 0 (softmax rows sum to one), so any common
+  //      vector may be taken off the keys -- in exact arithmetic.  With dS rounded to bf16 (and delta formed from the bf16-stored O) the row
+  //      sums are only ~2^-9 |dS|, and that residue times the COMMON part of the keys swamped the signal wherever the keys of a sequence are
+  //      nearly alike (the decoder's self-attention over time: cos(dQ, fp64) = 0.1 .. 0.4); with the mean removed it multiplies only the
+  //      spread of the keys.  The S recompute keeps the raw K (registers, below): the forward's P exactly. ----
+  if (!F32) {
+    constexpr int G = NTHR / DH;                       // row groups: thread = (column c, group gq)
+    static_assert(NTHR % DH == 0 && G >= 1, "one thread per (column, row group)");
+    float* part = reinterpret_cast<float*>(Ss16);      // [G][DH] partial sums (the dS image is not live before stage (g))
+    __syncthreads();
+    const int c = tid % DH, gq = tid / DH;
+    float cs = 0.f;
+    for (int row = gq; row < Lk; row += G) cs += bf2f(Ks16[row * RSK + c]);
+    part[gq * DH + c] = cs;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int u = 0; u < G; u++) mean += part[u * DH + c];
+    mean /= (float)Lk;
+    for (int row = gq; row < Lk; row += G) Ks16[row * RSK + c] = (unsigned short)f2bf(bf2f(Ks16[row * RSK + c]) - mean);
+    // (ordered before stage (i) by the barriers of the query-block loop; `part` is overwritten by stage (g) only after barrier (b))
+  }
   // ---- this wave's K and V rows as B-operand fragments (B[k = dh][col = key]) ----
   const int mykey = wave * 32 + lr;
   const int mykey_c = mykey < Lk ? mykey : Lk - 1;     // clamped address for unconditional loads
@@ -325,7 +347,7 @@ __global__ __launch_bounds__(KT * 64) void attn_bwd_kernel(const hftt_attn_desc 
           float p;
           if (HB) p = __builtin_amdgcn_exp2f((sacc[r] - rs_m[e]) * c2) * rs_i[e];
           else {
-            const float arg = sacc[r] * scale - rs_m[e];
+            const float arg = hftt_attn_scaled<DH, F32>(sacc[r]) - rs_m[e];      // the forward's own scaled score (attn_fwd.hip)
             p = (F32 ? expf(arg) : __expf(arg)) * rs_i[e];
           }
           if (!key_ok) p = 0.f;

@@ -168,11 +168,11 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
 #pragma unroll
       for (int r = 0; r < 16; r++) sacc[kt][r] = 0.f;
     if (F32) {
-      float qf[HD];                                    // Q[q][HD*lh + t] * scale
+      float qf[HD];                                    // Q[q][HD*lh + t], unscaled
 #pragma unroll
       for (int t4 = 0; t4 < HD / 4; t4++) {
         const float4 f = *reinterpret_cast<const float4*>(qp + HD * lh + 4 * t4);
-        qf[4 * t4] = f.x * scale; qf[4 * t4 + 1] = f.y * scale; qf[4 * t4 + 2] = f.z * scale; qf[4 * t4 + 3] = f.w * scale;
+        qf[4 * t4] = f.x; qf[4 * t4 + 1] = f.y; qf[4 * t4 + 2] = f.z; qf[4 * t4 + 3] = f.w;
       }
 #pragma unroll
       for (int kt = 0; kt < KT; kt++)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
         const float4 f1 = hftt_load4(g.q, q_bf, qofs + 16 * s + 8 * lh + 4);
         const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
-        for (int e = 0; e < 8; e++) qh[s][e] = (short)f2bf(v[e] * scale);
+        for (int e = 0; e < 8; e++) qh[s][e] = (short)f2bf(v[e]);
       }
       if (!ABL(g, 2))
 #pragma unroll
@@ -208,6 +208,16 @@ __global__ __launch_bounds__(256, (NPASS == 3 ? 1 : 2)) void attn_fwd_kernel(con
     // p = 2^((s - max) * c2), c2 = scale*log2e.  lse[0] holds that RAW maximum in this mode; the backward recomputes bitwise the same P.
     constexpr float LOG2E = 1.4426950408889634f;
     const float c2 = scale * LOG2E;
+    if (!HB) {
+      // energy = (Q K^T) / sqrt(dh), in the reference's order (model_spec2midi.py:354: the matmul first, then the division): folding the
+      // scale into q instead moves every logit by its own rounding (6e-8 relative: 0.006 at the 1e5 of a first-layer row, 0.6 % in p), and the
+      // backward -- which recomputes P from the raw product -- would then see other probabilities than the forward used.
+      // 1/8 is exact; for sqrt(32) the fp32 mode divides as the reference does.
+#pragma unroll
+      for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[kt][r] = hftt_attn_scaled<DH, F32>(sacc[kt][r]);
+    }
     // 4*lh as a value the optimiser cannot see through: every per-register key number below is then (compile-time constant + lh4) formed
     // where it is used.  Left visible, LICM hoists all KT*16 of them (and their 64-bit forms) out of the query-block loop and spills them.
     int lh4 = 4 * lh;

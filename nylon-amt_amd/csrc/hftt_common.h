@@ -142,6 +142,14 @@ __host__ __device__ inline float hftt_keep_scale(float p) {
   const uint32_t thr = hftt_keep_thr(p);
   return thr > 0u ? 256.0f / (float)thr : 0.0f;
 }
+// energy = (Q K^T) / sqrt(dh) applied to one raw product, the SAME way in a forward and the backward that recomputes its P:
+// dh = 64: x / 8 exactly;  dh = 32: the fp32 mode divides (the reference's own operation, model_spec2midi.py:354), the bf16 mode multiplies.
+template <int DH, bool EXACT>
+__device__ __forceinline__ float hftt_attn_scaled(float x) {
+  if constexpr (DH == 64) return x * 0.125f;
+  else if constexpr (EXACT) return x / sqrtf((float)DH);
+  else return x * (1.0f / sqrtf((float)DH));
+}
 __device__ __forceinline__ bool hftt_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr) {
   const uint32_t w = hftt_hash(seed, site, idx >> 2);
   return ((w >> (8u * ((uint32_t)idx & 3u))) & 0xFFu) < thr;
