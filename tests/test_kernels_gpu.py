@@ -177,6 +177,35 @@ def test_bf16_stream_attention_with_dropout(dev, n, H, Lq, Lk, dh, p):
     assert rel_err(dv.float(), v64.grad) < 3e-2
 
 
+@pytest.mark.parametrize('p', [0.0, 0.1])
+@pytest.mark.parametrize('n,H,Lq,Lk,dh', [(64, 4, 16, 16, 64), (16, 4, 128, 128, 64), (16, 2, 48, 48, 32), (8, 4, 88, 256, 64)])
+def test_bf16_stream_attention_backward_with_nearly_identical_keys(dev, n, H, Lq, Lk, dh, p):
+    """The decoder's self-attention over time at initialisation: the keys of a sequence are one common vector plus a 1 % spread.  dQ = dS.K
+    with sum_j dS_ij = 0 is then a small difference of large terms; with dS rounded to bf16 the single-pass kernel returned cos(dQ, fp64) of
+    0.1 .. 0.4 (and the mode stalled in training with dropout on) until the mean key was taken off the dQ operand (csrc/attn_bwd.hip)."""
+    ops = _ops()
+    bf = torch.bfloat16
+    d = H * dh
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(n, Lq, d, generator=g).to(bf)
+    k = (torch.randn(n, 1, d, generator=g) * 3 + 0.02 * torch.randn(n, Lk, d, generator=g)).to(bf)
+    v = (torch.randn(n, 1, d, generator=g) * 3 + torch.randn(n, Lk, d, generator=g)).to(bf)
+    do = torch.randn(n, Lq, d, generator=g).to(bf)
+    site, seed = 5, 777
+    mask = keep_mask_t(seed, site, (n, H, Lq, Lk), p).double() if p > 0 else None
+    q64, k64, v64 = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    o_ref, _, _ = _attn_ref(q64, k64, v64, H, mask, 1.0 / keep_scale(p))
+    (o_ref * do.double()).sum().backward()
+    a = [t.to(dev) for t in (q, k, v)]
+    out, lse = ops.attn_fwd(*a, H, npass=1, drop_p=p, drop_site=site, drop_seed=seed, out_dtype=bf)
+    dq, dk, dv = ops.attn_bwd(*a, out, lse, do.to(dev), H, npass=1, drop_p=p, drop_site=site, drop_seed=seed, dq_dtype=bf, dkv_dtype=bf)
+
+    def cos(x, y):
+        x = x.double().cpu().flatten(); y = y.flatten()
+        return float(x @ y / (x.norm() * y.norm()))
+    assert cos(dq, q64.grad) > 0.995 and cos(dk, k64.grad) > 0.995 and cos(dv, v64.grad) > 0.995
+
+
 @pytest.mark.parametrize('N', [256, 128, 64])
 def test_ln_bwd(dev, N):
     ops = _ops()

@@ -39,9 +39,9 @@ def traffic(fdir, wdir, out, what):
         fl, wl = f[n].get('FETCH_SIZE', [0]), w[n].get('WRITE_SIZE', [0])
         k[n] = {'launches': len(fl), 'fetch_MB_per_launch_x2_corrected': round(2 * sum(fl) / len(fl) * 1024 / 1e6, 2),
                 'write_MB_per_launch': round(sum(wl) / max(1, len(wl)) * 1024 / 1e6, 2)}
-    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) around `%s` (' + MODE + '); counter '
-                       'values are KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated on a 268 MB copy: '
-                       'profiles/r01_kernel_pmc_traffic.json); per-launch averages over all launches of a kernel symbol' % what, 'kernels': k},
+    json.dump({'note': ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) around `%s` (%s); counter '
+                        'values are KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated on a 268 MB copy: '
+                        'profiles/r01_kernel_pmc_traffic.json); per-launch averages over all launches of a kernel symbol') % (what, MODE), 'kernels': k},
               open(out, 'w'), indent=1)
 
 
