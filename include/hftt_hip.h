@@ -163,6 +163,10 @@ int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_p
  * other form the linear pack (order 0). */
 #define HFTT_SL_X3_F16 16u
 #define HFTT_SL_X3_BF16 32u
+/* fused block in a split mode: h_out / gate are bf16 [M, p] instead of fp32.  The hidden feeds fc_2 from registers at full width either way;
+ * the STORED copy is read only as the ReLU / dropout gate and as an operand of the weight-gradient products (hftt_gemm_tn, npass 4 with
+ * HFTT_TN_X_BF16 / HFTT_TN_DY_BF16), where 8 mantissa bits of one factor leave the gradient's direction untouched. */
+#define HFTT_SL_H_BF16 64u
 /* C[M,N] = epi(x[M,K] . Wl[N,K]^T + bias): same epilogue order as hftt_gemm_nt (relu, out_scale, gate, dropout, residual,
  * LayerNorm over N == 256).  N % 256 == 0; K % 32 == 0 and (K <= 256 or K % 256 == 0); gate is bf16. */
 typedef struct {
@@ -223,9 +227,9 @@ typedef struct {
   float* seg_dw[4];          /* [seg_rows, K] row-major (ld = K_out) */
   float* seg_db[4];          /* [seg_rows] or NULL */
   int32_t K_out;             /* number of K columns to write (<= K), destination leading dim */
-  uint32_t io_flags;         /* HFTT_TN_* (npass 1 only) */
+  uint32_t io_flags;         /* HFTT_TN_*: npass 1 (either / both), npass 4 (ONE of them: that operand is its own hi half, two MFMA passes) */
   void* ws; int64_t ws_bytes;
-} hftt_gemm_tn_desc;          /* npass 4 (split bf16): dY and X fp32, both split on their way into LDS */
+} hftt_gemm_tn_desc;          /* npass 4 (split bf16): dY and X fp32, split on their way into LDS (or one of them stored as bf16) */
 int64_t hftt_gemm_tn_ws_bytes(int32_t M, int32_t N, int32_t K);
 int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream);
 

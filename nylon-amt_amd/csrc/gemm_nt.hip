@@ -287,6 +287,11 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = hftt_keep_scale(g.drop_p);
   float* stage = reinterpret_cast<float*>(smem);
+  // Split modes, full 256-column tiles: the fp32 result leaves through LDS as whole rows (one wave per row, 16 bytes per lane) and the
+  // table add / gate / dropout / residual run there per QUAD of columns.  From the accumulator layout every element paid its own
+  // `row % add_mod`, its own hash and a 4-byte store: the embedding GEMM (K = 96, all epilogue) took 440 us for 268 MB at S_e.
+  const bool rowpass = X3M && !LN && BN == 256 && (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.gate == nullptr || g.ldg % 4 == 0) &&
+                       (g.residual == nullptr || g.ldr % 4 == 0) && ((((uintptr_t)g.C | (uintptr_t)g.gate | (uintptr_t)g.residual | (uintptr_t)g.add_table) & 15) == 0);
 
 #pragma unroll
   for (int i = 0; i < TM; i++) {
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
         float v = acc[i][j][r] + bv;
         if (g.act == 1) v = fmaxf(v, 0.f);
         v *= g.out_scale;
+        if (rowpass) { stage[row_l * Cfg::STAGE_LD + col_l] = v; continue; }      // (wave-uniform)
         if (ok) {
           if (g.add_table != nullptr) v += g.add_table[(long)(row % g.add_mod) * g.N + col];
           if (g.gate != nullptr) {
@@ -320,6 +326,37 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
           else g.C[row * g.ldc + col] = v;
         }
       }
+    }
+  }
+
+  if (rowpass) {
+    __syncthreads();
+    const int col = n0 + lane * 4;
+    for (int rr = 0; rr < BM / 8; rr++) {
+      const int row_l = wave * (BM / 8) + rr;
+      const long row = m0 + row_l;
+      if (row >= g.M) break;   // wave-uniform
+      if (col >= g.N) continue;
+      float4 v = *reinterpret_cast<const float4*>(stage + row_l * Cfg::STAGE_LD + lane * 4);
+      if (g.add_table != nullptr) {
+        const float4 t = *reinterpret_cast<const float4*>(g.add_table + (long)(row % g.add_mod) * g.N + col);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (g.gate != nullptr) {
+        const float4 gv = *reinterpret_cast<const float4*>(g.gate + row * g.ldg + col);
+        v.x = gv.x > 0.f ? v.x * g.gate_scale : 0.f; v.y = gv.y > 0.f ? v.y * g.gate_scale : 0.f;
+        v.z = gv.z > 0.f ? v.z * g.gate_scale : 0.f; v.w = gv.w > 0.f ? v.w * g.gate_scale : 0.f;
+      }
+      if (g.drop_p > 0.f) {
+        const uint32_t k4 = hftt_keep_quad(g.drop_seed, g.drop_site, ((uint64_t)row * (uint64_t)g.N + (uint64_t)col) >> 2, thr);
+        v.x = (k4 & 1u) ? v.x * inv_keep : 0.f; v.y = (k4 & 2u) ? v.y * inv_keep : 0.f;
+        v.z = (k4 & 4u) ? v.z * inv_keep : 0.f; v.w = (k4 & 8u) ? v.w * inv_keep : 0.f;
+      }
+      if (g.residual != nullptr) {
+        const float4 t = *reinterpret_cast<const float4*>(g.residual + (long)(row % g.res_mod) * g.ldr + col);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
     }
   }
 
@@ -964,7 +1001,7 @@ template <int BN, int PREC, bool LN>
 int launch_nt(const hftt_gemm_nt_desc& d, hipStream_t st) {
   using Cfg = NtCfg<BN, PREC>;
   int lds = Cfg::LOOP_BYTES;
-  if (LN && Cfg::STAGE_BYTES > lds) lds = Cfg::STAGE_BYTES;
+  if ((LN || (Cfg::X3M && BN == 256)) && Cfg::STAGE_BYTES > lds) lds = Cfg::STAGE_BYTES;      // (split modes: the row-pass epilogue stages the tile)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BN, PREC, LN>),

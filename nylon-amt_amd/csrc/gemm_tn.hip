@@ -95,7 +95,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   using Cfg = TnCfg<TM, TN, NPASS, DYB, XB>;
   constexpr bool F32 = Cfg::F32, X3M = Cfg::X3M;
   constexpr int EX = X3M ? NPASS : X3_BF16;         // element type of the split
-  static_assert(!(F32 || X3M) || (!DYB && !XB), "bf16-stored operands are a bf16-mode feature");
+  static_assert(!F32 || (!DYB && !XB), "bf16-stored operands: bf16 mode, or ONE side of a split-bf16 product");
+  // x3 with a bf16-stored operand (the saved FFN hidden / its gradient, kept as bf16 for this product only): that operand IS its hi
+  // half, the lo half is zero and the pass that would multiply it is skipped (two MFMAs per fragment pair instead of three)
+  static_assert(!(X3M && DYB && XB), "split product with both operands bf16-stored is the plain bf16 product");
   constexpr int RSY = Cfg::RSY, RSX = Cfg::RSX, TILE_N = Cfg::TILE_N, TILE_K = Cfg::TILE_K;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
         for (int i = 0; i < TM; i++) {
           const unsigned short* p = Ys + (16 * s + frag_row) * RSY + wn4 * TM * 32 + i * 32 + frag_col;
           ah[i] = join4(lds_read_tr16(p), lds_read_tr16(p + 4 * RSY));
-          al[i] = join4(lds_read_tr16(p + BMT * RSY), lds_read_tr16(p + BMT * RSY + 4 * RSY));
+          if (!DYB) al[i] = join4(lds_read_tr16(p + BMT * RSY), lds_read_tr16(p + BMT * RSY + 4 * RSY));
         }
         // one X fragment pair at a time (the next pair is read under this pair's six MFMAs): all TN pairs up front, as hipcc would
         // schedule them, put the 256 x 256 tile over the register budget
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
         {
           const unsigned short* p = Xs + (16 * s + frag_row) * RSX + wk2 * TN * 32 + frag_col;
           bh = join4(lds_read_tr16(p), lds_read_tr16(p + 4 * RSX));
-          bl = join4(lds_read_tr16(p + BMT * RSX), lds_read_tr16(p + BMT * RSX + 4 * RSX));
+          if (!XB) bl = join4(lds_read_tr16(p + BMT * RSX), lds_read_tr16(p + BMT * RSX + 4 * RSX));
         }
 #pragma unroll
         for (int j = 0; j < TN; j++) {
@@ -277,10 +280,17 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
           if (j + 1 < TN) {
             const unsigned short* p = Xs + (16 * s + frag_row) * RSX + wk2 * TN * 32 + (j + 1) * 32 + frag_col;
             nh = join4(lds_read_tr16(p), lds_read_tr16(p + 4 * RSX));
-            nl = join4(lds_read_tr16(p + BMT * RSX), lds_read_tr16(p + BMT * RSX + 4 * RSX));
+            if (!XB) nl = join4(lds_read_tr16(p + BMT * RSX), lds_read_tr16(p + BMT * RSX + 4 * RSX));
           }
 #pragma unroll
-          for (int i = 0; i < TM; i++) acc[i][j] = x3_mma<EX>(ah[i], al[i], bh, bl, acc[i][j]);
+          for (int i = 0; i < TM; i++) {
+            if (!DYB && !XB) acc[i][j] = x3_mma<EX>(ah[i], al[i], bh, bl, acc[i][j]);
+            else {                                            // same order as x3_mma: small terms first
+              if (!DYB) acc[i][j] = X3<EX>::mma(al[i], bh, acc[i][j]);
+              if (!XB) acc[i][j] = X3<EX>::mma(ah[i], bl, acc[i][j]);
+              acc[i][j] = X3<EX>::mma(ah[i], bh, acc[i][j]);
+            }
+          }
           bh = nh; bl = nl;
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -435,7 +445,8 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   }
   HFTT_REQUIRE(((uintptr_t)d->dY & 15) == 0 && ((uintptr_t)d->X & 15) == 0, "gemm_tn: dY/X must be 16-byte aligned");
   HFTT_REQUIRE(d->npass >= 1 && d->npass <= 4, "gemm_tn: npass must be 1 .. 4");
-  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1, "gemm_tn: bf16-stored operands need npass == 1");
+  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1 || (d->npass == 4 && d->io_flags != (HFTT_TN_DY_BF16 | HFTT_TN_X_BF16)),
+               "gemm_tn: bf16-stored operands need npass == 1, or npass == 4 with ONE of them");
   HFTT_REQUIRE(d->n_seg >= 1 && d->n_seg <= 4, "gemm_tn: n_seg must be 1..4");
   HFTT_REQUIRE(d->K_out > 0 && d->K_out <= d->K, "gemm_tn: K_out out of range");
   for (int s = 0; s < d->n_seg; s++) {
@@ -453,10 +464,13 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
     else if (p.tn == 2) rc = launch_tn<1, 2, 3, false, false>(*d, p, st);
     else rc = launch_tn<1, 1, 3, false, false>(*d, p, st);
   } else if (d->npass == 4) {
-    if (p.tm == 2) rc = launch_tn<2, 4, 4, false, false>(*d, p, st);
-    else if (p.tn == 4) rc = launch_tn<1, 4, 4, false, false>(*d, p, st);
-    else if (p.tn == 2) rc = launch_tn<1, 2, 4, false, false>(*d, p, st);
-    else rc = launch_tn<1, 1, 4, false, false>(*d, p, st);
+#define HFTT_TN_GO4(TM_, TN_)                                                     \
+    (dyb ? launch_tn<TM_, TN_, 4, true, false>(*d, p, st) : (xb ? launch_tn<TM_, TN_, 4, false, true>(*d, p, st) : launch_tn<TM_, TN_, 4, false, false>(*d, p, st)))
+    if (p.tm == 2) rc = HFTT_TN_GO4(2, 4);
+    else if (p.tn == 4) rc = HFTT_TN_GO4(1, 4);
+    else if (p.tn == 2) rc = HFTT_TN_GO4(1, 2);
+    else rc = HFTT_TN_GO4(1, 1);
+#undef HFTT_TN_GO4
   } else if (d->npass == 2) {
     if (p.tm == 2) rc = launch_tn<2, 4, 2, false, false>(*d, p, st);
     else if (p.tn == 4) rc = launch_tn<1, 4, 2, false, false>(*d, p, st);

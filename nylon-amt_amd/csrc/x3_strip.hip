@@ -207,6 +207,38 @@ __device__ __forceinline__ void tile_store_rows(float* stage, const float* v, in
   }
 }
 
+// The same tile as bf16 (the saved FFN hidden and its gradient: operands of the weight-gradient products only, HFTT_SL_H_BF16): 64-byte row
+// segments, 16 rows x 4 lanes per store instruction, through the same patch (rows of 40 shorts = 80 B: 16-byte pieces, 8 rows on 8 bank quads).
+__device__ __forceinline__ void tile_store_rows_bf16(float* stage, const float* v, int j, int h, int lane, unsigned short* gtile, long ld, bool ok) {
+  unsigned short* st16 = reinterpret_cast<unsigned short*>(stage);
+  constexpr int RS = 40;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    if ((j >> 4) == half) {
+      unsigned short* w = st16 + (j & 15) * RS + 16 * h;
+      uint4 a, b;
+      a.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); a.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+      a.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); a.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+      b.x = f2bf(v[8]) | ((unsigned)f2bf(v[9]) << 16); b.y = f2bf(v[10]) | ((unsigned)f2bf(v[11]) << 16);
+      b.z = f2bf(v[12]) | ((unsigned)f2bf(v[13]) << 16); b.w = f2bf(v[14]) | ((unsigned)f2bf(v[15]) << 16);
+      reinterpret_cast<uint4*>(w)[0] = a;
+      reinterpret_cast<uint4*>(w)[1] = b;
+    }
+    const int r = lane >> 2;
+    const uint4 t = *reinterpret_cast<const uint4*>(st16 + r * RS + (lane & 3) * 8);
+    if (ok) *reinterpret_cast<uint4*>(gtile + (long)(half * 16 + r) * ld + (lane & 3) * 8) = t;
+  }
+}
+__device__ __forceinline__ void load16h(const unsigned short* p, float* v) {      // 16 bf16 -> fp32
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const uint4 t = reinterpret_cast<const uint4*>(p)[q];
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[8 * q + 2 * e] = bf2f((unsigned short)(w[e] & 0xFFFFu)); v[8 * q + 2 * e + 1] = bf2f((unsigned short)(w[e] >> 16)); }
+  }
+}
+
 // LayerNorm over the 256 features of the lane's token (lane: 128 of them in acc, partner lane ^ 32 the rest), fp32 out
 __device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_lds, const float* beta_lds, int h, float* mean_out, float* rstd_out,
                                            long tok, bool ok, float* stage, int j, int lane, float* pre_wave, float* y_wave, long ld) {
@@ -492,7 +524,8 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
 // backward (bf16 halves).  Stream per hidden tile t: two slots of the first matrix (tile-major: k chunks 0-7, 8-15), then two slots of
 // the second (K-slice t: u = 0, 1).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MODE, int PT>
+// HH: h_out / gate are bf16 [M, p] (HFTT_SL_H_BF16) instead of fp32
+template <int MODE, int PT, bool HH>
 __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
   constexpr int E = (MODE == 0) ? X3_F16 : X3_BF16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -509,6 +542,8 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
   const float* rb = reinterpret_cast<const float*>(g.residual);
   float* hob = reinterpret_cast<float*>(g.h_out);
   const float* gtb = reinterpret_cast<const float*>(g.gate);
+  unsigned short* hob16 = reinterpret_cast<unsigned short*>(g.h_out);
+  const unsigned short* gtb16 = reinterpret_cast<const unsigned short*>(g.gate);
   const bool has_res = (MODE == 1) && g.residual != nullptr;
 
   XPipe P;
@@ -562,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       for (int q = 0; q < 16; q++) yacc[ot][q] = b[q];
     }
     float gnext[16];                                  // mode 1: stored hidden (the gate) of the next tile
-    if (MODE == 1) load16f(gtb + tokc * g.ldg + 16 * hb, gnext);
+    if (MODE == 1) { if (HH) load16h(gtb16 + tokc * g.ldg + 16 * hb, gnext); else load16f(gtb + tokc * g.ldg + 16 * hb, gnext); }
 
     // (a run-time loop: every hidden tile uses ring buffers 0..3 in order, and the body is ~100 MFMAs -- unrolled 16 times the kernel was
     // 14,000 instructions, far beyond the instruction cache)
@@ -585,7 +620,9 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       x3_slot_chunks<E, 0>(abase + 0 * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<0>();
-        if (i == 6 && MODE == 1 && t + 1 < PT) load16f(gtb + tokc * g.ldg + (t + 1) * 32 + 16 * hb, gnext);
+        if (i == 6 && MODE == 1 && t + 1 < PT) {
+          if (HH) load16h(gtb16 + tokc * g.ldg + (t + 1) * 32 + 16 * hb, gnext); else load16f(gtb + tokc * g.ldg + (t + 1) * 32 + 16 * hb, gnext);
+        }
       });
       P.begin_slot();
       if (!(g.pad & 256))
@@ -614,13 +651,17 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       }
       const bool st_h = hob != nullptr;                                     // (wave-uniform)
       float* hwave = hob + (blk * 128 + wave * 32) * g.ldh + t * 32;          // row 0 of this wave's strip, this hidden tile's columns
+      unsigned short* hwave16 = hob16 + (blk * 128 + wave * 32) * g.ldh + t * 32;
       // ---- second GEMM, K-slice t (u = 0, 1); the hidden tile's stores ride behind the first MFMAs ----
       P.begin_slot();
       if (!(g.pad & 512))
       x3_slot_tiles<E>(abase + 2 * SLOT_BYTES, hf[0], yacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<2>();
-        if (i == 4 && st_h) tile_store_rows(stage, v, j, hb, lane, hwave, g.ldh, wave_ok && !(g.pad & 16));
+        if (i == 4 && st_h) {
+          if (HH) tile_store_rows_bf16(stage, v, j, hb, lane, hwave16, g.ldh, wave_ok && !(g.pad & 16));
+          else tile_store_rows(stage, v, j, hb, lane, hwave, g.ldh, wave_ok && !(g.pad & 16));
+        }
       });
       P.begin_slot();
       if (!(g.pad & 512))
@@ -711,15 +752,15 @@ int launch_xn(const hftt_strip_desc& d, hipStream_t st) {
   HFTT_CHECK_LAUNCH("x3_strip_linear");
   return 0;
 }
-template <int MODE>
+template <int MODE, bool HH>
 int launch_xm(const hftt_ffn_desc& d, hipStream_t st) {
   const int lds = RING_BYTES + 4 * (d.p + 768) + 4 * STG_BYTES_PER_WAVE;
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(x3_mlp_kernel<MODE, 16>, lds, "x3_strip_mlp")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(x3_mlp_kernel<MODE, 16, HH>, lds, "x3_strip_mlp")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("x3_strip_mlp: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  hipLaunchKernelGGL((x3_mlp_kernel<MODE, 16>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  hipLaunchKernelGGL((x3_mlp_kernel<MODE, 16, HH>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("x3_strip_mlp");
   return 0;
 }
@@ -769,7 +810,11 @@ int hftt_x3_strip_mlp(const hftt_ffn_desc& d0, hipStream_t st) {
   HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_mlp: tensors are fp32 in the split modes");
   HFTT_REQUIRE(d.mode == 1 || d.residual == nullptr, "x3_strip_mlp: the forward block's residual is its input");
   HFTT_REQUIRE(((d.flags & HFTT_SL_X3_BF16) != 0) == (d.mode == 1), "x3_strip_mlp: mode 0 takes fp16 halves (HFTT_SL_X3_F16), mode 1 bf16 halves");
-  return d.mode == 0 ? launch_xm<0>(d, st) : launch_xm<1>(d, st);
+  if (d.flags & HFTT_SL_H_BF16) {
+    HFTT_REQUIRE((d.h_out == nullptr || d.ldh % 8 == 0) && (d.gate == nullptr || d.ldg % 8 == 0), "x3_strip_mlp: bf16 hidden rows must be 16-byte aligned");
+    return d.mode == 0 ? launch_xm<0, true>(d, st) : launch_xm<1, true>(d, st);
+  }
+  return d.mode == 0 ? launch_xm<0, false>(d, st) : launch_xm<1, false>(d, st);
 }
 
 extern "C" int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_pack_entry* table_dev, int n_entries, int elem, void* stream) {

@@ -23,7 +23,7 @@ import torch
 
 from . import _capi
 from ._capi import (AttnDesc, FfnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
+                    SL_C_BF16, SL_H_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
 
 # precision -> the descriptors' `npass` code (include/hftt_hip.h): 'x3' = split fp16 on forward products (2) and split bf16 on products with a
 # gradient operand (4): three bf16-rate MFMA passes per product, fp32 tensors in HBM, outputs within 1e-3 of the reference (measured 1e-4)
@@ -119,6 +119,10 @@ class HfttEngine:
         # bfs: the bf16 activation / gradient STREAM of the bf16 strip plans.  The x3 strip plans run the same launch sequence on fp32 tensors.
         self.bfs = self.strip and self.sb
         self.x3 = self.npass == 2
+        # x3 strip plans: the STORED copy of the FFN hidden and its gradient dh are bf16.  fc_2 takes the hidden from registers at full width;
+        # the stored copy is read as the ReLU / dropout gate and as ONE factor of the weight-gradient products (8 mantissa bits of one factor
+        # leave dW's direction untouched: tests/test_paper_bf16_gpu.py), and these two tensors were 2 x 537 MB per layer at S_e.
+        self.hh = self.strip and self.x3 and os.environ.get('HFTT_X3_FP32_HIDDEN', '0') != '1'
         self._prepared_frozen = False
         if getattr(self, '_bound', None) is not None:
             self._build_prep()
@@ -416,9 +420,10 @@ class HfttEngine:
         self._site += 1
         return self._site
 
-    def _buf(self, ws, name, *shape, dtype=torch.float32, half=False):
-        """half=True: a GEMM-only tensor -> bf16 when the engine stores such tensors as bf16."""
-        if half and self.sb:
+    def _buf(self, ws, name, *shape, dtype=torch.float32, half=False, hidden=False):
+        """half=True: a GEMM-only tensor -> bf16 when the engine stores such tensors as bf16; hidden=True: the FFN hidden / its gradient
+        (bf16 in the x3 strip plans too)."""
+        if (half and self.sb) or (hidden and self.hh):
             dtype = torch.bfloat16
         t = ws['bufs'].get(name)
         if t is not None:
@@ -535,7 +540,7 @@ class HfttEngine:
         d, p = self.d, self.p
         dsc = FfnDesc()
         dsc.M, dsc.d, dsc.p, dsc.mode = M, d, p, mode
-        dsc.flags = (SL_X3_F16 if mode == 0 else SL_X3_BF16) if self.x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)
+        dsc.flags = ((SL_X3_F16 if mode == 0 else SL_X3_BF16) | (SL_H_BF16 if self.hh else 0)) if self.x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)
         dsc.x, dsc.ldx, dsc.w = x, d, self.Ws(wkey)
         dsc.b1, dsc.b2 = b1, b2
         dsc.h_out, dsc.ldh = h_out, p
@@ -555,20 +560,22 @@ class HfttEngine:
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
         esz = 4.0 if self.x3 else 2.0
-        nbytes = esz * M * d * (2 + (1 if pre_saved else 0) + (1 if residual else 0)) + (esz * M * p if h_out else 0) + (esz * M * p if gate else 0) + 2 * esz * d * p
+        hsz = 2.0 if (self.hh or not self.x3) else 4.0
+        nbytes = esz * M * d * (2 + (1 if pre_saved else 0) + (1 if residual else 0)) + (hsz * M * p if h_out else 0) + (hsz * M * p if gate else 0) + 2 * esz * d * p
         v2 = os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and p == 512 and M % 32 == 0 and not (mode == 0 and residual)
-        meta = {'kernel': ('x3_mlp_kernel<%d, 16>' if self.x3 else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>')) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
+        meta = {'kernel': (('x3_mlp_kernel<%%d, 16, %s>' % ('true' if self.hh else 'false')) if self.x3 else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>')) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
                 'shape': (M, d, p), 'saves': bool(h_out or pre_saved)}
         plan.append((self.lib.hftt_ffn_res_ln_fwd if mode == 0 else self.lib.hftt_ffn_bwd_dx, (C.byref(dsc),), 'ffn_fwd' if mode == 0 else 'ffn_bwd_dx', meta))
         return dsc
 
-    def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0, dy_bf=False, x_bf=False):
+    def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0, dy_bf=False, x_bf=False, dy_hid=False, x_hid=False):
         """segs: list of (row0, rows, dw_addr, db_addr or 0)"""
         need = self.lib.hftt_gemm_tn_ws_bytes(M, N, K)
         ws['tn_need'] = max(ws.get('tn_need', 0), need)
         dsc = GemmTnDesc()
         dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, (4 if self.npass == 2 else self.npass)
-        dy_bf, x_bf = (dy_bf and self.sb), (x_bf and self.sb)
+        # dy_hid / x_hid: this operand is the FFN hidden's gradient / the stored hidden (bf16 in the x3 strip plans as well)
+        dy_bf, x_bf = (dy_bf and self.sb) or (dy_hid and self.hh), (x_bf and self.sb) or (x_hid and self.hh)
         dsc.io_flags = (1 if dy_bf else 0) | (2 if x_bf else 0)
         dsc.dY, dsc.lddy, dsc.X, dsc.ldx = dY, lddy, X, ldx
         dsc.out_scale, dsc.beta = out_scale, beta
@@ -687,7 +694,7 @@ class HfttEngine:
         lse = self._buf(ws, tag + '.lse', n_seq * H * L * 2)
         r1 = self._abuf(ws, tag + '.r1', S, d); x1 = self._abuf(ws, tag + '.x1', S, d)
         m1 = self._buf(ws, tag + '.m1', S); s1 = self._buf(ws, tag + '.s1', S)
-        h = self._buf(ws, tag + '.h', S, p, half=True)
+        h = self._buf(ws, tag + '.h', S, p, half=True, hidden=True)
         r2 = self._abuf(ws, tag + '.r2', S, d); x2 = self._abuf(ws, tag + '.x2', S, d)
         m2 = self._buf(ws, tag + '.m2', S); s2 = self._buf(ws, tag + '.s2', S)
         sites = ws.setdefault('sites', {})
@@ -719,7 +726,7 @@ class HfttEngine:
 
     def _ffn_fwd(self, plan, ws, tag, key, pre, S, x_in, sites, save=True):
         d, p = self.d, self.p
-        h = self._buf(ws, tag + '.h', S, p, half=True)
+        h = self._buf(ws, tag + '.h', S, p, half=True, hidden=True)
         r = self._abuf(ws, tag + '.fr', S, d); x = self._abuf(ws, tag + '.fx', S, d)
         m = self._buf(ws, tag + '.fm', S); s = self._buf(ws, tag + '.fs', S)
         sh, sf = self._new_site(), self._new_site()
@@ -910,9 +917,9 @@ class HfttEngine:
         # LN2 -> FFN
         self._lnb(plan, ws, S, GA, b[tag + '.r2'].data_ptr(), b[tag + '.m2'].data_ptr(), b[tag + '.s2'].data_ptr(), gam,
                   GB, GC if use_drop else 0, sf, dgam, dbet, 0.0, dy_bf=True, dr_bf=True)
-        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True)
+        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True, x_hid=True)
         self._mlp(plan, ws, 1, S, dbr, key + '.ffn_t', GA, h_out=Gh, gate=b[tag + '.h'].data_ptr(), gate_scale=('inv_keep',), residual=GB)
-        self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=True)
+        self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=True, dy_hid=True)
         # LN1 -> attention
         self._lnb(plan, ws, S, GA, b[tag + '.r1'].data_ptr(), b[tag + '.m1'].data_ptr(), b[tag + '.s1'].data_ptr(), gam,
                   GB, GC if use_drop else 0, so, dgam, dbet, 1.0, dy_bf=True, dr_bf=True)
@@ -943,9 +950,9 @@ class HfttEngine:
             dbr = GC if use_drop else GB
             self._lnb(plan, ws, S, GA, b[tag + '.fr'].data_ptr(), b[tag + '.fm'].data_ptr(), b[tag + '.fs'].data_ptr(), gam,
                       GB, GC if use_drop else 0, sf, dgam, dbet, ln_beta, dy_bf=True, dr_bf=True)
-            self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True)
+            self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True, x_hid=True)
             self._mlp(plan, ws, 1, S, dbr, key + '.ffn_t', GA, h_out=Gh, gate=b[tag + '.h'].data_ptr(), gate_scale=('inv_keep',), residual=GB)
-            self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=True)
+            self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=True, dy_hid=True)
             return
         self._lnb(plan, ws, S, GA, b[tag + '.fr'].data_ptr(), b[tag + '.fm'].data_ptr(), b[tag + '.fs'].data_ptr(), gam,
                   GB, GC if use_drop else 0, sf, dgam, dbet, ln_beta)
@@ -980,12 +987,12 @@ class HfttEngine:
         nGA = self._abuf(ws, 'g.nA', Sn, d).data_ptr(); nGB = self._abuf(ws, 'g.nB', Sn, d).data_ptr()
         hz = 2 if self.sb else 4
         nGC = self._buf(ws, 'g.nC', Sn, d, half=True).data_ptr(); nGD = self._abuf(ws, 'g.nD', Sn, d).data_ptr()
-        nGh = self._buf(ws, 'g.nh', Sn, p, half=True).data_ptr(); nGq = self._buf(ws, 'g.nq', Sn, 3 * d, half=True).data_ptr()
+        nGh = self._buf(ws, 'g.nh', Sn, p, half=True, hidden=True).data_ptr(); nGq = self._buf(ws, 'g.nq', Sn, 3 * d, half=True).data_ptr()
         nGx = self._buf(ws, 'g.nx', Sn, d, half=True).data_ptr()
         q1f = self._buf(ws, 'g.q1f', Sn, d).data_ptr() if bs else 0          # layer zero's per-sequence dq stays fp32 (summed over sequences)
         eGA = self._abuf(ws, 'g.eA', Se, d).data_ptr(); eGB = self._abuf(ws, 'g.eB', Se, d).data_ptr()
         eGC = self._buf(ws, 'g.eC', Se, d, half=True).data_ptr()
-        eGh = self._buf(ws, 'g.eh', Se, p, half=True).data_ptr(); eGq = self._buf(ws, 'g.eq', Se, 3 * d, half=True).data_ptr()
+        eGh = self._buf(ws, 'g.eh', Se, p, half=True, hidden=True).data_ptr(); eGq = self._buf(ws, 'g.eq', Se, 3 * d, half=True).data_ptr()
         eGx = self._buf(ws, 'g.ex', Se, d, half=True).data_ptr()
         dlog = self._buf(ws, 'g.dlog', Sn, self.NHp).data_ptr()
         cs_n = max(F * d, N * d, T * d)

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
+                    SL_C_BF16, SL_H_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
 
 
 def _stream(dev):
@@ -191,18 +191,18 @@ def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, g
     return (Cout,) + extra if extra else Cout
 
 
-def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_o=0, seed=0, save_hidden=True, save_pre=True, residual=None, x3=False):
+def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_o=0, seed=0, save_hidden=True, save_pre=True, residual=None, x3=False, hidden_bf16=False):
     """Fused FFN block: y = LN(x + drop(fc_2(drop(relu(fc_1 x))))) -> (y, hidden | None, pre_ln | None, mean, rstd); all bf16
-    (x3: all fp32, wpack from x3_ffn_pack)."""
+    (x3: all fp32, wpack from x3_ffn_pack; hidden_bf16: the stored hidden as bf16, SL_H_BF16)."""
     _need_cuda(x, wpack)
     M, dm = x.shape
     dt = torch.float32 if x3 else BF16
     y = torch.empty(M, dm, device=x.device, dtype=dt)
-    hid = torch.empty(M, p, device=x.device, dtype=dt) if save_hidden else None
+    hid = torch.empty(M, p, device=x.device, dtype=BF16 if hidden_bf16 else dt) if save_hidden else None
     pre = torch.empty(M, dm, device=x.device, dtype=dt) if save_pre else None
     mean = torch.empty(M, device=x.device); rstd = torch.empty(M, device=x.device)
     d = FfnDesc()
-    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, (SL_X3_F16 if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 0
+    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, ((SL_X3_F16 | (SL_H_BF16 if hidden_bf16 else 0)) if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 0
     d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
     d.b1, d.b2 = b1.data_ptr(), b2.data_ptr()
     if save_hidden:
@@ -224,9 +224,10 @@ def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False
     M, dm = dy.shape
     dt = torch.float32 if x3 else BF16
     dx = torch.empty(M, dm, device=dy.device, dtype=dt)
-    dh = torch.empty(M, p, device=dy.device, dtype=dt)
+    hbf = x3 and hidden.dtype == BF16                     # x3 with the hidden stored as bf16: dh leaves as bf16 too (SL_H_BF16)
+    dh = torch.empty(M, p, device=dy.device, dtype=BF16 if hbf else dt)
     d = FfnDesc()
-    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, (SL_X3_BF16 if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 1
+    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, ((SL_X3_BF16 | (SL_H_BF16 if hbf else 0)) if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 1
     d.x, d.ldx, d.w = dy.data_ptr(), dy.stride(0), wpack_bwd.data_ptr()
     d.h_out, d.ldh = dh.data_ptr(), p
     d.gate, d.ldg, d.gate_scale = hidden.data_ptr(), hidden.stride(0), gate_scale
