@@ -167,6 +167,9 @@ int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_p
  * the STORED copy is read only as the ReLU / dropout gate and as an operand of the weight-gradient products (hftt_gemm_tn, npass 4 with
  * HFTT_TN_X_BF16 / HFTT_TN_DY_BF16), where 8 mantissa bits of one factor leave the gradient's direction untouched. */
 #define HFTT_SL_H_BF16 64u
+/* split modes, LayerNorm forms (hftt_strip_linear with ln_gamma, hftt_ffn_res_ln_fwd): pre_ln_out is bf16 [M, 256] -- it is read only by
+ * hftt_ln_bwd (HFTT_LNB_R_BF16), as xhat = (r - mean) * rstd against the fp32 statistics. */
+#define HFTT_SL_PRE_BF16 128u
 /* C[M,N] = epi(x[M,K] . Wl[N,K]^T + bias): same epilogue order as hftt_gemm_nt (relu, out_scale, gate, dropout, residual,
  * LayerNorm over N == 256).  N % 256 == 0; K % 32 == 0 and (K <= 256 or K % 256 == 0); gate is bf16. */
 typedef struct {

@@ -241,7 +241,8 @@ __device__ __forceinline__ void load16h(const unsigned short* p, float* v) {    
 
 // LayerNorm over the 256 features of the lane's token (lane: 128 of them in acc, partner lane ^ 32 the rest), fp32 out
 __device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_lds, const float* beta_lds, int h, float* mean_out, float* rstd_out,
-                                           long tok, bool ok, float* stage, int j, int lane, float* pre_wave, float* y_wave, long ld) {
+                                           long tok, bool ok, float* stage, int j, int lane, float* pre_wave, float* y_wave, long ld,
+                                           unsigned short* pre16_wave = nullptr) {
   float s = 0.f;
 #pragma unroll
   for (int ot = 0; ot < 8; ot++)
@@ -263,7 +264,8 @@ __device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_
     float v[16], ga[16], be[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = acc[ot][q];
-    if (pre_wave != nullptr) tile_store_rows(stage, v, j, h, lane, pre_wave + ot * 32, ld, ok);      // (wave-uniform pointer test)
+    if (pre_wave != nullptr) tile_store_rows(stage, v, j, h, lane, pre_wave + ot * 32, ld, ok);      // (wave-uniform pointer tests)
+    if (pre16_wave != nullptr) tile_store_rows_bf16(stage, v, j, h, lane, pre16_wave + ot * 32, ld, ok);   // HFTT_SL_PRE_BF16: read by the LayerNorm backward only
     lds16f(gamma_lds + ot * 32 + 16 * h, ga);
     lds16f(beta_lds + ot * 32 + 16 * h, be);
 #pragma unroll
@@ -399,8 +401,10 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
         __builtin_amdgcn_sched_barrier(0);
       }
       if (LN) {
+        const bool p16 = g.flags & HFTT_SL_PRE_BF16;
         x3_ln_rows(acc, prm_b + g.N, prm_b + g.N + 256, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, stage, j, lane,
-                   preb != nullptr ? preb + (blk * 128 + wave * 32) * g.ldc : nullptr, cwave, g.ldc);
+                   (preb != nullptr && !p16) ? preb + (blk * 128 + wave * 32) * g.ldc : nullptr, cwave, g.ldc,
+                   (preb != nullptr && p16) ? reinterpret_cast<unsigned short*>(preb) + (blk * 128 + wave * 32) * g.ldc : nullptr);
       }
     }
   }
@@ -705,8 +709,10 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE == 0) {
+      const bool p16 = g.flags & HFTT_SL_PRE_BF16;
       x3_ln_rows(yacc, prm_b + p + 256, prm_b + p + 512, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, stage, j, lane,
-                 preb != nullptr ? preb + (blk * 128 + wave * 32) * g.ldy : nullptr, ywave, g.ldy);
+                 (preb != nullptr && !p16) ? preb + (blk * 128 + wave * 32) * g.ldy : nullptr, ywave, g.ldy,
+                 (preb != nullptr && p16) ? reinterpret_cast<unsigned short*>(preb) + (blk * 128 + wave * 32) * g.ldy : nullptr);
     }
   }
   P.drain();

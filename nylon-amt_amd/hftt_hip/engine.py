@@ -23,7 +23,7 @@ import torch
 
 from . import _capi
 from ._capi import (AttnDesc, FfnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_H_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
+                    SL_C_BF16, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
 
 # precision -> the descriptors' `npass` code (include/hftt_hip.h): 'x3' = split fp16 on forward products (2) and split bf16 on products with a
 # gradient operand (4): three bf16-rate MFMA passes per product, fp32 tensors in HBM, outputs within 1e-3 of the reference (measured 1e-4)
@@ -438,6 +438,10 @@ class HfttEngine:
         """activation-stream tensor: bf16 when the strip kernels run (bf16 residual stream), fp32 otherwise"""
         return self._buf(ws, name, *shape, dtype=torch.bfloat16 if self.bfs else torch.float32)
 
+    def _pbuf(self, ws, name, *shape):
+        """saved pre-LayerNorm sum (read by the LayerNorm backward only): bf16 on the bf16 stream and in the x3 strip plans"""
+        return self._buf(ws, name, *shape, dtype=torch.bfloat16 if (self.bfs or self.hh) else torch.float32)
+
     def _nt(self, plan, ws, M, N, K, A, lda, W, bias, Cp, ldc, act=0, out_scale=1.0, add_table=0, add_mod=0,
             gate=0, ldg=0, gate_scale=1.0, drop_site=0, residual=0, ldr=0, res_mod=0, ln=None, a_bf=False, c_bf=False, gate_bf=False, res_bf=False):
         a_bf, c_bf, gate_bf, res_bf = (a_bf and self.sb), (c_bf and self.sb), (gate_bf and self.sb), (res_bf and self.sb and bool(residual))
@@ -500,7 +504,7 @@ class HfttEngine:
         dsc.M, dsc.N, dsc.K = M, N, K
         if self.x3:                                  # fp32 tensors, fp16 halves on forward products, bf16 halves where a gradient is an operand
             x_bf = c_bf = res_bf = False
-            dsc.flags = (SL_X3_BF16 if self._in_backward else SL_X3_F16) | (SL_RELU if relu else 0)
+            dsc.flags = (SL_X3_BF16 if self._in_backward else SL_X3_F16) | (SL_RELU if relu else 0) | (SL_PRE_BF16 if (self.hh and ln is not None) else 0)
         else:
             dsc.flags = (SL_X_BF16 if x_bf else 0) | (SL_C_BF16 if c_bf else 0) | (SL_RES_BF16 if (residual and res_bf) else 0) | (SL_RELU if relu else 0)
         dsc.x, dsc.ldx, dsc.w, dsc.bias = x, ldx, self.Ws(wkey), bias
@@ -519,7 +523,7 @@ class HfttEngine:
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
         tf = lambda v: 'true' if v else 'false'
-        nbytes = (2 if x_bf else 4) * M * K + (2 if c_bf else 4) * M * N * (2 if pre_saved else 1) + (4 if self.x3 else 2) * N * K \
+        nbytes = (2 if x_bf else 4) * M * K + (2 if c_bf else 4) * M * N + ((2 if (c_bf or self.hh) else 4) * M * N if pre_saved else 0) + (4 if self.x3 else 2) * N * K \
             + ((2 if res_bf else 4) * M * N if residual else 0) + (2 * M * N if gate else 0)
         # kernel symbol as rocprofv3 prints it (the C side picks the pipelined form by the rule mirrored here: strip_gemm2.hip hftt_strip_linear2_try)
         passes, kch = N // 256, K // 256
@@ -540,7 +544,7 @@ class HfttEngine:
         d, p = self.d, self.p
         dsc = FfnDesc()
         dsc.M, dsc.d, dsc.p, dsc.mode = M, d, p, mode
-        dsc.flags = ((SL_X3_F16 if mode == 0 else SL_X3_BF16) | (SL_H_BF16 if self.hh else 0)) if self.x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)
+        dsc.flags = ((SL_X3_F16 if mode == 0 else SL_X3_BF16) | (SL_H_BF16 | SL_PRE_BF16 if self.hh else 0)) if self.x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)
         dsc.x, dsc.ldx, dsc.w = x, d, self.Ws(wkey)
         dsc.b1, dsc.b2 = b1, b2
         dsc.h_out, dsc.ldh = h_out, p
@@ -561,7 +565,7 @@ class HfttEngine:
         ws['keep'].append(dsc)
         esz = 4.0 if self.x3 else 2.0
         hsz = 2.0 if (self.hh or not self.x3) else 4.0
-        nbytes = esz * M * d * (2 + (1 if pre_saved else 0) + (1 if residual else 0)) + (hsz * M * p if h_out else 0) + (hsz * M * p if gate else 0) + 2 * esz * d * p
+        nbytes = esz * M * d * (2 + (1 if residual else 0)) + (hsz * M * d if pre_saved else 0) + (hsz * M * p if h_out else 0) + (hsz * M * p if gate else 0) + 2 * esz * d * p
         v2 = os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and p == 512 and M % 32 == 0 and not (mode == 0 and residual)
         meta = {'kernel': (('x3_mlp_kernel<%%d, 16, %s>' % ('true' if self.hh else 'false')) if self.x3 else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>')) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
                 'shape': (M, d, p), 'saves': bool(h_out or pre_saved)}
@@ -637,7 +641,7 @@ class HfttEngine:
         return dsc
 
     def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta, drop_bf=True, dy_bf=False, dr_bf=False):
-        r_bf = self.bfs                             # the bf16 strip forward kernels save the pre-LayerNorm sum as bf16
+        r_bf = self.bfs or self.hh                  # the strip forward kernels (bf16, and x3) save the pre-LayerNorm sum as bf16
         n_wg = self.lib.hftt_ln_bwd_wgs(M)
         ws['ln_need'] = max(ws.get('ln_need', 0), n_wg * 2 * self.d * 4)
         dsc = LnBwdDesc()
@@ -692,10 +696,10 @@ class HfttEngine:
         qkv = self._buf(ws, tag + '.qkv', S, 3 * d, half=True)
         ctx = self._buf(ws, tag + '.ctx', S, d, half=True)
         lse = self._buf(ws, tag + '.lse', n_seq * H * L * 2)
-        r1 = self._abuf(ws, tag + '.r1', S, d); x1 = self._abuf(ws, tag + '.x1', S, d)
+        r1 = self._pbuf(ws, tag + '.r1', S, d); x1 = self._abuf(ws, tag + '.x1', S, d)
         m1 = self._buf(ws, tag + '.m1', S); s1 = self._buf(ws, tag + '.s1', S)
         h = self._buf(ws, tag + '.h', S, p, half=True, hidden=True)
-        r2 = self._abuf(ws, tag + '.r2', S, d); x2 = self._abuf(ws, tag + '.x2', S, d)
+        r2 = self._pbuf(ws, tag + '.r2', S, d); x2 = self._abuf(ws, tag + '.x2', S, d)
         m2 = self._buf(ws, tag + '.m2', S); s2 = self._buf(ws, tag + '.s2', S)
         sites = ws.setdefault('sites', {})
         sa, so, sh, sf = (self._new_site() for _ in range(4))
@@ -727,7 +731,7 @@ class HfttEngine:
     def _ffn_fwd(self, plan, ws, tag, key, pre, S, x_in, sites, save=True):
         d, p = self.d, self.p
         h = self._buf(ws, tag + '.h', S, p, half=True, hidden=True)
-        r = self._abuf(ws, tag + '.fr', S, d); x = self._abuf(ws, tag + '.fx', S, d)
+        r = self._pbuf(ws, tag + '.fr', S, d); x = self._abuf(ws, tag + '.fx', S, d)
         m = self._buf(ws, tag + '.fm', S); s = self._buf(ws, tag + '.fs', S)
         sh, sf = self._new_site(), self._new_site()
         sites['ffn'] = (sh, sf)
@@ -786,7 +790,7 @@ class HfttEngine:
                 sqkv = self._buf(ws, tag + '.sqkv', Sn, 3 * d, half=True)
                 sctx = self._buf(ws, tag + '.sctx', Sn, d, half=True)
                 slse = self._buf(ws, tag + '.slse', BT * H * N * 2)
-                sr = self._abuf(ws, tag + '.sr', Sn, d); sx = self._abuf(ws, tag + '.sx', Sn, d)
+                sr = self._pbuf(ws, tag + '.sr', Sn, d); sx = self._abuf(ws, tag + '.sx', Sn, d)
                 sm = self._buf(ws, tag + '.sm', Sn); ss = self._buf(ws, tag + '.ss', Sn)
                 s_a, s_o = self._new_site(), self._new_site()
                 sites['self'] = (s_a, s_o)
@@ -816,7 +820,7 @@ class HfttEngine:
             ckv = self._buf(ws, tag + '.ckv', Se, 2 * d, half=True)
             cctx = self._buf(ws, tag + '.cctx', Sn, d, half=True)
             clse = self._buf(ws, tag + '.clse', BT * H * N * 2)
-            cr = self._abuf(ws, tag + '.cr', Sn, d); cx = self._abuf(ws, tag + '.cx', Sn, d)
+            cr = self._pbuf(ws, tag + '.cr', Sn, d); cx = self._abuf(ws, tag + '.cx', Sn, d)
             cm = self._buf(ws, tag + '.cm', Sn); cs = self._buf(ws, tag + '.cs', Sn)
             c_a, c_o = self._new_site(), self._new_site()
             sites['cross'] = (c_a, c_o)

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_H_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
+                    SL_C_BF16, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
 
 
 def _stream(dev):
@@ -159,7 +159,7 @@ def x3_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
 
 
 def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, drop_seed=0,
-                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0):
+                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0, pre_bf16=False):
     """C = epi(x @ Wl.T + bias) with Wl given as its strip pack.  ln = (gamma, beta) -> (C, pre_ln, mean, rstd).
     x3 = 2 / 4: the split-operand form (fp32 tensors, wpack from x3_strip_pack with the same element type)."""
     _need_cuda(x, wpack)
@@ -170,7 +170,8 @@ def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, g
     d = StripDesc()
     d.M, d.N, d.K = M, N, K
     d.flags = (SL_X_BF16 if x.dtype == BF16 else 0) | (SL_C_BF16 if out_dtype == BF16 else 0) | (SL_RELU if relu else 0) \
-        | (SL_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0) | (SL_X3_F16 if x3 == 2 else 0) | (SL_X3_BF16 if x3 == 4 else 0)
+        | (SL_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0) | (SL_X3_F16 if x3 == 2 else 0) | (SL_X3_BF16 if x3 == 4 else 0) \
+        | (SL_PRE_BF16 if (x3 and pre_bf16 and ln is not None) else 0)
     d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc, d.out_scale, d.gate_scale = Cout.data_ptr(), N, out_scale, gate_scale
@@ -181,7 +182,7 @@ def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, g
         d.residual, d.ldr, d.res_mod = residual.data_ptr(), residual.stride(0), res_mod
     extra = ()
     if ln is not None:
-        pre = torch.empty(M, N, device=x.device, dtype=out_dtype) if save_pre else None
+        pre = torch.empty(M, N, device=x.device, dtype=BF16 if (x3 and pre_bf16) else out_dtype) if save_pre else None
         mean = torch.empty(M, device=x.device)
         rstd = torch.empty(M, device=x.device)
         d.ln_gamma, d.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
@@ -191,7 +192,7 @@ def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, g
     return (Cout,) + extra if extra else Cout
 
 
-def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_o=0, seed=0, save_hidden=True, save_pre=True, residual=None, x3=False, hidden_bf16=False):
+def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_o=0, seed=0, save_hidden=True, save_pre=True, residual=None, x3=False, hidden_bf16=False, pre_bf16=False):
     """Fused FFN block: y = LN(x + drop(fc_2(drop(relu(fc_1 x))))) -> (y, hidden | None, pre_ln | None, mean, rstd); all bf16
     (x3: all fp32, wpack from x3_ffn_pack; hidden_bf16: the stored hidden as bf16, SL_H_BF16)."""
     _need_cuda(x, wpack)
@@ -199,10 +200,10 @@ def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_
     dt = torch.float32 if x3 else BF16
     y = torch.empty(M, dm, device=x.device, dtype=dt)
     hid = torch.empty(M, p, device=x.device, dtype=BF16 if hidden_bf16 else dt) if save_hidden else None
-    pre = torch.empty(M, dm, device=x.device, dtype=dt) if save_pre else None
+    pre = torch.empty(M, dm, device=x.device, dtype=BF16 if (x3 and pre_bf16) else dt) if save_pre else None
     mean = torch.empty(M, device=x.device); rstd = torch.empty(M, device=x.device)
     d = FfnDesc()
-    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, ((SL_X3_F16 | (SL_H_BF16 if hidden_bf16 else 0)) if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 0
+    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, ((SL_X3_F16 | (SL_H_BF16 if hidden_bf16 else 0) | (SL_PRE_BF16 if pre_bf16 else 0)) if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 0
     d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
     d.b1, d.b2 = b1.data_ptr(), b2.data_ptr()
     if save_hidden:

@@ -60,9 +60,13 @@ def main():
          4.0 * M * d * p, 4.0 * M * (3 * d + p))
     line('ffn fwd (inference)', timeit(lambda: ops.ffn_res_ln_fwd(x, wf, p, b1, b2, gam, bet, save_hidden=False, save_pre=False, x3=True)),
          4.0 * M * d * p, 4.0 * M * 2 * d)
+    line('ffn fwd (training, hidden as bf16)', timeit(lambda: ops.ffn_res_ln_fwd(x, wf, p, b1, b2, gam, bet, drop_p=0.1, site_h=1, site_o=2, seed=5, x3=True, hidden_bf16=True)),
+         4.0 * M * d * p, 4.0 * M * 3 * d + 2.0 * M * p)
     hid = torch.relu(torch.randn(M, p, generator=g)).to(dev)
     wb = ops.x3_ffn_pack(W1, W2, backward=True)
     line('ffn bwd dx', timeit(lambda: ops.ffn_bwd_dx(x, wb, p, hid, gate_scale=1.1, residual=res, x3=True)), 4.0 * M * d * p, 4.0 * M * (3 * d + 2 * p))
+    hb = hid.bfloat16()
+    line('ffn bwd dx (hidden / dh as bf16)', timeit(lambda: ops.ffn_bwd_dx(x, wb, p, hb, gate_scale=1.1, residual=res, x3=True)), 4.0 * M * d * p, 4.0 * M * 3 * d + 2.0 * M * 2 * p)
 
 
 if __name__ == '__main__':
