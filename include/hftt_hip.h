@@ -93,6 +93,7 @@ int hftt_prep_weights_x3(const float* params, uint16_t* whi, uint16_t* wlo, floa
 #define HFTT_NT_A_BF16 1u
 #define HFTT_NT_C_BF16 2u      /* not with LayerNorm */
 #define HFTT_NT_GATE_BF16 4u
+#define HFTT_NT_A_HI 16u       /* npass 4: A (a gradient) enters as its bf16 rounding only -- two MFMA passes against the weight pair */
 #define HFTT_NT_RES_BF16 8u    /* residual stored as bf16 (A-stationary bf16-mode kernels: N % 256 == 0, M >= 256, K <= 768) */
 typedef struct {
   int32_t M, N, K, npass;
@@ -167,6 +168,8 @@ int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_p
  * the STORED copy is read only as the ReLU / dropout gate and as an operand of the weight-gradient products (hftt_gemm_tn, npass 4 with
  * HFTT_TN_X_BF16 / HFTT_TN_DY_BF16), where 8 mantissa bits of one factor leave the gradient's direction untouched. */
 #define HFTT_SL_H_BF16 64u
+/* with HFTT_SL_X3_BF16: the strip x (hftt_ffn_bwd_dx: dy and the dh it forms) is a gradient and enters as its bf16 rounding only */
+#define HFTT_SL_X3_GRAD_HI 256u
 /* split modes, LayerNorm forms (hftt_strip_linear with ln_gamma, hftt_ffn_res_ln_fwd): pre_ln_out is bf16 [M, 256] -- it is read only by
  * hftt_ln_bwd (HFTT_LNB_R_BF16), as xhat = (r - mean) * rstd against the fp32 statistics. */
 #define HFTT_SL_PRE_BF16 128u
@@ -220,6 +223,7 @@ int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream);       /* mode 1 */
  * --------------------------------------------------------------------------------------------- */
 #define HFTT_TN_DY_BF16 1u
 #define HFTT_TN_X_BF16 2u
+#define HFTT_TN_DY_HI 4u       /* npass 4: dY (the gradient) enters as its bf16 rounding only; X keeps its bf16 pair (two MFMA passes) */
 typedef struct {
   int32_t M, N, K, npass;
   const float* dY; int64_t lddy;

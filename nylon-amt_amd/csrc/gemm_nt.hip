@@ -42,7 +42,7 @@ constexpr int BK = 32;
 template <int BN, int PREC>
 struct NtCfg {
   static constexpr bool F32 = (PREC == 3);
-  static constexpr bool X3M = (PREC == 2 || PREC == 4);
+  static constexpr bool X3M = (PREC == 2 || PREC == 4 || PREC == 5);   // 5 = npass 4 with HFTT_NT_A_HI: A (a gradient) enters as its bf16 rounding
   static constexpr int WM = (BN == 64) ? 4 : 2;
   static constexpr int WN = 8 / WM;
   static constexpr int TM = BM / WM / 32;
@@ -64,7 +64,8 @@ template <int BN, int PREC, bool LN>
 __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g) {
   using Cfg = NtCfg<BN, PREC>;
   constexpr bool F32 = Cfg::F32, X3M = Cfg::X3M;
-  constexpr int XE = X3M ? PREC : X3_BF16;          // element type of the split (unused otherwise)
+  constexpr int XE = X3M ? (PREC == 5 ? 4 : PREC) : X3_BF16;          // element type of the split (unused otherwise)
+  constexpr bool AH = (PREC == 5);
   constexpr int WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN, RS = Cfg::RS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
         uint2 hi, lo;
         x3_split4<XE>(areg[j], hi, lo);
         *reinterpret_cast<uint2*>(As + row * RS + c4 * 4) = hi;
-        *reinterpret_cast<uint2*>(As + BM * RS + row * RS + c4 * 4) = lo;
+        if (!AH) *reinterpret_cast<uint2*>(As + BM * RS + row * RS + c4 * 4) = lo;
       }
 #pragma unroll
       for (int j = 0; j < Cfg::WCH; j++) {
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 #pragma unroll
         for (int i = 0; i < TM; i++) {
           const unsigned short* p = As + (wm * TM * 32 + i * 32 + lr) * RS + s * 16 + lh * 8;
-          ah[i] = lds_read_b128(p); al[i] = lds_read_b128(p + BM * RS);
+          ah[i] = lds_read_b128(p);
+          if (!AH) al[i] = lds_read_b128(p + BM * RS);
         }
 #pragma unroll
         for (int j = 0; j < TN; j++) {
@@ -261,7 +263,10 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const hftt_gemm_nt_desc g)
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) acc[i][j] = x3_mma<XE>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+          for (int j = 0; j < TN; j++) {
+            if (AH) { acc[i][j] = X3<XE>::mma(ah[i], bl[j], acc[i][j]); acc[i][j] = X3<XE>::mma(ah[i], bh[j], acc[i][j]); }
+            else acc[i][j] = x3_mma<XE>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+          }
       }
     } else {
       const unsigned short* As = sm16 + buf * Cfg::BUF_ELEMS;
@@ -1082,7 +1087,8 @@ extern "C" int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream) {
   HFTT_REQUIRE(d != nullptr, "gemm_nt: null descriptor");
   HFTT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
   HFTT_REQUIRE(d->K % 32 == 0, "gemm_nt: K=%d must be a multiple of 32", d->K);
-  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1, "gemm_nt: bf16-stored operands need npass == 1");
+  HFTT_REQUIRE((d->io_flags & ~HFTT_NT_A_HI) == 0 || d->npass == 1, "gemm_nt: bf16-stored operands need npass == 1");
+  HFTT_REQUIRE(!(d->io_flags & HFTT_NT_A_HI) || d->npass == 4, "gemm_nt: HFTT_NT_A_HI goes with npass == 4");
   HFTT_REQUIRE(!(d->io_flags & HFTT_NT_C_BF16) || d->ln_gamma == nullptr, "gemm_nt: a bf16 C cannot be combined with LayerNorm");
   HFTT_REQUIRE(d->lda % ((d->io_flags & HFTT_NT_A_BF16) ? 8 : 4) == 0, "gemm_nt: lda=%ld breaks 16-byte row alignment", (long)d->lda);
   HFTT_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->W & 15) == 0, "gemm_nt: A/W must be 16-byte aligned");
@@ -1096,6 +1102,6 @@ extern "C" int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->npass == 3) return dispatch_nt<3>(*d, st);
   if (d->npass == 2) return dispatch_nt<2>(*d, st);
-  if (d->npass == 4) return dispatch_nt<4>(*d, st);
+  if (d->npass == 4) return (d->io_flags & HFTT_NT_A_HI) ? dispatch_nt<5>(*d, st) : dispatch_nt<4>(*d, st);
   return dispatch_nt_bf16(*d, st);
 }

@@ -67,7 +67,7 @@ TnPlan tn_plan(int M, int N, int K) {
 template <int TM, int TN, int NPASS, bool DYB = false, bool XB = false>
 struct TnCfg {
   static constexpr bool F32 = (NPASS == 3);
-  static constexpr bool X3M = (NPASS == 2 || NPASS == 4);
+  static constexpr bool X3M = (NPASS == 2 || NPASS == 4 || NPASS == 5);   // 5 = npass 4 with HFTT_TN_DY_HI: dY (the gradient) enters as its bf16 rounding
   static constexpr int PLANES = X3M ? 2 : 1;       // x3: hi plane, then lo plane of each tile
   static constexpr int YE = DYB ? 8 : 4;           // elements per 16-byte global slot (bf16- or fp32-stored operand)
   static constexpr int XE = XB ? 8 : 4;
@@ -94,11 +94,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
                                                      const long nws, const long kws, const int n_tiles_total, const int n_splits) {
   using Cfg = TnCfg<TM, TN, NPASS, DYB, XB>;
   constexpr bool F32 = Cfg::F32, X3M = Cfg::X3M;
-  constexpr int EX = X3M ? NPASS : X3_BF16;         // element type of the split
+  constexpr int EX = X3M ? (NPASS == 5 ? 4 : NPASS) : X3_BF16;         // element type of the split
+  constexpr bool DYH = (NPASS == 5);
   static_assert(!F32 || (!DYB && !XB), "bf16-stored operands: bf16 mode, or ONE side of a split-bf16 product");
   // x3 with a bf16-stored operand (the saved FFN hidden / its gradient, kept as bf16 for this product only): that operand IS its hi
   // half, the lo half is zero and the pass that would multiply it is skipped (two MFMAs per fragment pair instead of three)
   static_assert(!(X3M && DYB && XB), "split product with both operands bf16-stored is the plain bf16 product");
+  static_assert(!(NPASS == 5 && DYB), "a bf16-stored dY is its own hi half already");
   constexpr int RSY = Cfg::RSY, RSX = Cfg::RSX, TILE_N = Cfg::TILE_N, TILE_K = Cfg::TILE_K;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       uint2 hi, lo;
       x3_split4<EX>(f, hi, lo);
       *reinterpret_cast<uint2*>(base + off) = hi;
-      *reinterpret_cast<uint2*>(base + (which ? BMT * RSX : BMT * RSY) + off) = lo;
+      if (!(DYH && which == 0)) *reinterpret_cast<uint2*>(base + (which ? BMT * RSX : BMT * RSY) + off) = lo;
     } else {
       unsigned short* base = sm16 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
       uint2 ph;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
         for (int i = 0; i < TM; i++) {
           const unsigned short* p = Ys + (16 * s + frag_row) * RSY + wn4 * TM * 32 + i * 32 + frag_col;
           ah[i] = join4(lds_read_tr16(p), lds_read_tr16(p + 4 * RSY));
-          if (!DYB) al[i] = join4(lds_read_tr16(p + BMT * RSY), lds_read_tr16(p + BMT * RSY + 4 * RSY));
+          if (!DYB && !DYH) al[i] = join4(lds_read_tr16(p + BMT * RSY), lds_read_tr16(p + BMT * RSY + 4 * RSY));
         }
         // one X fragment pair at a time (the next pair is read under this pair's six MFMAs): all TN pairs up front, as hipcc would
         // schedule them, put the 256 x 256 tile over the register budget
@@ -284,9 +286,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
           }
 #pragma unroll
           for (int i = 0; i < TM; i++) {
-            if (!DYB && !XB) acc[i][j] = x3_mma<EX>(ah[i], al[i], bh, bl, acc[i][j]);
+            if (!DYB && !XB && !DYH) acc[i][j] = x3_mma<EX>(ah[i], al[i], bh, bl, acc[i][j]);
             else {                                            // same order as x3_mma: small terms first
-              if (!DYB) acc[i][j] = X3<EX>::mma(al[i], bh, acc[i][j]);
+              if (!DYB && !DYH) acc[i][j] = X3<EX>::mma(al[i], bh, acc[i][j]);
               if (!XB) acc[i][j] = X3<EX>::mma(ah[i], bl, acc[i][j]);
               acc[i][j] = X3<EX>::mma(ah[i], bh, acc[i][j]);
             }
@@ -445,8 +447,9 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   }
   HFTT_REQUIRE(((uintptr_t)d->dY & 15) == 0 && ((uintptr_t)d->X & 15) == 0, "gemm_tn: dY/X must be 16-byte aligned");
   HFTT_REQUIRE(d->npass >= 1 && d->npass <= 4, "gemm_tn: npass must be 1 .. 4");
-  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1 || (d->npass == 4 && d->io_flags != (HFTT_TN_DY_BF16 | HFTT_TN_X_BF16)),
+  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1 || (d->npass == 4 && (d->io_flags & 3u) != (HFTT_TN_DY_BF16 | HFTT_TN_X_BF16)),
                "gemm_tn: bf16-stored operands need npass == 1, or npass == 4 with ONE of them");
+  HFTT_REQUIRE(!(d->io_flags & HFTT_TN_DY_HI) || d->npass == 4, "gemm_tn: HFTT_TN_DY_HI goes with npass == 4");
   HFTT_REQUIRE(d->n_seg >= 1 && d->n_seg <= 4, "gemm_tn: n_seg must be 1..4");
   HFTT_REQUIRE(d->K_out > 0 && d->K_out <= d->K, "gemm_tn: K_out out of range");
   for (int s = 0; s < d->n_seg; s++) {
@@ -463,6 +466,13 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
     else if (p.tn == 4) rc = launch_tn<1, 4, 3, false, false>(*d, p, st);
     else if (p.tn == 2) rc = launch_tn<1, 2, 3, false, false>(*d, p, st);
     else rc = launch_tn<1, 1, 3, false, false>(*d, p, st);
+  } else if (d->npass == 4 && (d->io_flags & HFTT_TN_DY_HI) && !dyb) {
+#define HFTT_TN_GO5(TM_, TN_) (xb ? launch_tn<TM_, TN_, 5, false, true>(*d, p, st) : launch_tn<TM_, TN_, 5, false, false>(*d, p, st))
+    if (p.tm == 2) rc = HFTT_TN_GO5(2, 4);
+    else if (p.tn == 4) rc = HFTT_TN_GO5(1, 4);
+    else if (p.tn == 2) rc = HFTT_TN_GO5(1, 2);
+    else rc = HFTT_TN_GO5(1, 1);
+#undef HFTT_TN_GO5
   } else if (d->npass == 4) {
 #define HFTT_TN_GO4(TM_, TN_)                                                     \
     (dyb ? launch_tn<TM_, TN_, 4, true, false>(*d, p, st) : (xb ? launch_tn<TM_, TN_, 4, false, true>(*d, p, st) : launch_tn<TM_, TN_, 4, false, false>(*d, p, st)))

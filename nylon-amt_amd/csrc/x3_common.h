@@ -21,6 +21,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int X3_F16 = 2;      // the values double as the descriptors' `npass` codes
 constexpr int X3_BF16 = 4;
+// X3_BF16H: bf16 halves where the GRADIENT operand of the product enters as its bf16 rounding only (hi half; two MFMA passes
+// hi.lo + hi.hi against the other operand's pair).  A gradient only has to point the right way: its 2^-9 zero-mean rounding moves no
+// gradient tensor's cosine against the exact-fp32 mode below 0.9999 (tests/test_paper_bf16_gpu.py), the saved forward operand keeps 16 bits.
+constexpr int X3_BF16H = 5;
 
 template <int E>
 struct X3;
@@ -56,6 +60,9 @@ struct X3<X3_BF16> {
   static __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) { return mfma32(a, b, c); }
   static __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) { return mfma16(a, b, c); }
 };
+
+template <>
+struct X3<X3_BF16H> : X3<X3_BF16> {};
 
 // (a, b) -> packed hi pair + packed lo pair
 template <int E>

@@ -114,6 +114,12 @@ __device__ __forceinline__ void chunk_convert(XChunk& c) {
   const float v[8] = {__uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
                       __uint_as_float(c.b.x), __uint_as_float(c.b.y), __uint_as_float(c.b.z), __uint_as_float(c.b.w)};
   bf16x8 hi, lo;
+  if (E == X3_BF16H) {                                 // hi half only (c.b is not read in this form)
+    uint4 h;
+    h.x = X3<E>::pk(v[0], v[1]); h.y = X3<E>::pk(v[2], v[3]); h.z = X3<E>::pk(v[4], v[5]); h.w = X3<E>::pk(v[6], v[7]);
+    c.a = __builtin_bit_cast(u4v, h);
+    return;
+  }
   x3_split8<E>(v, hi, lo);
   c.a = __builtin_bit_cast(u4v, hi); c.b = __builtin_bit_cast(u4v, lo);
 }
@@ -145,7 +151,7 @@ __device__ __forceinline__ void x3_slot_tiles(const unsigned char* slot, const X
     acc[t] = X3<E>::mma(fr[2 * t + 1], xh, acc[t]);
     side(std::integral_constant<int, 3 * t>{});
     if (2 * t + 4 < 16) fr[2 * t + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 4) * 1024);
-    acc[t] = X3<E>::mma(fr[2 * t], xl, acc[t]);
+    if (E != X3_BF16H) acc[t] = X3<E>::mma(fr[2 * t], xl, acc[t]);      // (X3_BF16H: the strip is a gradient, hi half only)
     side(std::integral_constant<int, 3 * t + 1>{});
     if (2 * t + 5 < 16) fr[2 * t + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 5) * 1024);
     acc[t] = X3<E>::mma(fr[2 * t], xh, acc[t]);
@@ -165,7 +171,7 @@ __device__ __forceinline__ void x3_slot_chunks(const unsigned char* slot, const 
     acc = X3<E>::mma(fr[2 * q + 1], xh, acc);
     side(std::integral_constant<int, 3 * q>{});
     if (2 * q + 4 < 16) fr[2 * q + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 4) * 1024);
-    acc = X3<E>::mma(fr[2 * q], xl, acc);
+    if (E != X3_BF16H) acc = X3<E>::mma(fr[2 * q], xl, acc);
     side(std::integral_constant<int, 3 * q + 1>{});
     if (2 * q + 5 < 16) fr[2 * q + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 5) * 1024);
     acc = X3<E>::mma(fr[2 * q], xh, acc);
@@ -528,10 +534,10 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
 // backward (bf16 halves).  Stream per hidden tile t: two slots of the first matrix (tile-major: k chunks 0-7, 8-15), then two slots of
 // the second (K-slice t: u = 0, 1).
 // ---------------------------------------------------------------------------------------------------------------------
-// HH: h_out / gate are bf16 [M, p] (HFTT_SL_H_BF16) instead of fp32
-template <int MODE, int PT, bool HH>
+// HH: h_out / gate are bf16 [M, p] (HFTT_SL_H_BF16) instead of fp32; GH (mode 1): the gradient strips (dy, dh) enter as their hi halves
+template <int MODE, int PT, bool HH, bool GH>
 __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
-  constexpr int E = (MODE == 0) ? X3_F16 : X3_BF16;
+  constexpr int E = (MODE == 0) ? X3_F16 : (GH ? X3_BF16H : X3_BF16);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -758,15 +764,15 @@ int launch_xn(const hftt_strip_desc& d, hipStream_t st) {
   HFTT_CHECK_LAUNCH("x3_strip_linear");
   return 0;
 }
-template <int MODE, bool HH>
+template <int MODE, bool HH, bool GH = false>
 int launch_xm(const hftt_ffn_desc& d, hipStream_t st) {
   const int lds = RING_BYTES + 4 * (d.p + 768) + 4 * STG_BYTES_PER_WAVE;
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(x3_mlp_kernel<MODE, 16, HH>, lds, "x3_strip_mlp")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(x3_mlp_kernel<MODE, 16, HH, GH>, lds, "x3_strip_mlp")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("x3_strip_mlp: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  hipLaunchKernelGGL((x3_mlp_kernel<MODE, 16, HH>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  hipLaunchKernelGGL((x3_mlp_kernel<MODE, 16, HH, GH>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("x3_strip_mlp");
   return 0;
 }
@@ -806,6 +812,8 @@ int hftt_x3_strip_linear(const hftt_strip_desc& d0, hipStream_t st) {
   HFTT_REQUIRE(d.gate == nullptr, "x3_strip_linear: no gate form (the fused block hftt_ffn_bwd_dx carries the gate)");
   HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_linear: tensors are fp32 in the split modes");
   HFTT_REQUIRE(d.ldx % 4 == 0 && d.ldc % 4 == 0 && (d.residual == nullptr || d.ldr % 4 == 0), "x3_strip_linear: rows must be 16-byte aligned");
+  HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_GRAD_HI) || (d.flags & HFTT_SL_X3_BF16), "x3_strip_linear: HFTT_SL_X3_GRAD_HI goes with HFTT_SL_X3_BF16");
+  if (d.flags & HFTT_SL_X3_GRAD_HI) return dispatch_xl<X3_BF16H>(d, st);
   return (d.flags & HFTT_SL_X3_BF16) ? dispatch_xl<X3_BF16>(d, st) : dispatch_xl<X3_F16>(d, st);
 }
 
@@ -816,11 +824,15 @@ int hftt_x3_strip_mlp(const hftt_ffn_desc& d0, hipStream_t st) {
   HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_mlp: tensors are fp32 in the split modes");
   HFTT_REQUIRE(d.mode == 1 || d.residual == nullptr, "x3_strip_mlp: the forward block's residual is its input");
   HFTT_REQUIRE(((d.flags & HFTT_SL_X3_BF16) != 0) == (d.mode == 1), "x3_strip_mlp: mode 0 takes fp16 halves (HFTT_SL_X3_F16), mode 1 bf16 halves");
+  const bool gh = (d.flags & HFTT_SL_X3_GRAD_HI) != 0;
+  HFTT_REQUIRE(!gh || d.mode == 1, "x3_strip_mlp: HFTT_SL_X3_GRAD_HI belongs to the backward form");
   if (d.flags & HFTT_SL_H_BF16) {
     HFTT_REQUIRE((d.h_out == nullptr || d.ldh % 8 == 0) && (d.gate == nullptr || d.ldg % 8 == 0), "x3_strip_mlp: bf16 hidden rows must be 16-byte aligned");
-    return d.mode == 0 ? launch_xm<0, true>(d, st) : launch_xm<1, true>(d, st);
+    if (d.mode == 0) return launch_xm<0, true>(d, st);
+    return gh ? launch_xm<1, true, true>(d, st) : launch_xm<1, true, false>(d, st);
   }
-  return d.mode == 0 ? launch_xm<0, false>(d, st) : launch_xm<1, false>(d, st);
+  if (d.mode == 0) return launch_xm<0, false>(d, st);
+  return gh ? launch_xm<1, false, true>(d, st) : launch_xm<1, false, false>(d, st);
 }
 
 extern "C" int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_pack_entry* table_dev, int n_entries, int elem, void* stream) {

@@ -115,6 +115,7 @@ class FfnDesc(C.Structure):
 
 SL_X_BF16, SL_C_BF16, SL_RES_BF16, SL_RELU = 1, 2, 4, 8
 SL_PRE_BF16 = 128                           # split modes, LayerNorm forms: pre_ln_out stored as bf16
+SL_X3_GRAD_HI = 256                         # with SL_X3_BF16: the gradient strip enters as its bf16 rounding (two MFMA passes)
 SL_H_BF16 = 64                              # fused block in a split mode: h_out / gate stored as bf16
 SL_X3_F16, SL_X3_BF16 = 16, 32               # split-operand forms of the strip kernels (fp32 tensors; fp16 / bf16 hi + lo halves)
 TE_X_BF16, TE_Y_BF16, TE_M_BF16 = 1, 2, 4          # hftt_time_embed_fwd / _bwd io_flags

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
+                    SL_C_BF16, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
 
 
 def _stream(dev):
@@ -25,8 +25,8 @@ def _need_cuda(*ts):
 
 
 BF16 = torch.bfloat16
-NT_A_BF16, NT_C_BF16, NT_GATE_BF16, NT_RES_BF16 = 1, 2, 4, 8
-TN_DY_BF16, TN_X_BF16 = 1, 2
+NT_A_BF16, NT_C_BF16, NT_GATE_BF16, NT_RES_BF16, NT_A_HI = 1, 2, 4, 8, 16
+TN_DY_BF16, TN_X_BF16, TN_DY_HI = 1, 2, 4
 ATTN_Q_BF16, ATTN_KV_BF16, ATTN_O_BF16, ATTN_DQ_BF16, ATTN_DKV_BF16 = 1, 2, 4, 8, 16
 
 
@@ -59,8 +59,9 @@ def prepare_weight(w: torch.Tensor, npass=3, transposed=False, n_pad=64):
 
 
 def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_mod=0, gate=None, gate_scale=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, residual=None, res_mod=0, ln=None, planes=None, debug=0, out_dtype=torch.float32):
-    """C = epi(A @ W.T + bias); W fp32 [N, K].  ln = (gamma, beta) -> returns (C, pre_ln, mean, rstd)."""
+            drop_p=0.0, drop_site=0, drop_seed=0, residual=None, res_mod=0, ln=None, planes=None, debug=0, out_dtype=torch.float32, grad_hi=False):
+    """C = epi(A @ W.T + bias); W fp32 [N, K].  ln = (gamma, beta) -> returns (C, pre_ln, mean, rstd).  grad_hi (npass 4): A enters as
+    its bf16 rounding (NT_A_HI)."""
     _need_cuda(A, W)
     M, K = A.shape
     N = W.shape[0]
@@ -74,7 +75,7 @@ def gemm_nt(A, W, bias=None, npass=3, act=0, out_scale=1.0, add_table=None, add_
         d.W_lo = Wprep[1].data_ptr()
     d.debug = debug
     d.io_flags = (NT_A_BF16 if A.dtype == BF16 else 0) | (NT_C_BF16 if out_dtype == BF16 else 0) | (NT_GATE_BF16 if (gate is not None and gate.dtype == BF16) else 0) \
-        | (NT_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0)
+        | (NT_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0) | (NT_A_HI if grad_hi else 0)
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc = Cout.data_ptr(), N
     d.act, d.out_scale = act, out_scale
@@ -159,7 +160,7 @@ def x3_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
 
 
 def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, drop_seed=0,
-                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0, pre_bf16=False):
+                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0, pre_bf16=False, grad_hi=False):
     """C = epi(x @ Wl.T + bias) with Wl given as its strip pack.  ln = (gamma, beta) -> (C, pre_ln, mean, rstd).
     x3 = 2 / 4: the split-operand form (fp32 tensors, wpack from x3_strip_pack with the same element type)."""
     _need_cuda(x, wpack)
@@ -171,7 +172,7 @@ def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, g
     d.M, d.N, d.K = M, N, K
     d.flags = (SL_X_BF16 if x.dtype == BF16 else 0) | (SL_C_BF16 if out_dtype == BF16 else 0) | (SL_RELU if relu else 0) \
         | (SL_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0) | (SL_X3_F16 if x3 == 2 else 0) | (SL_X3_BF16 if x3 == 4 else 0) \
-        | (SL_PRE_BF16 if (x3 and pre_bf16 and ln is not None) else 0)
+        | (SL_PRE_BF16 if (x3 and pre_bf16 and ln is not None) else 0) | (SL_X3_GRAD_HI if (x3 == 4 and grad_hi) else 0)
     d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc, d.out_scale, d.gate_scale = Cout.data_ptr(), N, out_scale, gate_scale
@@ -219,7 +220,7 @@ def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_
     return y, hid, pre, mean, rstd
 
 
-def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False):
+def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False, grad_hi=False):
     """dh = (hidden > 0) * (dy @ fc_2.weight) * gate_scale;  dx = dh @ fc_1.weight (+ residual) -> (dx, dh); all bf16 (x3: all fp32)."""
     _need_cuda(dy, wpack_bwd, hidden)
     M, dm = dy.shape
@@ -228,7 +229,7 @@ def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False
     hbf = x3 and hidden.dtype == BF16                     # x3 with the hidden stored as bf16: dh leaves as bf16 too (SL_H_BF16)
     dh = torch.empty(M, p, device=dy.device, dtype=BF16 if hbf else dt)
     d = FfnDesc()
-    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, ((SL_X3_BF16 | (SL_H_BF16 if hbf else 0)) if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 1
+    d.M, d.d, d.p, d.flags, d.mode = M, dm, p, ((SL_X3_BF16 | (SL_H_BF16 if hbf else 0) | (SL_X3_GRAD_HI if grad_hi else 0)) if x3 else (SL_X_BF16 | SL_C_BF16 | SL_RES_BF16)), 1
     d.x, d.ldx, d.w = dy.data_ptr(), dy.stride(0), wpack_bwd.data_ptr()
     d.h_out, d.ldh = dh.data_ptr(), p
     d.gate, d.ldg, d.gate_scale = hidden.data_ptr(), hidden.stride(0), gate_scale
@@ -239,7 +240,7 @@ def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False
     return dx, dh
 
 
-def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True):
+def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True, grad_hi=False):
     """dW[N,K] = out_scale * dY[M,N].T @ X[M,K]; db[N] = colsum(dY)."""
     _need_cuda(dY, X)
     M, N = dY.shape
@@ -253,7 +254,7 @@ def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True):
     d.M, d.N, d.K, d.npass = M, N, K, npass
     d.dY, d.lddy, d.X, d.ldx = dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0)
     d.out_scale, d.beta, d.n_seg = out_scale, 0.0, 1
-    d.io_flags = (TN_DY_BF16 if dY.dtype == BF16 else 0) | (TN_X_BF16 if X.dtype == BF16 else 0)
+    d.io_flags = (TN_DY_BF16 if dY.dtype == BF16 else 0) | (TN_X_BF16 if X.dtype == BF16 else 0) | (TN_DY_HI if (grad_hi and dY.dtype != BF16) else 0)
     d.seg_row0[0], d.seg_rows[0], d.seg_dw[0], d.seg_db[0] = 0, N, dW.data_ptr(), (db.data_ptr() if with_bias else 0)
     d.K_out = K
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4

@@ -59,6 +59,9 @@ def test_gemm_nt_plain(dev, M, N, K, npass):
     assert rel_err(out, ref) < TOL[npass]
     out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=npass, act=1, out_scale=2.5)
     assert rel_err(out, torch.relu(ref) * 2.5) < TOL[npass]
+    if npass == 4:      # HFTT_NT_A_HI: A (a gradient in the backward) enters as its bf16 rounding, the weights keep their pair
+        out = ops.gemm_nt(A.to(dev), W.to(dev), b.to(dev), npass=4, grad_hi=True)
+        assert rel_err(out, A.bfloat16().double() @ W.double().T + b.double()) < TOL[4]
 
 
 def test_gemm_nt_small_and_large_magnitudes(dev):
@@ -124,6 +127,10 @@ def test_gemm_tn(dev, M, N, K, npass):
     scale = math.sqrt(M) * dY.abs().max().item()
     assert max_err(dW, ref) / scale < TOL[npass] * 3
     assert max_err(db, 0.5 * dY.double().sum(0)) / scale < 1e-5
+    if npass == 4:      # HFTT_TN_DY_HI: dY enters the product as its bf16 rounding (the bias gradient still sums the fp32 values)
+        dW, db = ops.gemm_tn(dY.to(dev), X.to(dev), npass=4, out_scale=0.5, grad_hi=True)
+        assert max_err(dW, 0.5 * dY.bfloat16().double().T @ X.double()) / scale < TOL[4] * 3
+        assert max_err(db, 0.5 * dY.double().sum(0)) / scale < 1e-5
 
 
 def _attn_ref(q, k, v, H, mask=None, keep_sc=1.0):
@@ -267,6 +274,9 @@ def test_strip_linear(dev, M, N, K, elem):
     mask = keep_mask_t(seed, site, (M, N), p).double()
     out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res[:7].contiguous().to(dev), res_mod=7, x3=elem)
     assert rel_err(out, ref * mask * keep_scale(p) + res.double()[torch.arange(M) % 7]) < TOL[elem]
+    if elem == 4:       # HFTT_SL_X3_GRAD_HI: the strip (a gradient in the backward) enters as its bf16 rounding, the weights keep their pair
+        out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), residual=res.to(dev), x3=4, grad_hi=True)
+        assert rel_err(out, x.bfloat16().double() @ W.double().T + b.double() + res.double()) < TOL[4]
 
 
 @pytest.mark.parametrize('elem', [2, 4])
@@ -315,6 +325,9 @@ def test_gemm_tn_with_one_operand_stored_as_bf16(dev, M, N, K, side):
     scale = math.sqrt(M) * dY.float().abs().max().item()
     assert max_err(dW, ref) / scale < TOL[4] * 3
     assert max_err(db, 0.5 * dY.double().sum(0)) / scale < 1e-5
+    if side == 'X':     # + HFTT_TN_DY_HI: the plain bf16 product of the stored hidden and the rounded gradient (what the engine's dW2 is)
+        dW, db = ops.gemm_tn(dY.to(dev), X.to(dev), npass=4, out_scale=0.5, grad_hi=True)
+        assert max_err(dW, 0.5 * dY.bfloat16().double().T @ X.double()) / scale < TOL[4] * 3
 
 
 @pytest.mark.parametrize('hbf', [False, True])
@@ -350,3 +363,8 @@ def test_fused_ffn_forward_and_dx(dev, M, hbf):
     assert dh.dtype == hid.dtype
     assert rel_err(dh.float(), dh_ref) < (4e-3 if hbf else 6e-5)       # (stored copy; dx is formed from the full-width dh in registers)
     assert rel_err(dx, dh_ref @ W1.double() + res.double()) < 6e-5
+    # HFTT_SL_X3_GRAD_HI: dy and the dh formed from it enter their products as bf16 roundings
+    dx2, dh2 = ops.ffn_bwd_dx(dy.to(dev), wb, pf, hid, gate_scale=1.25, residual=res.to(dev), x3=True, grad_hi=True)
+    dh_r = torch.where(hid.cpu().double() > 0, (dy.bfloat16().double() @ W2.double()) * 1.25, torch.zeros((), dtype=torch.float64))
+    assert rel_err(dh2.float(), dh_r) < (4e-3 if hbf else 6e-5)
+    assert rel_err(dx2, dh_r.float().bfloat16().double() @ W1.double() + res.double()) < 1.5e-3      # (dh is rounded from the device's fp32 value, not from this fp64 one: ties fall either way)
