@@ -30,13 +30,14 @@ struct XfCfg {
   static constexpr int RSV = (DH == 64) ? ((KT == 8) ? 72 : 96) : 32;      // tr16 reads (see attn_fwd.hip)
   static constexpr int K_PL = LKP * RSK;              // elements of one K plane
   static constexpr int V_PL = LKP * RSV;
-  static constexpr int LDS_BYTES = (2 * K_PL + 2 * V_PL) * 2;
+  static constexpr int LDS_BYTES = (2 * K_PL + 2 * V_PL) * 2 + 8 * 32 * 4;      // + one 1/sum per query row and wave (fused loop below)
 };
 
 // NW waves per workgroup, one 32-query block per wave at a time: 8 waves for the long key axes (KT = 8: K + V take 147 KB of LDS, so one
 // workgroup per CU -- two waves per SIMD then let one wave's softmax run under the other's MFMAs, and the staging phase has twice the
 // threads), 4 otherwise
-template <int KT, int DH, int NW>
+// MAP: the attention map (g.probs) is an output -- the phase-wise form below; otherwise the fused per-tile loop
+template <int KT, int DH, int NW, bool MAP>
 __global__ __launch_bounds__(NW * 64) void x3_attn_fwd_kernel(const hftt_attn_desc g) {
   using Cfg = XfCfg<KT, DH>;
   constexpr int E = X3_F16;
@@ -141,6 +142,85 @@ __global__ __launch_bounds__(NW * 64) void x3_attn_fwd_kernel(const hftt_attn_de
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
     mx = xor32_max(mx);
+    if (!MAP) {
+      // ---- no attention map wanted (every launch but the last decoder layer's cross-attention): ONE loop over the key tiles --
+      // exponentials, row-sum contribution, dropout, fp16 split, then this tile's P.V MFMAs -- with the UNNORMALISED probabilities (<= 1,
+      // the maximum element exactly 1); 1/sum multiplies the 32 x dh output rows at the end.  The exponentials / dropout / split of tile
+      // kt + 1 then issue while the matrix pipe works on tile kt: in phases (all exponentials, all dropout, then P.V) the softmax's VALU
+      // work ran with the matrix pipe idle.
+      const long prow = (((long)seq * g.n_heads + head) * Lq + qrow) * (long)Lk;
+      const uint32_t q0lo = (uint32_t)((uint64_t)prow >> 2) + (uint32_t)(lh4 >> 2);
+      float sum = 0.f;
+      f32x16 oacc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[n][r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; kt++) {
+        float pt[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          pt[r] = __builtin_amdgcn_exp2f((sacc[kt][r] - mx) * c2);
+          sum += pt[r];
+        }
+        if (g.drop_p > 0.f) {        // (wave-uniform)
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            if (quad_ok) {
+              const uint32_t w = hftt_hash_mix(hk, q0lo + (uint32_t)(kt * 8 + 2 * c), 0u);      // keys kt*32 + 8c + 4lh + {0..3}
+              pt[4 * c] = (w & 0xFFu) < thr ? pt[4 * c] * inv_keep : 0.f;
+              pt[4 * c + 1] = ((w >> 8) & 0xFFu) < thr ? pt[4 * c + 1] * inv_keep : 0.f;
+              pt[4 * c + 2] = ((w >> 16) & 0xFFu) < thr ? pt[4 * c + 2] * inv_keep : 0.f;
+              pt[4 * c + 3] = (w >> 24) < thr ? pt[4 * c + 3] * inv_keep : 0.f;
+            } else {
+              const int key0 = kt * 32 + 8 * c + lh4;
+#pragma unroll
+              for (int e = 0; e < 4; e++)
+                pt[4 * c + e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(prow + key0 + e), thr) ? pt[4 * c + e] * inv_keep : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          bf16x8 ph, pl;
+          x3_split8<E>(pt + 8 * s2, ph, pl);
+#pragma unroll
+          for (int n = 0; n < NT; n++) {
+            const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
+            const int r0 = kt * 32 + 16 * s2 + 4 * lh + qq;     // + 8 for the second half of the fragment
+            const unsigned short* pvp = Vs + r0 * RSV + col;
+            const bf16x8 vh = join4(lds_read_tr16(pvp), lds_read_tr16(pvp + 8 * RSV));
+            const bf16x8 vl = join4(lds_read_tr16(pvp + V_PL), lds_read_tr16(pvp + V_PL + 8 * RSV));
+            oacc[n] = x3_mma<E>(ph, pl, vh, vl, oacc[n]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one tile at a time in program order (the MFMAs still run under the next tile's VALU work)
+      }
+      sum = xor32_sum(sum);
+      const float inv = 1.0f / sum;
+      if (lh == 0 && qrow < Lq) {
+        float* st = g.lse + (((long)seq * g.n_heads + head) * Lq + qrow) * 2;
+        st[0] = mx; st[1] = inv;
+      }
+      // the output tile has the QUERY on its register index (row acc_row32(r, lh)): 1/sum of those rows comes through 128 bytes of LDS
+      float* invs = reinterpret_cast<float*>(smem + (size_t)(2 * K_PL + 2 * V_PL) * 2) + wave * 32;
+      if (lh == 0) invs[lr] = inv;
+      const long oofs = (long)seq * g.o_seq_stride + head * DH;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; j4++) {
+        const float4 i4 = *reinterpret_cast<const float4*>(invs + 8 * j4 + lh4);      // rows 8*j4 + 4*lh + {0..3} = acc_row32(4*j4 + e, lh)
+        const float iv[4] = {i4.x, i4.y, i4.z, i4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int q = qb * 32 + 8 * j4 + lh4 + e;
+#pragma unroll
+          for (int n = 0; n < NT; n++)
+            if (q < Lq) g.out[oofs + (long)q * g.ldo + n * 32 + lr] = oacc[n][4 * j4 + e] * iv[e];
+        }
+      }
+      continue;
+    }
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
@@ -235,19 +315,23 @@ __global__ __launch_bounds__(NW * 64) void x3_attn_fwd_kernel(const hftt_attn_de
   }
 }
 
-template <int KT, int DH>
-int launch_xf(const hftt_attn_desc& d, hipStream_t st) {
+template <int KT, int DH, bool MAP>
+int launch_xf2(const hftt_attn_desc& d, hipStream_t st) {
   using Cfg = XfCfg<KT, DH>;
   constexpr int NW = (KT == 8) ? 8 : 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3_attn_fwd_kernel<KT, DH, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3_attn_fwd_kernel<KT, DH, NW, MAP>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) { hftt_set_error("x3_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((x3_attn_fwd_kernel<KT, DH, NW>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(NW * 64), Cfg::LDS_BYTES, st, d);
+  hipLaunchKernelGGL((x3_attn_fwd_kernel<KT, DH, NW, MAP>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(NW * 64), Cfg::LDS_BYTES, st, d);
   HFTT_CHECK_LAUNCH("x3_attn_fwd");
   return 0;
+}
+template <int KT, int DH>
+int launch_xf(const hftt_attn_desc& d, hipStream_t st) {
+  return d.probs != nullptr ? launch_xf2<KT, DH, true>(d, st) : launch_xf2<KT, DH, false>(d, st);
 }
 template <int DH>
 int dispatch_xf(const hftt_attn_desc& d, hipStream_t st) {
