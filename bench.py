@@ -158,39 +158,48 @@ def cpu_baseline(cfg, micro=2, accum=4, timed_steps=2):
                       % (clips, accum, micro, len(times), ' / '.join('%.1f' % t for t in times), threads)}
 
 
-def _newest_profile(suffix):
+_PROFILE_TINY = False        # set by main(): PMC summaries are quoted only from a profile of the same configuration
+
+
+def _profiles_newest_first(suffix):
+    """committed PMC summaries of this configuration (paper size / `--config tiny`), newest tag first"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix)))
-    return files[-1] if files else None
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix)), reverse=True):
+        try:
+            note = json.load(open(f)).get('note', '')
+        except Exception:
+            continue
+        if ('--config tiny' in note) == _PROFILE_TINY:
+            out.append(f)
+    return out
 
 
 def pmc_traffic_bytes(kernel_key, kind='bench'):
-    """(HBM bytes per launch of `kernel_key`, source file) from the newest committed PMC summary (profiles/*_bench_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, FETCH_SIZE doubled for gfx950); (None, None)
-    when that file has no such kernel symbol -- an older profile of a different kernel is never quoted."""
-    f = _newest_profile('_%s_pmc_traffic.json' % kind)
-    if f is None:
-        return None, None
-    try:
-        k = json.load(open(f))['kernels'].get(kernel_key)
-        if k is None:
-            return None, None
-        return (k['fetch_MB_per_launch_x2_corrected'] + k['write_MB_per_launch']) * 1e6, os.path.relpath(f, ROOT)
-    except Exception:
-        return None, None
+    """(HBM bytes per launch of `kernel_key`, source file) from the newest committed PMC summary of this configuration that has this
+    kernel symbol (profiles/*_bench_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command,
+    FETCH_SIZE doubled for gfx950); (None, None) when no committed profile has the symbol -- another kernel's figure is never quoted."""
+    for f in _profiles_newest_first('_%s_pmc_traffic.json' % kind):
+        try:
+            k = json.load(open(f))['kernels'].get(kernel_key)
+        except Exception:
+            k = None
+        if k is not None:
+            return (k['fetch_MB_per_launch_x2_corrected'] + k['write_MB_per_launch']) * 1e6, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def pmc_busy(kernel_key, kind='bench'):
-    """MFMA-busy fraction of `kernel_key` (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES... as tools/save_profiles.py derives it) from the newest
-    committed profiles/*_bench_pmc_busy.json, or None"""
-    f = _newest_profile('_%s_pmc_busy.json' % kind)
-    if f is None:
-        return None
-    try:
-        k = json.load(open(f))['kernels'].get(kernel_key)
-        return None if k is None else k.get('mfma_busy')
-    except Exception:
-        return None
+    """MFMA-busy fraction of `kernel_key` (as tools/save_profiles.py derives it) from the newest committed profiles/*_pmc_busy.json of this
+    configuration that has the symbol, or None"""
+    for f in _profiles_newest_first('_%s_pmc_busy.json' % kind):
+        try:
+            k = json.load(open(f))['kernels'].get(kernel_key)
+        except Exception:
+            k = None
+        if k is not None:
+            return k.get('mfma_busy')
+    return None
 
 
 def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench', mfma_passes=1):
@@ -292,6 +301,8 @@ def main():
         collective = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'devices': seen}
 
     cfg = CONFIGS[args.config]
+    global _PROFILE_TINY
+    _PROFILE_TINY = (args.config == 'tiny')
     B = args.batch
     model = build_model(cfg, 1234, args.dropout, dev)
     model.hftt_precision = args.precision

@@ -16,6 +16,12 @@
 #include "../../include/hftt_hip.h"
 #include <math.h>
 
+#ifdef HFTT_X3_ATTN_ABLATE
+#define XABL(g, bit) (((g).pad & (bit)) != 0)
+#else
+#define XABL(g, bit) false
+#endif
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         const int row = i / F4R, cs = i % F4R;
         if (qb * 32 + row >= Lq) { pq[u] = make_float4(0.f, 0.f, 0.f, 0.f); pdo[u] = pq[u]; po[u] = pq[u]; pl[u] = make_float2(0.f, 0.f); }
         uint2 hi, lo;
-        if (!(g.pad & 1)) {
+        if (!XABL(g, 1)) {
         x3_split4<EF>(pq[u], hi, lo);
         *reinterpret_cast<uint2*>(Qf + row * RSQ + cs * 4) = hi;
         *reinterpret_cast<uint2*>(Qf + Q_PL + row * RSQ + cs * 4) = lo;
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     f32x16 sacc, pacc;
 #pragma unroll
     for (int r = 0; r < 16; r++) { sacc[r] = 0.f; pacc[r] = 0.f; }
-    if (!(g.pad & 2))
+    if (!XABL(g, 2))
 #pragma unroll
     for (int s = 0; s < KS; s++) {
       const int off = lr * RSQ + 16 * s + 8 * lh;
@@ -571,12 +577,12 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         }
       }
     };
-    if (g.pad & 4) {
+    if (XABL(g, 4)) {
     } else if (g.drop_p > 0.f) {
       if (pair_ok) softmax_bwd(std::true_type{}, std::true_type{}); else softmax_bwd(std::true_type{}, std::false_type{});
     } else softmax_bwd(std::false_type{}, std::false_type{});
     // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS ----
-    if (!(g.pad & 8))
+    if (!XABL(g, 8))
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++) {
       __builtin_amdgcn_sched_barrier(0);
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       }
     }
     // ---- (g) dS -> LDS [query][key], bf16 pair.  Lanes 2i / 2i+1 hold adjacent keys: one packed pair (ds_write_b32) per register pair ----
-    if (!(g.pad & 16)) {
+    if (!XABL(g, 16)) {
       const bool odd = lane & 1;
 #pragma unroll
       for (int rp = 0; rp < 8; rp++) {
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
 
     // ---- (i) dQ block = dS . K with 16x16 tiles spread over the waves ----
     constexpr int CT = DH / 16;
-    for (int t = wave; t < 2 * CT && !(g.pad & 16); t += KT) {
+    for (int t = wave; t < 2 * CT && !XABL(g, 16); t += KT) {
       const int qh2 = t / CT, ct = t % CT;
       f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int q = qb * 32 + qh2 * 16 + gi * 4 + r;
-        if (q < Lq && !(g.pad & 32)) g.dq[dqofs + (long)q * g.lddq + ct * 16 + (lane & 15)] = a4[r];
+        if (q < Lq && !XABL(g, 32)) g.dq[dqofs + (long)q * g.lddq + ct * 16 + (lane & 15)] = a4[r];
       }
     }
     // no barrier needed here: the next iteration's staging touches only Qf / Qb / Ob / statistics, which no wave reads in (i);
@@ -701,11 +707,16 @@ int dispatch_xb(const hftt_attn_desc& d, hipStream_t st) {
 int hftt_x3_attn_fwd(const hftt_attn_desc& d, hipStream_t st) {
   return d.dh == 64 ? dispatch_xf<64>(d, st) : dispatch_xf<32>(d, st);
 }
-// HFTT_X3_ATTN_DEBUG (timing experiments on the backward, results garbage): 1 no Q / dO staging conversions, 2 no S / dP MFMAs,
+// Ablation build only (tools/ablate_x3_attn.sh, -DHFTT_X3_ATTN_ABLATE): HFTT_X3_ATTN_DEBUG switches mechanisms of the backward off
+// (timing experiments, results garbage): 1 no Q / dO staging conversions, 2 no S / dP MFMAs,
 // 4 no softmax-backward arithmetic, 8 no dV / dK products (splits + MFMAs), 16 no dS -> LDS and no dQ product, 32 no dQ stores
 static int x3_attn_debug() { static const int v = [] { const char* e = getenv("HFTT_X3_ATTN_DEBUG"); return e ? atoi(e) : 0; }(); return v; }
 int hftt_x3_attn_bwd(const hftt_attn_desc& d0, hipStream_t st) {
   hftt_attn_desc d = d0;
+#ifdef HFTT_X3_ATTN_ABLATE
   d.pad = (uint32_t)x3_attn_debug();
+#else
+  d.pad = 0;
+#endif
   return d.dh == 64 ? dispatch_xb<64>(d, st) : dispatch_xb<32>(d, st);
 }
