@@ -21,6 +21,14 @@
 #include "x3_internal.h"
 #include "../../include/hftt_hip.h"
 
+// Timing switches (HFTT_X3_DEBUG, results garbage) exist in the ablation build only (-DHFTT_X3_STRIP_ABLATE, tools/bench_x3.py): as run-time
+// tests inside the slot loops they are not free (the same switches cost the attention backward 24 %).
+#ifdef HFTT_X3_STRIP_ABLATE
+#define XDBG(g, bit) (((g).pad & (bit)) != 0)
+#else
+#define XDBG(g, bit) false
+#endif
+
 namespace {
 
 #include "strip_pipe.h"
@@ -304,8 +312,8 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
   P.w = g.w; P.S = STEPS * 16; P.fill_pos = 0;
   P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
   P.wave = wave; P.lane = lane;
-  P.nofill = g.pad & 1; P.nobar = g.pad & 2;
-  const bool dbg_nostore = g.pad & 16, dbg_noload = g.pad & 32, dbg_noconv = g.pad & 64;
+  P.nofill = XDBG(g, 1); P.nobar = XDBG(g, 2);
+  const bool dbg_nostore = XDBG(g, 16), dbg_noload = XDBG(g, 32), dbg_noconv = XDBG(g, 64);
 
   auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
 
@@ -443,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
   P.w = g.w; P.S = 2 * NT; P.fill_pos = 0;
   P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
   P.wave = wave; P.lane = lane;
-  P.nofill = g.pad & 1; P.nobar = g.pad & 2;
-  const bool dbg_nostore = g.pad & 16;
+  P.nofill = XDBG(g, 1); P.nobar = XDBG(g, 2);
+  const bool dbg_nostore = XDBG(g, 16);
 
   auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
   for (int i = tid; i < g.N; i += 256) prm[i] = g.bias != nullptr ? g.bias[i] : 0.f;
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
   P.w = g.w; P.S = 4 * PT; P.fill_pos = 0;
   P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
   P.wave = wave; P.lane = lane;
-  P.nofill = g.pad & 1; P.nobar = g.pad & 2;
+  P.nofill = XDBG(g, 1); P.nobar = XDBG(g, 2);
 
   auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
 
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
         for (int q = 0; q < 16; q++) gcur[q] = gnext[q];
       }
       P.begin_slot();
-      if (!(g.pad & 256))
+      if (!XDBG(g, 256))
       x3_slot_chunks<E, 0>(abase + 0 * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<0>();
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
         }
       });
       P.begin_slot();
-      if (!(g.pad & 256))
+      if (!XDBG(g, 256))
       x3_slot_chunks<E, 8>(abase + 1 * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<1>();
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       if (MODE == 0) {
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = fmaxf(hacc[q], 0.f);
-        if (g.drop_p > 0.f && !(g.pad & 128)) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 2), thr, inv_keep);
+        if (g.drop_p > 0.f && !XDBG(g, 128)) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 2), thr, inv_keep);
       } else {
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = gcur[q] > 0.f ? hacc[q] * g.gate_scale : 0.f;
@@ -664,17 +672,17 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       unsigned short* hwave16 = hob16 + (blk * 128 + wave * 32) * g.ldh + t * 32;
       // ---- second GEMM, K-slice t (u = 0, 1); the hidden tile's stores ride behind the first MFMAs ----
       P.begin_slot();
-      if (!(g.pad & 512))
+      if (!XDBG(g, 512))
       x3_slot_tiles<E>(abase + 2 * SLOT_BYTES, hf[0], yacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<2>();
         if (i == 4 && st_h) {
-          if (HH) tile_store_rows_bf16(stage, v, j, hb, lane, hwave16, g.ldh, wave_ok && !(g.pad & 16));
-          else tile_store_rows(stage, v, j, hb, lane, hwave, g.ldh, wave_ok && !(g.pad & 16));
+          if (HH) tile_store_rows_bf16(stage, v, j, hb, lane, hwave16, g.ldh, wave_ok && !XDBG(g, 16));
+          else tile_store_rows(stage, v, j, hb, lane, hwave, g.ldh, wave_ok && !XDBG(g, 16));
         }
       });
       P.begin_slot();
-      if (!(g.pad & 512))
+      if (!XDBG(g, 512))
       x3_slot_tiles<E>(abase + 3 * SLOT_BYTES, hf[1], yacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<3>();
