@@ -26,6 +26,16 @@
 #include "strip_internal.h"
 #include "../../include/hftt_hip.h"
 
+// Timing switches / clock stamps (HFTT_STRIP2_DEBUG, results garbage) exist in the ablation and stamp builds only (-DHFTT_STRIP2_ABLATE,
+// -DHFTT_STRIP_STAMPS): as run-time tests inside the slot loops they cost ~1 % of the step.
+#if defined(HFTT_STRIP2_ABLATE) || defined(HFTT_STRIP_STAMPS)
+#define S2DBG(g, bit) (((g).pad & (bit)) != 0)
+#define S2PAD(g) ((g).pad)
+#else
+#define S2DBG(g, bit) false
+#define S2PAD(g) 0
+#endif
+
 namespace {
 
 #include "strip_pipe.h"
@@ -157,13 +167,13 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   constexpr bool has_res = HR;                      // residual rows are prefetched into the pending registers (a template parameter: no per-slot test)
 
   Pipe P;
-  P.w = g.w; P.S = steps * 8; P.nofill = g.pad & 1; P.fill_pos = 0; P.nobar = g.pad & 2;
+  P.w = g.w; P.S = steps * 8; P.nofill = S2DBG(g, 1); P.fill_pos = 0; P.nobar = S2DBG(g, 2);
   P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
   P.wave = wave; P.lane = lane; P.issued = 0;
 
   auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
 #ifdef HFTT_STRIP_STAMPS
-  if (!LN && (g.pad & 4) && tid == 0) (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[34] = __builtin_amdgcn_s_memtime();
+  if (!LN && S2DBG(g, 4) && tid == 0) (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[34] = __builtin_amdgcn_s_memtime();
 #endif
 
   // ---- prologue: parameters to LDS (compiler loads), first block's activations, first ring slots
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
 
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
 #ifdef HFTT_STRIP_STAMPS
-    const bool bstamp = !LN && (g.pad & 4) && blk == (long)blockIdx.x + gridDim.x && tid == 0;
+    const bool bstamp = !LN && S2DBG(g, 4) && blk == (long)blockIdx.x + gridDim.x && tid == 0;
     unsigned long long* bsb = reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40;
     if (bstamp) bsb[36] = __builtin_amdgcn_s_memtime();
 #endif
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
         // -DHFTT_STRIP_STAMPS builds only (tools/stamp_linear2.sh), HFTT_STRIP2_DEBUG & 4, !LN: thread 0 of each workgroup's SECOND block stamps the shader clock around the phases of every
         // slot of pass 1 into the (otherwise unused) ln_mean buffer: [workgroup][slot 0..7][4] + [workgroup][8][0..1] for the pass epilogue
 #ifdef HFTT_STRIP_STAMPS
-        const bool stamp = !LN && (g.pad & 4) && pass == (int)((g.pad >> 8) & 3) && kc == 0 && blk == (long)blockIdx.x + gridDim.x && tid == 0;
+        const bool stamp = !LN && S2DBG(g, 4) && pass == (int)((S2PAD(g) >> 8) & 3) && kc == 0 && blk == (long)blockIdx.x + gridDim.x && tid == 0;
         unsigned long long* sb = reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40;
 #define L2STAMP(k) do { if (stamp) sb[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -254,8 +264,8 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
                          [&](auto i_c) __attribute__((always_inline)) {
                            constexpr int i = decltype(i_c)::value;
                            if (i == 1) P.template fill_piece<BUF, 0>();
-                           if (i == 4) { if (pf_x && !(g.pad & 32)) { pload16(xn[2 * pt], pf_src + piece_off(2 * pt)); pload16(xn[2 * pt + 1], pf_src + piece_off(2 * pt + 1)); } }
-                           if (i == 7) { if (pend_valid && !(g.pad & 16)) { astore16(pend_ptr + piece_off(2 * pt), pend[2 * pt]); astore16(pend_ptr + piece_off(2 * pt + 1), pend[2 * pt + 1]); } }
+                           if (i == 4) { if (pf_x && !S2DBG(g, 32)) { pload16(xn[2 * pt], pf_src + piece_off(2 * pt)); pload16(xn[2 * pt + 1], pf_src + piece_off(2 * pt + 1)); } }
+                           if (i == 7) { if (pend_valid && !S2DBG(g, 16)) { astore16(pend_ptr + piece_off(2 * pt), pend[2 * pt]); astore16(pend_ptr + piece_off(2 * pt + 1), pend[2 * pt + 1]); } }
                            if (i == 10) { if (HR && pf_res) { pload16(pend[2 * pt], res_src + piece_off(2 * pt)); pload16(pend[2 * pt + 1], res_src + piece_off(2 * pt + 1)); } }
                            if (i == 12) P.template fill_close<BUF>();
                          });
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
       if (bstamp && pass == passes - 1) bsb[38] = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef HFTT_STRIP_STAMPS
-      if (!LN && (g.pad & 4) && pass == (int)((g.pad >> 8) & 3) && blk == (long)blockIdx.x + gridDim.x && tid == 0)
+      if (!LN && S2DBG(g, 4) && pass == (int)((S2PAD(g) >> 8) & 3) && blk == (long)blockIdx.x + gridDim.x && tid == 0)
         (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[33] = __builtin_amdgcn_s_memtime();
 #endif
     }
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   }
   P.drain();
 #ifdef HFTT_STRIP_STAMPS
-  if (!LN && (g.pad & 4) && tid == 0) (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[35] = __builtin_amdgcn_s_memtime();
+  if (!LN && S2DBG(g, 4) && tid == 0) (reinterpret_cast<unsigned long long*>(g.ln_mean) + (long)blockIdx.x * 40)[35] = __builtin_amdgcn_s_memtime();
 #endif
 }
 
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
   const bool has_res = (MODE == 1) && g.residual != nullptr;
 
   PipeDyn P;
-  P.w = g.w; P.S = 2 * PT; P.fill_left = (g.pad & 1) ? 0 : my_blocks * P.S; P.fill_pos = 0; P.nobar = g.pad & 2; P.closing = false;
+  P.w = g.w; P.S = 2 * PT; P.fill_left = S2DBG(g, 1) ? 0 : my_blocks * P.S; P.fill_pos = 0; P.nobar = S2DBG(g, 2); P.closing = false;
   P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
   P.wave = wave; P.lane = lane; P.issued = 0;
 #pragma unroll
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
       constexpr int t = decltype(t_c)::value;
       // ---- first GEMM, hidden tile t ----
       constexpr int BA = (2 * t) & 3, BB = (2 * t + 1) & 3;
-      const bool stamp = MODE == 0 && (g.pad & 4) && (t == 4 || t == 5) && blk == (long)blockIdx.x + gridDim.x && tid == 0;
+      const bool stamp = MODE == 0 && S2DBG(g, 4) && (t == 4 || t == 5) && blk == (long)blockIdx.x + gridDim.x && tid == 0;
       unsigned long long* sb = reinterpret_cast<unsigned long long*>(const_cast<unsigned short*>(g.gate)) + (long)blockIdx.x * 16 + (t - 4) * 8;
       if (stamp) sb[0] = __builtin_amdgcn_s_memtime();
       P.template begin_slot<BA>();
