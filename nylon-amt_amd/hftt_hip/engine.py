@@ -126,7 +126,7 @@ class HfttEngine:
         # Option (HFTT_X3_GRAD_HI=1): the GRADIENT operand of every GEMM-shaped backward product (dY of dW = dY^T X, the strip of a dX kernel,
         # A of the block dX GEMMs) enters as its bf16 rounding only -- two MFMA passes against the saved operand's / the weights' bf16 pair
         # instead of three: +3.5 % (260 against 251 clips/s on one box), every gradient tensor's cosine against the exact-fp32 mode still
-        # >= 0.9999 at paper size, but the gradients move from 2e-4 to 3e-3 .. 6e-3 of the oracle's (relative to the tensor's maximum) --
+        # >= 0.9999 at paper size, but the gradients move from 2e-4 to 3e-3 .. 6e-3 of the fp32 reference's (relative to the tensor's maximum) --
         # outside the 1e-3 the default mode keeps for gradients too, hence opt-in.
         self.g8 = self.x3 and os.environ.get('HFTT_X3_GRAD_HI', '0') == '1'
         self._prepared_frozen = False
