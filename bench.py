@@ -478,6 +478,16 @@ def main():
                                        'the two velocity-logit tensors against the benchmarked mode "%s" (eval forward)' % (m, args.precision)}
                 if 'roofline_ffn' in inf[m]:
                     extras[key]['roofline_ffn'] = inf[m]['roofline_ffn']
+            if args.precision == 'x3' and args.config == 'paper':
+                # the opt-in of DESIGN.md section 3: gradient operands of the backward GEMMs as their bf16 rounding (two MFMA passes)
+                os.environ['HFTT_X3_GRAD_HI'] = '1'
+                model.hftt_precision = 'bf16'; model.hftt_engine()          # (the engine reads the switch when its precision is set)
+                try:
+                    extras['x3_gradient_rounding_option'] = {'clips_per_s': train_leg('x3'), 'env': 'HFTT_X3_GRAD_HI=1', 'default': False,
+                                                             'what': 'x3 with the gradient operand of every backward GEMM rounded to bf16 (same forward: same outputs)'}
+                finally:
+                    del os.environ['HFTT_X3_GRAD_HI']
+                    model.hftt_precision = 'bf16'; model.hftt_engine()
             model.hftt_precision = args.precision
             # ---- compatibility path: the reference's loop unchanged (torch.optim.Adam, 8 nn criteria, loss.backward()) through training.train
             import torch.nn as nn
