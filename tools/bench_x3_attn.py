@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'nylon-amt_amd'))
 from hftt_hip import ops
 dev = torch.device('cuda:0')
-n, H, L, dh = 1024, 4, 256, 64
+n, H, L, dh = int(os.environ.get('NSEQ', 1024)), 4, int(os.environ.get('L', 256)), 64
 d = H * dh
 g = torch.Generator().manual_seed(1)
 qkv = torch.randn(n * L, 3 * d, generator=g).to(dev).view(n, L, 3 * d)
