@@ -106,7 +106,7 @@ def host_cpu():
     return max(1, n), model or 'unknown'
 
 
-def cpu_baseline(cfg, micro=2, accum=4, timed_steps=2):
+def cpu_baseline(cfg, micro=2, accum=4, timed_steps=2, config_name='paper'):
     """The CPU oracle (a port of the reference algorithm in plain PyTorch fp32) on the host cores, SAME model config and batch as the
     measured leg: a step = `accum` micro-batches of `micro` clips with gradient accumulation (8 clips) + Adam.  One untimed micro-batch
     warms the allocator, then `timed_steps` whole steps are timed."""
@@ -152,27 +152,45 @@ def cpu_baseline(cfg, micro=2, accum=4, timed_steps=2):
     clips = micro * accum
     return {'value': clips * len(times) / sum(times), 'unit': 'clips/s', 'cores': threads, 'kind': 'port', 'cpu_model': model_name,
             'host_physical_cores': physical, 'thread_sweep_s_per_micro_batch': {str(k): round(v, 2) for k, v in sweep.items()},
-            'sample': 'paper-size hFT, fp32, dropout 0.1, batch %d as %d micro-batches of %d clips with gradient accumulation: 1 warm-up '
+            'sample': '%s-size hFT (d=%d, ff=%d, %d+%d layers), fp32, dropout 0.1, batch %d as %d micro-batches of %d clips with gradient accumulation: 1 warm-up '
                       'micro-batch + %d timed steps of forward+loss+backward+Adam (%s s) with the pure-PyTorch CPU oracle on %d threads (the fastest of a '
                       '32 / 64 / all-physical-cores sweep over one micro-batch each)'
-                      % (clips, accum, micro, len(times), ' / '.join('%.1f' % t for t in times), threads)}
+                      % (config_name, cfg.hid_dim, cfg.pf_dim, cfg.enc_layer, cfg.dec_layer, clips, accum, micro, len(times), ' / '.join('%.1f' % t for t in times), threads)}
 
 
-_PROFILE_TINY = False        # set by main(): PMC summaries are quoted only from a profile of the same configuration
+_PROFILE_CONFIG = 'paper'        # set by main(): PMC summaries are quoted only from a profile of the same configuration and precision mode
+_PROFILE_PRECISION = 'x3'
 
 
 def _profiles_newest_first(suffix):
-    """committed PMC summaries of this configuration (paper size / `--config tiny`), newest tag first"""
+    """committed PMC summaries of this configuration and precision mode, newest tag first.  tools/save_profiles.py writes explicit
+    `config` / `precision` fields (round 4 on); older summaries carry neither and are told apart by the kernel symbols they hold."""
     import glob
     out = []
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix)), reverse=True):
         try:
-            note = json.load(open(f)).get('note', '')
+            j = json.load(open(f))
         except Exception:
             continue
-        if ('--config tiny' in note) == _PROFILE_TINY:
-            out.append(f)
+        if 'config' in j:
+            if j['config'] == _PROFILE_CONFIG and j.get('precision', 'x3') == _PROFILE_PRECISION:
+                out.append(f)
+        elif (('--config tiny' in j.get('note', '')) == (_PROFILE_CONFIG == 'tiny')):
+            out.append(f)          # (pre-round-4 file: pmc_traffic_bytes / pmc_busy still only quote it when it has the exact kernel symbol)
     return out
+
+
+def pmc_step_bytes():
+    """(HBM bytes per training step summed over every kernel, source file) from the newest committed traffic summary of this configuration
+    and precision mode that carries the total, or (None, None)"""
+    for f in _profiles_newest_first('_bench_pmc_traffic.json'):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get('hbm_bytes_per_step') and j.get('config') == _PROFILE_CONFIG and j.get('precision') == _PROFILE_PRECISION:
+            return float(j['hbm_bytes_per_step']), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def pmc_traffic_bytes(kernel_key, kind='bench'):
@@ -216,10 +234,11 @@ def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench', mfma_passes=
     # (PMC figures are per-launch averages over ALL launches of the kernel symbol in the profiled command: `kind` picks the training step's
     # files or the inference plan's)
     traffic, src = pmc_traffic_bytes(key, kind)
-    if mfma_passes != 1:
-        # split-operand mode: `achieved` counts ALGORITHMIC flops (one multiply-add per product of the reference's arithmetic); the matrix
-        # pipe executes `mfma_passes` bf16-rate passes per product, so its own utilisation is mfma_passes x that
-        roof.update({'mfma_passes': mfma_passes, 'matrix_pipe_tflops': mfma_passes * tf, 'matrix_pipe_frac_of_bf16_peak': mfma_passes * tf / PEAK_BF16_TFLOPS})
+    # two unambiguous fractions of the dense bf16 MFMA peak, whatever `bound` says: the ALGORITHMIC one (one multiply-add per product of the
+    # reference's arithmetic -- what north_star's ">= 40 % on the FFN GEMMs" is priced in) and the matrix pipe's own (the split-operand mode
+    # executes `mfma_passes` bf16-rate passes per product, so the pipe is mfma_passes x as busy as the algorithmic figure says)
+    roof.update({'mfma_passes': mfma_passes, 'frac_of_bf16_mfma_peak': tf / PEAK_BF16_TFLOPS, 'matrix_pipe_tflops': mfma_passes * tf,
+                 'matrix_pipe_frac_of_bf16_peak': mfma_passes * tf / PEAK_BF16_TFLOPS})
     roof.update({'traffic': traffic, 'traffic_source': src, 'mfma_busy': pmc_busy(key, kind), 'kernel': key,
                  'launches_per_step': v['launches'] / steps, 'avg_launch_ms': v['ms'] / v['launches'],
                  'share_of_step_device_time': v['ms'] / max(total_ms, 1e-9), 'arithmetic_intensity': ai,
@@ -301,8 +320,8 @@ def main():
         collective = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'devices': seen}
 
     cfg = CONFIGS[args.config]
-    global _PROFILE_TINY
-    _PROFILE_TINY = (args.config == 'tiny')
+    global _PROFILE_CONFIG, _PROFILE_PRECISION
+    _PROFILE_CONFIG, _PROFILE_PRECISION = args.config, args.precision
     B = args.batch
     model = build_model(cfg, 1234, args.dropout, dev)
     model.hftt_precision = args.precision
@@ -506,7 +525,9 @@ def main():
             'metric': 'training clips/sec (128-frame x 256-bin)', 'value': value, 'unit': 'clips/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'x3': 'f16x3 (split fp16 / bf16 operands, three bf16-rate MFMA passes, fp32 accumulate and storage)', 'bf16': 'bf16', 'parity': 'f32'}[args.precision],
+            'dtype': {'x3': 'f16x3 (split fp16 / bf16 operand pairs, three bf16-rate MFMA passes per product, fp32 accumulate; tensors that flow between '
+                            'kernels are fp32 (attention q/k/v as fp16 hi+lo pairs), the copies SAVED only for the backward -- FFN hidden, its gradient, '
+                            'pre-LayerNorm sums -- are bf16)', 'bf16': 'bf16', 'parity': 'f32'}[args.precision],
             'data': 'synthetic' if args.data == 'synthetic' else 'synthetic (MAESTRO-format store resident in HBM, clips gathered inside the step)',
             'config': {'workload': '%s-size hFT-Transformer training step (d=%d, ff=%d, %d+%d layers, %d heads), batch %d clips/GPU, '
                                    'dropout %.2f, forward+loss+backward+Adam' % (args.config, cfg.hid_dim, cfg.pf_dim, cfg.enc_layer, cfg.dec_layer,
@@ -520,9 +541,15 @@ def main():
             'kernels': kernels,
             'collective': collective,
         }
+        step_bytes, step_src = pmc_step_bytes()
+        if step_bytes is not None:
+            # whole-step HBM traffic (PMC sum over every kernel of a profiled run of this same command) over THIS run's step time
+            result['hbm_bytes_per_step'] = step_bytes
+            result['hbm_frac_of_peak'] = step_bytes / (dt / args.steps) / (PEAK_HBM_GBS * 1e9)
+            result['hbm_bytes_source'] = step_src
         result.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(cfg)
+            result['cpu_baseline'] = cpu_baseline(cfg, config_name=args.config)
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result))

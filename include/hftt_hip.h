@@ -261,7 +261,8 @@ typedef struct {
   float* lse;                 /* [n_seq, n_heads, Lq, 2]: (row max, 1 / sum(exp(score - max))); the max is of the scaled scores, except
                                  in the npass == 2 kernels and the npass == 1 kernels with q, k, v AND out stored as bf16, which keep the
                                  max of the RAW Q.K^T (before the 1/sqrt(dh)) -- an opaque pair between a forward and the backward of
-                                 the SAME npass and storage flags */
+                                 the SAME npass, storage flags AND strides (the all-bf16 form also needs every row / sequence stride of
+                                 q, k, v, out to be a multiple of 8 elements; forward and backward test that with one shared predicate) */
   float* probs;               /* [n_seq, n_heads, Lq, Lk] or NULL */
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   /* backward only */

@@ -20,9 +20,12 @@ HEADERS = [os.path.join(CSRC, 'hftt_common.h'), os.path.join(CSRC, 'hftt_host.h'
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
 # HFTT_BUILD_EXPERIMENTS=1: also build csrc/experiments/ (three alternative schedules of the bf16 strip tiling, each measured slower than
 # the shipped one: DESIGN.md section 4) and let HFTT_STRIP_V3 / V4 / V5 select them; the default library does not carry them
+# -- into a library of its own (libhftt_hip_x.so, which hftt_hip/_capi.py loads under the same switch), so switching the flag off again can
+# never leave the experiments build behind under the product library's name
 if os.environ.get('HFTT_BUILD_EXPERIMENTS') == '1':
     SOURCES += ['experiments/strip_gemm3.hip', 'experiments/strip_gemm4.hip', 'experiments/strip_gemm5.hip']
     FLAGS += ['-DHFTT_STRIP_EXPERIMENTS']
+    LIB = os.path.join(LIBDIR, 'libhftt_hip_x.so')
 
 
 def _hipcc():

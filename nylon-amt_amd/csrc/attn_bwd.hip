@@ -544,9 +544,7 @@ extern "C" int hftt_attn_bwd(const hftt_attn_desc* d0, void* stream) {
 #endif
   const hftt_attn_desc* d = &dd;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
-  const bool hb = (d->io_flags & all_half) == all_half && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 8 == 0 &&
-                  d->q_seq_stride % 8 == 0 && d->k_seq_stride % 8 == 0 && d->v_seq_stride % 8 == 0 && d->o_seq_stride % 8 == 0;
+  const bool hb = hftt_attn_hb_form(*d);      // the forward's predicate: lse[0] is the raw maximum exactly when the forward ran this form
   HFTT_REQUIRE(!(d->io_flags & HFTT_ATTN_DQ_BF16) || (d->lddq % 2 == 0 && d->dq_seq_stride % 2 == 0), "attn_bwd: bf16 dq needs even strides");
   if (d->npass == 2) return hftt_x3_attn_bwd(*d, st);
   if (d->npass == 3) return d->dh == 64 ? dispatch_ab<64, 3, false>(*d, st) : dispatch_ab<32, 3, false>(*d, st);

@@ -428,10 +428,14 @@ extern "C" int hftt_attn_fwd(const hftt_attn_desc* d0, void* stream) {
     if (rc8 >= 0) return rc8;
   }
 #endif
-  const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
-  const bool hb = (d->io_flags & all_half) == all_half && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 2 == 0 &&
-                  d->q_seq_stride % 8 == 0 && d->k_seq_stride % 8 == 0 && d->v_seq_stride % 8 == 0 && d->o_seq_stride % 2 == 0;
+  const bool hb = hftt_attn_hb_form(*d);
   if (d->npass == 3) return d->dh == 64 ? dispatch_af<64, 3, false>(*d, st) : dispatch_af<32, 3, false>(*d, st);
   if (d->dh == 64) return hb ? dispatch_af<64, 1, true>(*d, st) : dispatch_af<64, 1, false>(*d, st);
   return hb ? dispatch_af<32, 1, true>(*d, st) : dispatch_af<32, 1, false>(*d, st);
+}
+
+bool hftt_attn_hb_form(const hftt_attn_desc& d) {
+  const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
+  return (d.io_flags & all_half) == all_half && d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 8 == 0 &&
+         d.q_seq_stride % 8 == 0 && d.k_seq_stride % 8 == 0 && d.v_seq_stride % 8 == 0 && d.o_seq_stride % 8 == 0;
 }

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "hftt_common.h"
 #include "hftt_host.h"
+#include "x3_internal.h"
 #include "../../include/hftt_hip.h"
 #include <math.h>
 
@@ -197,10 +198,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const hftt_attn_desc 
 int hftt_attn_fwd8_try(const hftt_attn_desc& d, hipStream_t st) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("HFTT_ATTN_FWD8"); enabled = !(e && e[0] == '0'); }
-  const unsigned all_half = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16;
-  if (!enabled || d.npass != 1 || d.dh != 64 || (d.io_flags & all_half) != all_half || d.probs != nullptr) return -1;
+  if (!enabled || d.npass != 1 || d.dh != 64 || d.probs != nullptr || !hftt_attn_hb_form(d)) return -1;
   if (d.Lk <= 128 || d.Lk > 256 || d.Lq <= 128 || d.Lq > 256) return -1;                 // long rows, and enough query blocks for the 8 waves
-  if (d.ldq % 8 || d.ldk % 8 || d.ldv % 8 || d.ldo % 2 || d.q_seq_stride % 8 || d.k_seq_stride % 8 || d.v_seq_stride % 8 || d.o_seq_stride % 2) return -1;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES8);

@@ -36,6 +36,13 @@ struct X3<X3_F16> {
     const f32x2_t v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
   }
+  // the lo half is NOT clamped: for a finite |x| <= 65504 it is below one fp16 ulp of hi anyway, and a NaN / Inf input -- which v_med3_f32
+  // turns into a finite hi (it returns the minimum of the other two operands for a NaN) -- reappears here as x - hi = NaN / Inf, so a diverged
+  // tensor still poisons every product it enters instead of being laundered into +-65504; 65504 < |x| <= 131008 stays exact
+  static __device__ __forceinline__ unsigned pk_lo(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  }
   static __device__ __forceinline__ void unpk(unsigned p, float& a, float& b) {
     const f32x2_t v = __builtin_convertvector(__builtin_bit_cast(f16x2_t, p), f32x2_t);
     a = v[0]; b = v[1];
@@ -54,6 +61,7 @@ struct X3<X3_BF16> {
     const f32x2_t v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
   }
+  static __device__ __forceinline__ unsigned pk_lo(float a, float b) { return pk(a, b); }
   static __device__ __forceinline__ void unpk(unsigned p, float& a, float& b) {
     a = __uint_as_float(p << 16); b = __uint_as_float(p & 0xFFFF0000u);
   }
@@ -70,7 +78,7 @@ __device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsign
   hi = X3<E>::pk(a, b);
   float ha, hb;
   X3<E>::unpk(hi, ha, hb);
-  lo = X3<E>::pk(a - ha, b - hb);
+  lo = X3<E>::pk_lo(a - ha, b - hb);
 }
 // four consecutive elements -> 8 bytes of the hi plane + 8 bytes of the lo plane
 template <int E>

@@ -7,3 +7,8 @@ int hftt_x3_attn_fwd(const hftt_attn_desc& d, hipStream_t st);      // x3_attn.h
 int hftt_x3_attn_bwd(const hftt_attn_desc& d, hipStream_t st);
 int hftt_x3_strip_linear(const hftt_strip_desc& d, hipStream_t st);  // x3_strip.hip
 int hftt_x3_strip_mlp(const hftt_ffn_desc& d, hipStream_t st);
+
+// The "all-bf16 stream" form of the attention kernels (bf16 mode): q, k, v, out stored as bf16 with every row / sequence stride a multiple
+// of 8 elements.  ONE predicate for attn_fwd.hip, attn_fwd8.hip and attn_bwd.hip: in this form lse[0] holds the RAW row maximum (the
+// scaled maximum otherwise), so forward and backward must agree on it for every descriptor.
+bool hftt_attn_hb_form(const hftt_attn_desc& d);

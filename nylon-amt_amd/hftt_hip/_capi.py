@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('HFTT_LIB_PATH') or os.path.join(_HERE, '..', 'lib', 'libhftt_hip.so')      # HFTT_LIB_PATH: dev builds (tools/ablate_strip.sh)
+LIB_PATH = os.environ.get('HFTT_LIB_PATH') or os.path.join(_HERE, '..', 'lib', 'libhftt_hip_x.so' if os.environ.get('HFTT_BUILD_EXPERIMENTS') == '1' else 'libhftt_hip.so')      # HFTT_LIB_PATH: dev builds (tools/ablate_strip.sh)
 
 c_f32p = C.c_void_p   # device pointers travel as plain integers
 c_u16p = C.c_void_p

@@ -674,18 +674,30 @@ class HfttEngine:
         if not self.is_bound():
             raise _capi.HfttError('engine parameters are not bound')
         ws = {'bufs': {}, 'drop': [], 'keep': [], 'tn': [], 'ln': [], 'B': B}
-        self._site = 0
-        self._build_forward(ws, save=True)
-        if self.strip:                               # inference plan: same buffers, nothing saved for a backward
-            n_sites = self._site
-            self._site = 0
-            self._build_forward(ws, save=False)
-            assert self._site == n_sites
-        self._in_backward = True
+        # The x3 strip kernels take whole 32-token strips (hftt_x3_strip_linear / hftt_x3_strip_mlp: M % 32 == 0).  A batch whose token counts
+        # are not multiples of 32 (B * T % 4 != 0 with 88 notes: odd batch x odd frame count) gets the block-GEMM plans of the same precision
+        # for THIS workspace only -- same arithmetic (npass 2 / 4 in gemm_nt / gemm_tn), fp32 saved tensors.
+        Se, Sn = B * self.T * self.F, B * self.T * self.N
+        strip_here = self.strip and not (self.x3 and (Se % 32 or Sn % 32))
+        saved_mode = (self.strip, self.bfs, self.hh)
+        if not strip_here:
+            self.strip = self.bfs = self.hh = False
+        ws['strip'] = strip_here
         try:
-            self._build_backward(ws)
+            self._site = 0
+            self._build_forward(ws, save=True)
+            if self.strip:                           # inference plan: same buffers, nothing saved for a backward
+                n_sites = self._site
+                self._site = 0
+                self._build_forward(ws, save=False)
+                assert self._site == n_sites
+            self._in_backward = True
+            try:
+                self._build_backward(ws)
+            finally:
+                self._in_backward = False
         finally:
-            self._in_backward = False
+            self.strip, self.bfs, self.hh = saved_mode
         tnb = torch.empty(max(ws.get('tn_need', 8), 8) // 4 + 16, dtype=torch.float32, device=self.device)
         lnb = torch.empty(max(ws.get('ln_need', 8), 8) // 4 + 16, dtype=torch.float32, device=self.device)
         ws['bufs']['tn_ws'], ws['bufs']['ln_ws'] = tnb, lnb

@@ -40,12 +40,14 @@ def test_split_planes_reconstruct_the_weights(dev, npass):
         bound = w.double().abs() * 2.0 ** -15
     assert (err <= bound).all(), (err / bound).max()
     if npass == 2:
-        big = torch.tensor([[7.0e4, -9.9e4, 1.3e5, 3.0e38] + [0.0] * 28])
+        big = torch.tensor([[7.0e4, -9.9e4, 1.3e5, 3.0e38, float('nan'), float('inf'), float('-inf')] + [0.0] * 25])
         pl = ops.prepare_weight(big.to(dev), npass=2)
         rec = pl[0, :1].cpu().view(torch.float16).double() + pl[1, :1].cpu().view(torch.float16).double()
-        assert torch.isfinite(rec).all()
+        assert torch.isfinite(rec[0, :3]).all()
         assert max_err(rec[0, :3], big[0, :3]) <= 32.0                   # hi saturates at 65504, lo carries the rest (fp16 steps of 32 up there)
-        assert rec[0, 3] == 2 * 65504.0
+        # beyond 2 x 65504, and for NaN / Inf, the (unclamped) lo half is not finite: a diverged tensor poisons its products instead of
+        # being laundered into +-65504
+        assert rec[0, 3] == float('inf') and torch.isnan(rec[0, 4]) and rec[0, 5] == float('inf') and rec[0, 6] == float('-inf')
 
 
 @pytest.mark.parametrize('npass', [2, 4])

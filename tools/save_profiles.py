@@ -12,6 +12,14 @@ import sys
 
 tag = sys.argv[1]
 MODE = sys.argv[2] if len(sys.argv) > 2 else 'paper size, B=8, x3 mode'
+# the BENCH_ARGS the profiled commands ran with (third argument, e.g. "--config tiny --precision bf16"): written into every summary as
+# explicit fields -- bench.py picks the summaries of ITS configuration by these fields, not by the prose of `note`
+BENCH_ARGS = sys.argv[3] if len(sys.argv) > 3 else ''
+_m = re.search(r'--config\s+(\w+)', BENCH_ARGS)
+CONFIG = _m.group(1) if _m else 'paper'
+_m = re.search(r'--precision\s+(\w+)', BENCH_ARGS)
+PRECISION = _m.group(1) if _m else 'x3'
+FIELDS = {'config': CONFIG, 'precision': PRECISION, 'bench_args': BENCH_ARGS}
 G = 'gpurun_out/' + tag
 
 
@@ -39,9 +47,14 @@ def traffic(fdir, wdir, out, what):
         fl, wl = f[n].get('FETCH_SIZE', [0]), w[n].get('WRITE_SIZE', [0])
         k[n] = {'launches': len(fl), 'fetch_MB_per_launch_x2_corrected': round(2 * sum(fl) / len(fl) * 1024 / 1e6, 2),
                 'write_MB_per_launch': round(sum(wl) / max(1, len(wl)) * 1024 / 1e6, 2)}
-    json.dump({'note': ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) around `%s` (%s); counter '
+    m = re.search(r'--steps (\d+)', what)
+    w_ = re.search(r'--warmup (\d+)', what)
+    n_steps = (int(m.group(1)) if m else 2) + (int(w_.group(1)) if w_ else 0)       # every step of the profiled command (warm-up included) is in the counters
+    total = sum(v['launches'] * (v['fetch_MB_per_launch_x2_corrected'] + v['write_MB_per_launch']) for v in k.values()) * 1e6
+    json.dump(dict(FIELDS, **{'note': ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) around `%s` (%s); counter '
                         'values are KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated on a 268 MB copy: '
-                        'profiles/r01_kernel_pmc_traffic.json); per-launch averages over all launches of a kernel symbol') % (what, MODE), 'kernels': k},
+                        'profiles/r01_kernel_pmc_traffic.json); per-launch averages over all launches of a kernel symbol') % (what, MODE),
+                        'steps_in_profiled_command': n_steps, 'hbm_bytes_per_step': total / n_steps, 'kernels': k}),
               open(out, 'w'), indent=1)
 
 
@@ -85,9 +98,9 @@ def busy(dirs, out, what):
             e['mfma_busy'] = round(mf / (N_SIMD * c['duration_ns_in_this_pass'] * 2.4), 4)
             e['mfma_busy_basis'] = 'duration x 2.4 GHz (lower bound)'
         k[n] = e
-    json.dump({'note': 'rocprofv3 --pmc passes around `%s`; per-launch averages per kernel symbol. mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / '
+    json.dump(dict(FIELDS, **{'note': 'rocprofv3 --pmc passes around `%s`; per-launch averages per kernel symbol. mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / '
                        '(1024 SIMDs x cycles of the dispatch); cycles of the dispatch = GRBM_GUI_ACTIVE / 8 where that counter was collected in the '
-                       'same pass, else the traced duration at 2.4 GHz' % what, 'kernels': k}, open(out, 'w'), indent=1)
+                       'same pass, else the traced duration at 2.4 GHz' % what, 'kernels': k}), open(out, 'w'), indent=1)
 
 
 cmd = 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras'
