@@ -402,7 +402,11 @@ int hftt_attn_check(const hftt_attn_desc* d, bool bwd) {
   HFTT_REQUIRE(d->q_seq_stride % 4 == 0 && d->k_seq_stride % 4 == 0 && d->v_seq_stride % 4 == 0, "attn: seq strides must be multiples of 4");
   HFTT_REQUIRE((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 15) == 0, "attn: operands must be 16-byte aligned");
   HFTT_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "attn: drop_p out of range");
-  HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1, "attn: bf16-stored tensors need npass == 1");
+  const unsigned bf_flags = HFTT_ATTN_Q_BF16 | HFTT_ATTN_KV_BF16 | HFTT_ATTN_O_BF16 | HFTT_ATTN_DQ_BF16 | HFTT_ATTN_DKV_BF16;
+  const unsigned pl_flags = HFTT_ATTN_Q_F16PAIR | HFTT_ATTN_KV_F16PAIR;
+  HFTT_REQUIRE((d->io_flags & bf_flags) == 0 || d->npass == 1, "attn: bf16-stored tensors need npass == 1");
+  HFTT_REQUIRE((d->io_flags & pl_flags) == 0 || d->npass == 2, "attn: f16-pair planes need npass == 2");
+  HFTT_REQUIRE((d->io_flags & ~(bf_flags | pl_flags)) == 0, "attn: unknown io_flags 0x%x", d->io_flags);
   if (bwd) {
     HFTT_REQUIRE(d->dout && d->dq && d->dk && d->dv, "attn_bwd: null gradient operand");
     HFTT_REQUIRE(d->lddq % 4 == 0 && d->lddk % 4 == 0 && d->lddv % 4 == 0, "attn_bwd: row strides must be multiples of 4");

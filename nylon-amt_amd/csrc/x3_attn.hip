@@ -156,53 +156,65 @@ __global__ __launch_bounds__(NW * 64) void x3_attn_fwd_kernel(const hftt_attn_de
       // work ran with the matrix pipe idle.
       const long prow = (((long)seq * g.n_heads + head) * Lq + qrow) * (long)Lk;
       const uint32_t q0lo = (uint32_t)((uint64_t)prow >> 2) + (uint32_t)(lh4 >> 2);
-      float sum = 0.f;
       f32x16 oacc[NT];
 #pragma unroll
       for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int r = 0; r < 16; r++) oacc[n][r] = 0.f;
+      // the dropout form is a compile-time parameter of the loop (DM: 0 none, 1 one hash per key quad, 2 per element): as run-time tests
+      // inside the tile loop the forms met in phi copies of the whole tile and a branch per quad.  The kept probabilities enter P.V
+      // unscaled; inv_keep rides on 1/sum at the end.
+      auto pv_fused = [&](auto dm_c) __attribute__((always_inline)) {
+        constexpr int DM = decltype(dm_c)::value;
+        float sum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < KT; kt++) {
-        float pt[16];
+        for (int kt = 0; kt < KT; kt++) {
+          float pt[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          pt[r] = __builtin_amdgcn_exp2f((sacc[kt][r] - mx) * c2);
-          sum += pt[r];
-        }
-        if (g.drop_p > 0.f) {        // (wave-uniform)
+          for (int r = 0; r < 16; r++) {
+            pt[r] = __builtin_amdgcn_exp2f((sacc[kt][r] - mx) * c2);
+            sum += pt[r];
+          }
+          if (DM == 1) {
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
-            if (quad_ok) {
+            for (int c = 0; c < 4; c++) {
               const uint32_t w = hftt_hash_mix(hk, q0lo + (uint32_t)(kt * 8 + 2 * c), 0u);      // keys kt*32 + 8c + 4lh + {0..3}
-              pt[4 * c] = (w & 0xFFu) < thr ? pt[4 * c] * inv_keep : 0.f;
-              pt[4 * c + 1] = ((w >> 8) & 0xFFu) < thr ? pt[4 * c + 1] * inv_keep : 0.f;
-              pt[4 * c + 2] = ((w >> 16) & 0xFFu) < thr ? pt[4 * c + 2] * inv_keep : 0.f;
-              pt[4 * c + 3] = (w >> 24) < thr ? pt[4 * c + 3] * inv_keep : 0.f;
-            } else {
+              pt[4 * c] = (w & 0xFFu) < thr ? pt[4 * c] : 0.f;
+              pt[4 * c + 1] = ((w >> 8) & 0xFFu) < thr ? pt[4 * c + 1] : 0.f;
+              pt[4 * c + 2] = ((w >> 16) & 0xFFu) < thr ? pt[4 * c + 2] : 0.f;
+              pt[4 * c + 3] = (w >> 24) < thr ? pt[4 * c + 3] : 0.f;
+            }
+          } else if (DM == 2) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
               const int key0 = kt * 32 + 8 * c + lh4;
 #pragma unroll
               for (int e = 0; e < 4; e++)
-                pt[4 * c + e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(prow + key0 + e), thr) ? pt[4 * c + e] * inv_keep : 0.f;
+                pt[4 * c + e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(prow + key0 + e), thr) ? pt[4 * c + e] : 0.f;
             }
           }
-        }
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-          bf16x8 ph, pl;
-          x3_split8<E>(pt + 8 * s2, ph, pl);
+          for (int s2 = 0; s2 < 2; s2++) {
+            bf16x8 ph, pl;
+            x3_split8_nc<E>(pt + 8 * s2, ph, pl);
 #pragma unroll
-          for (int n = 0; n < NT; n++) {
-            const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
-            const int r0 = kt * 32 + 16 * s2 + 4 * lh + qq;     // + 8 for the second half of the fragment
-            const unsigned short* pvp = Vs + r0 * RSV + col;
-            const bf16x8 vh = join4(lds_read_tr16(pvp), lds_read_tr16(pvp + 8 * RSV));
-            const bf16x8 vl = join4(lds_read_tr16(pvp + V_PL), lds_read_tr16(pvp + V_PL + 8 * RSV));
-            oacc[n] = x3_mma<E>(ph, pl, vh, vl, oacc[n]);
+            for (int n = 0; n < NT; n++) {
+              const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
+              const int r0 = kt * 32 + 16 * s2 + 4 * lh + qq;     // + 8 for the second half of the fragment
+              const unsigned short* pvp = Vs + r0 * RSV + col;
+              const bf16x8 vh = join4(lds_read_tr16(pvp), lds_read_tr16(pvp + 8 * RSV));
+              const bf16x8 vl = join4(lds_read_tr16(pvp + V_PL), lds_read_tr16(pvp + V_PL + 8 * RSV));
+              oacc[n] = x3_mma<E>(ph, pl, vh, vl, oacc[n]);
+            }
           }
+          __builtin_amdgcn_sched_barrier(0);      // one tile at a time in program order (the MFMAs still run under the next tile's VALU work)
         }
-        __builtin_amdgcn_sched_barrier(0);      // one tile at a time in program order (the MFMAs still run under the next tile's VALU work)
-      }
+        return sum;
+      };
+      float sum;
+      if (g.drop_p > 0.f) {        // (wave-uniform)
+        if (quad_ok) sum = pv_fused(std::integral_constant<int, 1>{}); else sum = pv_fused(std::integral_constant<int, 2>{});
+      } else sum = pv_fused(std::integral_constant<int, 0>{});
       sum = xor32_sum(sum);
       const float inv = 1.0f / sum;
       if (lh == 0 && qrow < Lq) {
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void x3_attn_fwd_kernel(const hftt_attn_de
       }
       // the output tile has the QUERY on its register index (row acc_row32(r, lh)): 1/sum of those rows comes through 128 bytes of LDS
       float* invs = reinterpret_cast<float*>(smem + (size_t)(2 * K_PL + 2 * V_PL) * 2) + wave * 32;
-      if (lh == 0) invs[lr] = inv;
+      if (lh == 0) invs[lr] = inv * inv_keep;
       const long oofs = (long)seq * g.o_seq_stride + head * DH;
 #pragma unroll
       for (int j4 = 0; j4 < 4; j4++) {
@@ -352,6 +364,36 @@ int dispatch_xf(const hftt_attn_desc& d, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------------------
+// f16-pair planes (HFTT_ATTN_*_F16PAIR, dh == 64: x3_attn_pl.hip): four consecutive elements of one (row, head) = 8 bytes of the hi plane
+// + 8 bytes of the lo plane, 128 bytes apart; hi + lo is exact in fp32 (at most 23 significant bits)
+__device__ __forceinline__ void pl_load4(const float* head_row, int c4, uint2& hi, uint2& lo) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(head_row) + c4 * 8;
+  hi = *reinterpret_cast<const uint2*>(p);
+  lo = *reinterpret_cast<const uint2*>(p + 128);
+}
+__device__ __forceinline__ float4 pl_vals4(const uint2& hi, const uint2& lo) {
+  float h0, h1, h2, h3, l0, l1, l2, l3;
+  X3<X3_F16>::unpk(hi.x, h0, h1); X3<X3_F16>::unpk(hi.y, h2, h3);
+  X3<X3_F16>::unpk(lo.x, l0, l1); X3<X3_F16>::unpk(lo.y, l2, l3);
+  return make_float4(h0 + l0, h1 + l1, h2 + l2, h3 + l3);
+}
+// eight consecutive elements (one MFMA fragment): 16 bytes of each plane
+__device__ __forceinline__ void pl_load8(const float* head_row, int e0, bf16x8& hi, bf16x8& lo) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(head_row) + e0 * 2;
+  hi = *reinterpret_cast<const bf16x8*>(p);
+  lo = *reinterpret_cast<const bf16x8*>(p + 128);
+}
+__device__ __forceinline__ void pl_vals8(const bf16x8& hi, const bf16x8& lo, float* v) {
+  const uint4 h = __builtin_bit_cast(uint4, hi), l = __builtin_bit_cast(uint4, lo);
+  const unsigned hh[4] = {h.x, h.y, h.z, h.w}, ll[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    float a0, a1, b0, b1;
+    X3<X3_F16>::unpk(hh[q], a0, a1); X3<X3_F16>::unpk(ll[q], b0, b1);
+    v[2 * q] = a0 + b0; v[2 * q + 1] = a1 + b1;
+  }
+}
+
 template <int KT, int DH>
 struct XbCfg {
   static constexpr int LKP = KT * 32;
@@ -370,8 +412,11 @@ struct XbCfg {
   static constexpr int NTHR = KT * 64;
 };
 
-template <int KT, int DH>
+// PL: q, k, v are f16-pair planes (dh == 64): the fp16 halves the score recomputation needs are the stored bytes (the forward's, bit for
+// bit); the bf16 pairs of the gradient products are formed from hi + lo
+template <int KT, int DH, bool PL>
 __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_desc g) {
+  static_assert(!PL || DH == 64, "f16-pair planes: dh == 64");
   using Cfg = XbCfg<KT, DH>;
   constexpr int EF = X3_F16, EB = X3_BF16;
   constexpr int RSK = Cfg::RSK, RSQ = Cfg::RSQ, RSS = Cfg::RSS, LKP = Cfg::LKP, NTHR = Cfg::NTHR;
@@ -410,7 +455,13 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       const int ic = i < LKP * F4R ? i : LKP * F4R - 1;
       const int key = ic / F4R, c4 = ic % F4R;
       const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
-      kst[u] = *reinterpret_cast<const float4*>(g.k + kofs + (long)kc * g.ldk + c4 * 4);
+      if (PL) {
+        uint2 ph_, pl_;
+        pl_load4(g.k + kofs + (long)kc * g.ldk, c4, ph_, pl_);
+        kst[u] = pl_vals4(ph_, pl_);
+      } else {
+        kst[u] = *reinterpret_cast<const float4*>(g.k + kofs + (long)kc * g.ldk + c4 * 4);
+      }
       if (key >= Lk) kst[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -431,6 +482,21 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];
 #pragma unroll
   for (int s = 0; s < KS; s++) {
+    if (PL) {
+      bf16x8 th, tl;
+      pl_load8(g.k + kofs + (long)mykey_c * g.ldk, 16 * s + 8 * lh0, kfh[s], kfl[s]);
+      pl_load8(g.v + vofs + (long)mykey_c * g.ldv, 16 * s + 8 * lh0, th, tl);
+      float vv[8];
+      pl_vals8(th, tl, vv);
+      if (mykey >= Lk) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        kfh[s] = z; kfl[s] = z;
+#pragma unroll
+        for (int e = 0; e < 8; e++) vv[e] = 0.f;
+      }
+      x3_split8<EB>(vv, vfh[s], vfl[s]);
+      continue;
+    }
     const float* kp = g.k + kofs + (long)mykey_c * g.ldk + 16 * s + 8 * lh0;
     const float* vp = g.v + vofs + (long)mykey_c * g.ldv + 16 * s + 8 * lh0;
     const float4 a0 = *reinterpret_cast<const float4*>(kp), a1 = *reinterpret_cast<const float4*>(kp + 4);
@@ -468,7 +534,13 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       const int row = ic / F4R, cs = ic % F4R;
       const int q = qb * 32 + row;
       const int qc = q < Lq ? q : Lq - 1;          // clamped address: loads stay unconditional (rows past Lq are zeroed at consumption)
-      pq[u] = *reinterpret_cast<const float4*>(g.q + qofs + (long)qc * g.ldq + cs * 4);
+      if (PL) {                                    // (hi, lo) pairs of the four elements, carried in the same four registers
+        uint2 ph_, pl_;
+        pl_load4(g.q + qofs + (long)qc * g.ldq, cs, ph_, pl_);
+        pq[u] = make_float4(__uint_as_float(ph_.x), __uint_as_float(ph_.y), __uint_as_float(pl_.x), __uint_as_float(pl_.y));
+      } else {
+        pq[u] = *reinterpret_cast<const float4*>(g.q + qofs + (long)qc * g.ldq + cs * 4);
+      }
       pdo[u] = *reinterpret_cast<const float4*>(g.dout + oofs + (long)qc * g.ldo + cs * 4);
       po[u] = *reinterpret_cast<const float4*>(g.out + oofs + (long)qc * g.ldo + cs * 4);
       pl[u] = *reinterpret_cast<const float2*>(g.lse + (sh * Lq + qc) * 2);
@@ -490,7 +562,13 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         if (qb * 32 + row >= Lq) { pq[u] = make_float4(0.f, 0.f, 0.f, 0.f); pdo[u] = pq[u]; po[u] = pq[u]; pl[u] = make_float2(0.f, 0.f); }
         uint2 hi, lo;
         if (!XABL(g, 1)) {
-        x3_split4<EF>(pq[u], hi, lo);
+        if (PL) {                                     // the stored fp16 pair IS the score operand; its sum feeds the bf16 pair of dK
+          hi = make_uint2(__float_as_uint(pq[u].x), __float_as_uint(pq[u].y));
+          lo = make_uint2(__float_as_uint(pq[u].z), __float_as_uint(pq[u].w));
+          pq[u] = pl_vals4(hi, lo);
+        } else {
+          x3_split4<EF>(pq[u], hi, lo);
+        }
         *reinterpret_cast<uint2*>(Qf + row * RSQ + cs * 4) = hi;
         *reinterpret_cast<uint2*>(Qf + Q_PL + row * RSQ + cs * 4) = lo;
         x3_split4<EB>(pq[u], hi, lo);
@@ -679,32 +757,34 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   }
 }
 
-template <int KT, int DH>
+template <int KT, int DH, bool PL>
 int launch_xb(const hftt_attn_desc& d, hipStream_t st) {
   using Cfg = XbCfg<KT, DH>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3_attn_bwd_kernel<KT, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3_attn_bwd_kernel<KT, DH, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) { hftt_set_error("x3_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((x3_attn_bwd_kernel<KT, DH>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, d);
+  hipLaunchKernelGGL((x3_attn_bwd_kernel<KT, DH, PL>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, d);
   HFTT_CHECK_LAUNCH("x3_attn_bwd");
   return 0;
 }
-template <int DH>
+template <int DH, bool PL>
 int dispatch_xb(const hftt_attn_desc& d, hipStream_t st) {
   const int kt = (d.Lk + 31) / 32;
-  if (kt <= 1) return launch_xb<1, DH>(d, st);
-  if (kt <= 2) return launch_xb<2, DH>(d, st);
-  if (kt <= 3) return launch_xb<3, DH>(d, st);
-  if (kt <= 4) return launch_xb<4, DH>(d, st);
-  return launch_xb<8, DH>(d, st);
+  if (kt <= 1) return launch_xb<1, DH, PL>(d, st);
+  if (kt <= 2) return launch_xb<2, DH, PL>(d, st);
+  if (kt <= 3) return launch_xb<3, DH, PL>(d, st);
+  if (kt <= 4) return launch_xb<4, DH, PL>(d, st);
+  return launch_xb<8, DH, PL>(d, st);
 }
 
 }  // namespace
 
 int hftt_x3_attn_fwd(const hftt_attn_desc& d, hipStream_t st) {
+  const int rcp = hftt_x3p_attn_fwd_try(d, st);      // q, k, v as f16-pair planes: the LDS-DMA form (x3_attn_pl.hip)
+  if (rcp >= 0) return rcp;
   return d.dh == 64 ? dispatch_xf<64>(d, st) : dispatch_xf<32>(d, st);
 }
 // Ablation build only (tools/ablate_x3_attn.sh, -DHFTT_X3_ATTN_ABLATE): HFTT_X3_ATTN_DEBUG switches mechanisms of the backward off
@@ -718,5 +798,12 @@ int hftt_x3_attn_bwd(const hftt_attn_desc& d0, hipStream_t st) {
 #else
   d.pad = 0;
 #endif
-  return d.dh == 64 ? dispatch_xb<64>(d, st) : dispatch_xb<32>(d, st);
+  const unsigned both = HFTT_ATTN_Q_F16PAIR | HFTT_ATTN_KV_F16PAIR;
+  if (d.io_flags & both) {
+    HFTT_REQUIRE((d.io_flags & both) == both && d.dh == 64, "attn_bwd: f16-pair planes need both flags and dh == 64");
+    HFTT_REQUIRE(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.q_seq_stride % 4 == 0 && d.k_seq_stride % 4 == 0 && d.v_seq_stride % 4 == 0,
+                 "attn_bwd: f16-pair planes must be 16-byte aligned");
+    return dispatch_xb<64, true>(d, st);
+  }
+  return d.dh == 64 ? dispatch_xb<64, false>(d, st) : dispatch_xb<32, false>(d, st);
 }

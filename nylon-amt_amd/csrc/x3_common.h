@@ -47,6 +47,15 @@ struct X3<X3_F16> {
     const f32x2_t v = __builtin_convertvector(__builtin_bit_cast(f16x2_t, p), f32x2_t);
     a = v[0]; b = v[1];
   }
+  // the packed lo halves of (a, b) whose packed hi halves are `hi`: a - hi in ONE v_fma_mix_f32 per element (the fp16 half is read in place
+  // as an FMA operand; the difference is exact either way) instead of a conversion back to fp32 plus a subtraction -- the split runs inside
+  // every VALU-bound loop of the x3 kernels (per pair: cvt_pk, 2 x fma_mix, cvt_pk)
+  static __device__ __forceinline__ unsigned lo_of(float a, float b, unsigned hi) {
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+    return pk_lo(la, lb);
+  }
   static __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
@@ -65,6 +74,11 @@ struct X3<X3_BF16> {
   static __device__ __forceinline__ void unpk(unsigned p, float& a, float& b) {
     a = __uint_as_float(p << 16); b = __uint_as_float(p & 0xFFFF0000u);
   }
+  static __device__ __forceinline__ unsigned lo_of(float a, float b, unsigned hi) {
+    float ha, hb;
+    unpk(hi, ha, hb);
+    return pk(a - ha, b - hb);
+  }
   static __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) { return mfma32(a, b, c); }
   static __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) { return mfma16(a, b, c); }
 };
@@ -76,9 +90,20 @@ struct X3<X3_BF16H> : X3<X3_BF16> {};
 template <int E>
 __device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsigned& lo) {
   hi = X3<E>::pk(a, b);
-  float ha, hb;
-  X3<E>::unpk(hi, ha, hb);
-  lo = X3<E>::pk_lo(a - ha, b - hb);
+  lo = X3<E>::lo_of(a, b, hi);
+}
+// the same for values known to be finite and inside the element type's range (softmax probabilities): no saturation step
+template <int E>
+__device__ __forceinline__ void x3_split2_nc(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = X3<E>::pk_lo(a, b);
+  lo = X3<E>::lo_of(a, b, hi);
+}
+template <int E>
+__device__ __forceinline__ void x3_split8_nc(const float* v, bf16x8& hi, bf16x8& lo) {
+  uint4 h, l;
+  x3_split2_nc<E>(v[0], v[1], h.x, l.x); x3_split2_nc<E>(v[2], v[3], h.y, l.y);
+  x3_split2_nc<E>(v[4], v[5], h.z, l.z); x3_split2_nc<E>(v[6], v[7], h.w, l.w);
+  hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
 }
 // four consecutive elements -> 8 bytes of the hi plane + 8 bytes of the lo plane
 template <int E>

@@ -243,6 +243,33 @@ __device__ __forceinline__ void tile_store_rows_bf16(float* stage, const float* 
     if (ok) *reinterpret_cast<uint4*>(gtile + (long)(half * 16 + r) * ld + (lane & 3) * 8) = t;
   }
 }
+// The same tile as an f16 PAIR (HFTT_SL_C_F16PAIR: the q / k / v projections, read by the attention kernels as MFMA operands without any
+// further conversion -- x3_attn_pl.hip): the tile's 32 columns are one half of a 64-column head group whose 256 bytes per row hold the 64
+// hi halves, then the 64 lo halves.  ghi: byte address of this tile's 64-byte hi segment in row 0 of the wave's strip (group base +
+// 64 * (tile & 1)); the lo segment sits 128 bytes behind it.  Through the same patch (rows of 144 B: hi 64 | lo 64 | pad), 8 rows x (4 + 4)
+// 16-byte pieces per store instruction.
+__device__ __forceinline__ void tile_store_rows_f16pair(float* stage, const float* v, int j, int h, int lane, unsigned char* ghi, long ld_bytes, bool ok) {
+  unsigned char* st8 = reinterpret_cast<unsigned char*>(stage);
+  bf16x8 hi0, lo0, hi1, lo1;
+  x3_split8<X3_F16>(v, hi0, lo0);
+  x3_split8<X3_F16>(v + 8, hi1, lo1);
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    if ((j >> 4) == half) {
+      unsigned char* w = st8 + (j & 15) * (STG_RS * 4) + 32 * h;
+      *reinterpret_cast<bf16x8*>(w) = hi0;
+      *reinterpret_cast<bf16x8*>(w + 16) = hi1;
+      *reinterpret_cast<bf16x8*>(w + 64) = lo0;
+      *reinterpret_cast<bf16x8*>(w + 80) = lo1;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int r = (lane >> 3) + 8 * k, pc = lane & 7;
+      const uint4 t = *reinterpret_cast<const uint4*>(st8 + r * (STG_RS * 4) + pc * 16);
+      if (ok) *reinterpret_cast<uint4*>(ghi + (long)(half * 16 + r) * ld_bytes + (pc & 3) * 16 + (pc >> 2) * 128) = t;
+    }
+  }
+}
 __device__ __forceinline__ void load16h(const unsigned short* p, float* v) {      // 16 bf16 -> fp32
 #pragma unroll
   for (int q = 0; q < 2; q++) {
@@ -433,8 +460,10 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
 // strip loads under the other's MFMAs.  (The K-outer form above, one wave per SIMD, ran MFMA, loads and stores strictly one after the
 // other: QKV at 262,144 tokens 560 us = 250 us of MFMA + 240 us of stores + 120 us of loads, HFTT_X3_DEBUG.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int E, int NT, bool HR>
+// PLN: C leaves as f16-pair planes (HFTT_SL_C_F16PAIR; forward products only, no residual)
+template <int E, int NT, bool HR, bool PLN = false>
 __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_desc g) {
+  static_assert(!PLN || (E == X3_F16 && !HR), "f16-pair output: a forward projection without residual");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -531,7 +560,8 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] += r[q];
       }
-      tile_store_rows(stage, v, j, hb, lane, cwave + t * 32, g.ldc, wave_ok && !dbg_nostore);
+      if (PLN) tile_store_rows_f16pair(stage, v, j, hb, lane, reinterpret_cast<unsigned char*>(cwave) + (t >> 1) * 256 + (t & 1) * 64, g.ldc * 4, wave_ok && !dbg_nostore);
+      else tile_store_rows(stage, v, j, hb, lane, cwave + t * 32, g.ldc, wave_ok && !dbg_nostore);
     });
   }
   P.drain();
@@ -760,15 +790,15 @@ int launch_xl(const hftt_strip_desc& d, hipStream_t st) {
   HFTT_CHECK_LAUNCH("x3_strip_linear");
   return 0;
 }
-template <int E, int NT, bool HR>
+template <int E, int NT, bool HR, bool PLN = false>
 int launch_xn(const hftt_strip_desc& d, hipStream_t st) {
   const int lds = RING_BYTES + 4 * d.N + 4 * STG_BYTES_PER_WAVE;
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(x3_linear_n_kernel<E, NT, HR>, lds, "x3_strip_linear")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(x3_linear_n_kernel<E, NT, HR, PLN>, lds, "x3_strip_linear")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("x3_strip_linear: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  hipLaunchKernelGGL((x3_linear_n_kernel<E, NT, HR>), dim3((unsigned)(nblk < 2 * cus ? nblk : 2 * cus)), dim3(256), lds, st, d);
+  hipLaunchKernelGGL((x3_linear_n_kernel<E, NT, HR, PLN>), dim3((unsigned)(nblk < 2 * cus ? nblk : 2 * cus)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("x3_strip_linear");
   return 0;
 }
@@ -796,6 +826,13 @@ int dispatch_xl(const hftt_strip_desc& d, hipStream_t st) {
     hftt_set_error("x3_strip_linear: the LayerNorm form covers K = 256 / 512 (got %d)", d.K);
     return 1;
   }
+  if constexpr (E == X3_F16) {
+    if (d.flags & HFTT_SL_C_F16PAIR) {                // (validated by the caller: no LayerNorm, no residual, K == 256)
+      if (passes == 1) return launch_xn<E, 8, false, true>(d, st);
+      if (passes == 2) return launch_xn<E, 16, false, true>(d, st);
+      return launch_xn<E, 24, false, true>(d, st);
+    }
+  }
   // K == 256 without LayerNorm: the output-tile-major kernel (tile-major pack, two workgroups per CU)
   if (kch == 1 && passes == 1) return hr ? launch_xn<E, 8, true>(d, st) : launch_xn<E, 8, false>(d, st);
   if (kch == 1 && passes == 2) return hr ? launch_xn<E, 16, true>(d, st) : launch_xn<E, 16, false>(d, st);
@@ -821,6 +858,11 @@ int hftt_x3_strip_linear(const hftt_strip_desc& d0, hipStream_t st) {
   HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_linear: tensors are fp32 in the split modes");
   HFTT_REQUIRE(d.ldx % 4 == 0 && d.ldc % 4 == 0 && (d.residual == nullptr || d.ldr % 4 == 0), "x3_strip_linear: rows must be 16-byte aligned");
   HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_GRAD_HI) || (d.flags & HFTT_SL_X3_BF16), "x3_strip_linear: HFTT_SL_X3_GRAD_HI goes with HFTT_SL_X3_BF16");
+  if (d.flags & HFTT_SL_C_F16PAIR) {
+    HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_BF16) && d.K == 256 && d.N <= 768 && d.ln_gamma == nullptr && d.residual == nullptr && !(d.flags & HFTT_SL_RELU) && !(d.drop_p > 0.f),
+                 "x3_strip_linear: HFTT_SL_C_F16PAIR is the plain forward projection (HFTT_SL_X3_F16, K == 256, N <= 768, no LayerNorm / residual / ReLU / dropout)");
+    HFTT_REQUIRE(((uintptr_t)d.C & 15) == 0, "x3_strip_linear: C must be 16-byte aligned");
+  }
   if (d.flags & HFTT_SL_X3_GRAD_HI) return dispatch_xl<X3_BF16H>(d, st);
   return (d.flags & HFTT_SL_X3_BF16) ? dispatch_xl<X3_BF16>(d, st) : dispatch_xl<X3_F16>(d, st);
 }

@@ -118,6 +118,8 @@ SL_PRE_BF16 = 128                           # split modes, LayerNorm forms: pre_
 SL_X3_GRAD_HI = 256                         # with SL_X3_BF16: the gradient strip enters as its bf16 rounding (two MFMA passes)
 SL_H_BF16 = 64                              # fused block in a split mode: h_out / gate stored as bf16
 SL_X3_F16, SL_X3_BF16 = 16, 32               # split-operand forms of the strip kernels (fp32 tensors; fp16 / bf16 hi + lo halves)
+SL_C_F16PAIR = 512                          # SL_X3_F16 projection: C written as f16-pair planes (the attention kernels' operand form)
+ATTN_Q_F16PAIR, ATTN_KV_F16PAIR = 32, 64    # npass 2, dh 64: q / k, v are f16-pair planes
 TE_X_BF16, TE_Y_BF16, TE_M_BF16 = 1, 2, 4          # hftt_time_embed_fwd / _bwd io_flags
 
 
@@ -156,6 +158,7 @@ SIGNATURES = {
     'hftt_gemm_tn': (C.c_int, [C.POINTER(GemmTnDesc), C.c_void_p]),
     'hftt_attn_fwd': (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
     'hftt_attn_bwd': (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
+    'hftt_x3_to_planes': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     'hftt_embed_fold_fwd': (C.c_int, [C.POINTER(FoldDesc), C.c_void_p]),
     'hftt_embed_fold_bwd': (C.c_int, [C.POINTER(FoldDesc), C.c_void_p]),
     'hftt_im2win': (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -181,7 +184,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HfttError(RuntimeError):

@@ -23,7 +23,8 @@ import torch
 
 from . import _capi
 from ._capi import (AttnDesc, FfnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
+                    SL_C_BF16, SL_C_F16PAIR, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16,
+                    ATTN_Q_F16PAIR, ATTN_KV_F16PAIR, check, lib)
 
 # precision -> the descriptors' `npass` code (include/hftt_hip.h): 'x3' = split fp16 on forward products (2) and split bf16 on products with a
 # gradient operand (4): three bf16-rate MFMA passes per product, fp32 tensors in HBM, outputs within 1e-3 of the reference (measured 1e-4)
@@ -90,6 +91,7 @@ class HfttEngine:
         self.NHp = _align(self.NH + 1, 64)
         self.store_bf16_opt = os.environ.get('HFTT_BF16_STORE', '1') != '0'
         self.strip_opt = os.environ.get('HFTT_STRIP', '1') != '0'
+        self.planes_opt = os.environ.get('HFTT_X3_PLANES', '1') != '0'      # x3 strip plans: q / k / v between projection and attention as f16-pair planes
         self.set_precision(precision)
         self.dropout = float(dropout)
         self.base_seed = int(seed)
@@ -505,14 +507,14 @@ class HfttEngine:
         return dsc
 
     def _sl(self, plan, ws, M, N, K, x, ldx, wkey, bias, Cp, ldc, relu=False, out_scale=1.0, gate=0, ldg=0, gate_scale=1.0, drop_site=0,
-            residual=0, ldr=0, res_mod=0, res_bf=True, ln=None, x_bf=True, c_bf=True):
+            residual=0, ldr=0, res_mod=0, res_bf=True, ln=None, x_bf=True, c_bf=True, c_planes=False):
         """hftt_strip_linear plan entry (bf16 mode, N % 256 == 0): C = epi(x . Wl^T + bias), Wl = strip pack `wkey`."""
         dsc = StripDesc()
         dsc.M, dsc.N, dsc.K = M, N, K
         if self.x3:                                  # fp32 tensors, fp16 halves on forward products, bf16 halves where a gradient is an operand
             x_bf = c_bf = res_bf = False
             dsc.flags = (SL_X3_BF16 if self._in_backward else SL_X3_F16) | (SL_RELU if relu else 0) | (SL_PRE_BF16 if (self.hh and ln is not None) else 0) \
-                | (SL_X3_GRAD_HI if (self._in_backward and self.g8) else 0)
+                | (SL_X3_GRAD_HI if (self._in_backward and self.g8) else 0) | (SL_C_F16PAIR if c_planes else 0)
         else:
             dsc.flags = (SL_X_BF16 if x_bf else 0) | (SL_C_BF16 if c_bf else 0) | (SL_RES_BF16 if (residual and res_bf) else 0) | (SL_RELU if relu else 0)
         dsc.x, dsc.ldx, dsc.w, dsc.bias = x, ldx, self.Ws(wkey), bias
@@ -543,7 +545,7 @@ class HfttEngine:
             xe = (5 if self.g8 else 4) if self._in_backward else 2
             kname = 'x3_linear_kernel<%d, %s, %d, %d, %s>' % (xe, tf(ln is not None), passes, kch, tf(bool(residual)))
             if ln is None and kch == 1:
-                kname = 'x3_linear_n_kernel<%d, %d, %s>' % (xe, N // 32, tf(bool(residual)))
+                kname = 'x3_linear_n_kernel<%d, %d, %s, %s>' % (xe, N // 32, tf(bool(residual)), tf(c_planes))
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_strip_linear, (C.byref(dsc),), 'strip_linear', meta))
         return dsc
@@ -607,8 +609,8 @@ class HfttEngine:
         return dsc
 
     def _attn(self, plan, ws, bwd, n_seq, H, Lq, Lk, q, qss, ldq, k, kss, ldk, v, vss, ldv, out, oss, ldo, lse, probs=0,
-              drop_site=0, dout=0, dq=0, dqss=0, lddq=0, dk=0, dkss=0, lddk=0, dv=0, dvss=0, lddv=0, flags=0):
-        flags = flags if self.sb else 0
+              drop_site=0, dout=0, dq=0, dqss=0, lddq=0, dk=0, dkss=0, lddk=0, dv=0, dvss=0, lddv=0, flags=0, planes=False):
+        flags = (flags if self.sb else 0) | ((ATTN_Q_F16PAIR | ATTN_KV_F16PAIR) if planes else 0)
         dsc = AttnDesc()
         dsc.io_flags = flags
         dsc.n_seq, dsc.n_heads, dsc.Lq, dsc.Lk, dsc.dh, dsc.npass = n_seq, H, Lq, Lk, self.d // H, self.npass
@@ -634,20 +636,30 @@ class HfttEngine:
         qkv_bytes = n_seq * (eq * Lq + 2 * ekv * Lk) * self.d
         if bwd:
             hb = 'true' if (flags & 7) == 7 else 'false'
-            meta = {'kernel': ('x3_attn_bwd_kernel<%d, %d>' % (kt, dh)) if self.npass == 2 else 'attn_bwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
+            meta = {'kernel': ('x3_attn_bwd_kernel<%d, %d, %s>' % (kt, dh, 'true' if planes else 'false')) if self.npass == 2 else 'attn_bwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
                     'bytes': qkv_bytes + n_seq * ((2.0 if flags & 8 else 4.0) * Lq + 2 * (2.0 if flags & 16 else 4.0) * Lk) * self.d + 2 * eo * n_seq * Lq * self.d
                     + 8.0 * n_seq * H * Lq, 'shape': (n_seq, H, Lq, Lk, dh)}
         else:
             hb = 'true' if (flags & 7) == 7 else 'false'
             long_rows = (hb == 'true' and dh == 64 and self.npass == 1 and 128 < Lk <= 256 and 128 < Lq <= 256 and not probs
                          and os.environ.get('HFTT_ATTN_FWD8', '1')[:1] != '0')                   # csrc/attn_fwd8.hip: hftt_attn_fwd8_try
-            meta = {'kernel': 'attn_fwd8_kernel' if long_rows else (('x3_attn_fwd_kernel<%d, %d, %d>' % (kt, dh, 8 if kt == 8 else 4)) if self.npass == 2 else
+            x3name = ('x3p_attn_fwd_kernel<%d, %d, %s>' % (kt, 8 if (kt == 8 and Lq > 128) else 4, 'true' if probs else 'false')) if planes else \
+                ('x3_attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, 8 if kt == 8 else 4, 'true' if probs else 'false'))
+            meta = {'kernel': 'attn_fwd8_kernel' if long_rows else (x3name if self.npass == 2 else
                                                                      'attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb)), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
                     # q, k, v, out + the row statistics (max, 1/sum) + the attention map where it is a model output (fp32, mandatory)
                     'bytes': qkv_bytes + eo * n_seq * Lq * self.d + 8.0 * n_seq * H * Lq + (4.0 * n_seq * H * Lq * Lk if probs else 0.0),
                     'shape': (n_seq, H, Lq, Lk, dh)}
         plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd', meta))
         return dsc
+
+    def _planes(self, H, Lq, Lk):
+        """x3 strip plans: do the q / k / v projections of this attention hand their results over as f16-pair planes (written once by the
+        projection's epilogue, staged by LDS-DMA in the attention forward: csrc/x3_attn_pl.hip)?  dh == 64 and one query block per wave."""
+        if not (self.x3 and self.strip and self.planes_opt and self.d // H == 64):
+            return False
+        nqb = (Lq + 31) // 32
+        return nqb <= (8 if Lk > 128 else 4)
 
     def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta, drop_bf=True, dy_bf=False, dr_bf=False):
         r_bf = self.bfs or self.hh                  # the strip forward kernels (bf16, and x3) save the pre-LayerNorm sum as bf16
@@ -728,10 +740,11 @@ class HfttEngine:
         gam, bet = self.P(pre + 'layer_norm.weight'), self.P(pre + 'layer_norm.bias')
         if self.strip:
             sv = (lambda t: t.data_ptr()) if save else (lambda t: 0)
-            self._sl(plan, ws, S, 3 * d, d, x_in, d, key + '.sa.qkv', self.Fp(key + '.sa.qkv_b'), qkv.data_ptr(), 3 * d)
+            pln = self._planes(H, L, L)
+            self._sl(plan, ws, S, 3 * d, d, x_in, d, key + '.sa.qkv', self.Fp(key + '.sa.qkv_b'), qkv.data_ptr(), 3 * d, c_planes=pln)
             q = qkv.data_ptr()
             self._attn(plan, ws, False, n_seq, H, L, L, q, L * 3 * d, 3 * d, q + hz * d, L * 3 * d, 3 * d, q + 2 * hz * d, L * 3 * d, 3 * d,
-                       ctx.data_ptr(), L * d, d, lse.data_ptr(), drop_site=sa, flags=1 | 2 | 4)
+                       ctx.data_ptr(), L * d, d, lse.data_ptr(), drop_site=sa, flags=1 | 2 | 4, planes=pln)
             self._sl(plan, ws, S, d, d, ctx.data_ptr(), d, key + '.sa.o', self.P(pre + 'self_attention.fc_o.bias'), x1.data_ptr(), d,
                      drop_site=so, residual=x_in, ldr=d, ln=(gam, bet, sv(r1), sv(m1), sv(s1)))
             self._mlp(plan, ws, 0, S, x1.data_ptr(), key + '.ffn', x2.data_ptr(), b1=self.P(pre + 'positionwise_feedforward.fc_1.bias'),
@@ -815,18 +828,20 @@ class HfttEngine:
                 sm = self._buf(ws, tag + '.sm', Sn); ss = self._buf(ws, tag + '.ss', Sn)
                 s_a, s_o = self._new_site(), self._new_site()
                 sites['self'] = (s_a, s_o)
+                pls = st and self._planes(H, N, N)
                 if st:
-                    self._sl(plan, ws, Sn, 3 * d, d, trg, d, tag + '.sa.qkv', self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d)
+                    self._sl(plan, ws, Sn, 3 * d, d, trg, d, tag + '.sa.qkv', self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d, c_planes=pls)
                 else:
                     self._nt(plan, ws, Sn, 3 * d, d, trg, d, self.Wp(tag + '.sa.qkv'), self.Fp(tag + '.sa.qkv_b'), sqkv.data_ptr(), 3 * d, c_bf=True)
                 q = sqkv.data_ptr()
                 self._attn(plan, ws, False, BT, H, N, N, q, N * 3 * d, 3 * d, q + hz * d, N * 3 * d, 3 * d, q + 2 * hz * d, N * 3 * d, 3 * d,
-                           sctx.data_ptr(), N * d, d, slse.data_ptr(), drop_site=s_a, flags=1 | 2 | 4)
+                           sctx.data_ptr(), N * d, d, slse.data_ptr(), drop_site=s_a, flags=1 | 2 | 4, planes=pls)
                 cq = self._buf(ws, tag + '.cq', Sn, d, half=True)
                 if st:
                     self._sl(plan, ws, Sn, d, d, sctx.data_ptr(), d, tag + '.sa.o', self.P(pre + 'self_attention.fc_o.bias'), sx.data_ptr(), d,
                              drop_site=s_o, residual=trg, ldr=d, ln=(gam, bet, sv(sr), sv(sm), sv(ss)))
-                    self._sl(plan, ws, Sn, d, d, sx.data_ptr(), d, tag + '.ca.q', self.P(pre + 'encoder_attention.fc_q.bias'), cq.data_ptr(), d)
+                    self._sl(plan, ws, Sn, d, d, sx.data_ptr(), d, tag + '.ca.q', self.P(pre + 'encoder_attention.fc_q.bias'), cq.data_ptr(), d,
+                             c_planes=self._planes(H, N, F))
                 else:
                     self._nt(plan, ws, Sn, d, d, sctx.data_ptr(), d, self.Wp(tag + '.sa.o'), self.P(pre + 'self_attention.fc_o.bias'), sx.data_ptr(), d,
                              drop_site=s_o, residual=trg, ldr=d, ln=(gam, bet, sr.data_ptr(), sm.data_ptr(), ss.data_ptr()), a_bf=True)
@@ -837,6 +852,10 @@ class HfttEngine:
             else:
                 self._nt(plan, ws, N, d, d, pos_dec, d, self.Wp(tag + '.ca.q'), self.P(pre + 'encoder_attention.fc_q.bias'), q0.data_ptr(), d, c_bf=True)
                 qaddr, qss = q0.data_ptr(), 0
+                if st and self._planes(H, N, F):     # the shared query of layer zero comes from the block GEMM as fp32: one small conversion
+                    q0p = self._buf(ws, 'dec0.q0p', N, d)
+                    plan.append((self.lib.hftt_x3_to_planes, (q0.data_ptr(), d, q0p.data_ptr(), d, N, d), 'x3_to_planes', None))
+                    qaddr = q0p.data_ptr()
                 res, res_mod = (self.wbf.data_ptr() + 2 * self.Woff['dec_pos_bf'] if bs else pos_dec), N
             ckv = self._buf(ws, tag + '.ckv', Se, 2 * d, half=True)
             cctx = self._buf(ws, tag + '.cctx', Sn, d, half=True)
@@ -845,13 +864,14 @@ class HfttEngine:
             cm = self._buf(ws, tag + '.cm', Sn); cs = self._buf(ws, tag + '.cs', Sn)
             c_a, c_o = self._new_site(), self._new_site()
             sites['cross'] = (c_a, c_o)
+            plc = st and self._planes(H, N, F)
             if st:
-                self._sl(plan, ws, Se, 2 * d, d, enc, d, tag + '.ca.kv', self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d)
+                self._sl(plan, ws, Se, 2 * d, d, enc, d, tag + '.ca.kv', self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d, c_planes=plc)
             else:
                 self._nt(plan, ws, Se, 2 * d, d, enc, d, self.Wp(tag + '.ca.kv'), self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d, c_bf=True)
             kk = ckv.data_ptr()
             ad = self._attn(plan, ws, False, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
-                            cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a, flags=1 | 2 | 4)
+                            cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a, flags=1 | 2 | 4, planes=plc)
             if j == self.Ld - 1:
                 ws.setdefault('attn_out_descs', []).append(ad)
             if st:
@@ -955,7 +975,7 @@ class HfttEngine:
         self._attn(plan, ws, True, n_seq, H, L, L, qkv, L * 3 * d, 3 * d, qkv + hz * d, L * 3 * d, 3 * d, qkv + 2 * hz * d, L * 3 * d, 3 * d,
                    b[tag + '.ctx'].data_ptr(), L * d, d, b[tag + '.lse'].data_ptr(), drop_site=sa, dout=Gx,
                    dq=Gq, dqss=L * 3 * d, lddq=3 * d, dk=Gq + hz * d, dkss=L * 3 * d, lddk=3 * d, dv=Gq + 2 * hz * d, dvss=L * 3 * d, lddv=3 * d,
-                   flags=1 | 2 | 4 | 8 | 16)
+                   flags=1 | 2 | 4 | 8 | 16, planes=self._planes(H, L, L))
         self._tn(plan, ws, S, 3 * d, d, Gq, 3 * d, x_in, d,
                  [(0, d, self.G(pa + 'fc_q.weight'), self.G(pa + 'fc_q.bias')), (d, d, self.G(pa + 'fc_k.weight'), self.G(pa + 'fc_k.bias')),
                   (2 * d, d, self.G(pa + 'fc_v.weight'), self.G(pa + 'fc_v.bias'))], dy_bf=True, x_bf=True)
@@ -1081,10 +1101,11 @@ class HfttEngine:
             else:
                 self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.ca.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
             kk = b[tag + '.ckv'].data_ptr()
+            plc = st and self._planes(H, N, F)
             if j > 0:
                 qaddr, qss = b[tag + '.cq'].data_ptr(), N * d
             else:
-                qaddr, qss = b['dec0.q0'].data_ptr(), 0
+                qaddr, qss = b['dec0.q0p' if plc else 'dec0.q0'].data_ptr(), 0
             # dq (per sequence) -> Q1 ; dk,dv -> eGq viewed as [Se, 2d]
             # per-sequence dq stays fp32 (layer zero sums it over sequences with the fp32 colsum); dk, dv are "half" tensors
             # strip mode: dq of the layers with their own query projection is a GEMM operand only -> bf16; layer zero keeps fp32 (q1f)
@@ -1092,7 +1113,7 @@ class HfttEngine:
             self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
                        b[tag + '.cctx'].data_ptr(), N * d, d, b[tag + '.clse'].data_ptr(), drop_site=c_a, dout=nGx,
                        dq=dq_buf, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + hz * d, dvss=F * 2 * d, lddv=2 * d,
-                       flags=1 | 2 | 4 | 16 | (8 if (st and j > 0) else 0))
+                       flags=1 | 2 | 4 | 16 | (8 if (st and j > 0) else 0), planes=plc)
             self._tn(plan, ws, Se, 2 * d, d, eGq, 2 * d, enc, d,
                      [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
             if st:                                   # (in place: a lane reads exactly the residual elements it then overwrites)
@@ -1126,7 +1147,7 @@ class HfttEngine:
                 self._attn(plan, ws, True, BT, H, N, N, q, N * 3 * d, 3 * d, q + hz * d, N * 3 * d, 3 * d, q + 2 * hz * d, N * 3 * d, 3 * d,
                            b[tag + '.sctx'].data_ptr(), N * d, d, b[tag + '.slse'].data_ptr(), drop_site=s_a, dout=nGx,
                            dq=nGq, dqss=N * 3 * d, lddq=3 * d, dk=nGq + hz * d, dkss=N * 3 * d, lddk=3 * d, dv=nGq + 2 * hz * d, dvss=N * 3 * d, lddv=3 * d,
-                           flags=1 | 2 | 4 | 8 | 16)
+                           flags=1 | 2 | 4 | 8 | 16, planes=st and self._planes(H, N, N))
                 self._tn(plan, ws, Sn, 3 * d, d, nGq, 3 * d, trg, d,
                          [(0, d, self.G(ps + 'fc_q.weight'), self.G(ps + 'fc_q.bias')), (d, d, self.G(ps + 'fc_k.weight'), self.G(ps + 'fc_k.bias')),
                           (2 * d, d, self.G(ps + 'fc_v.weight'), self.G(ps + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)

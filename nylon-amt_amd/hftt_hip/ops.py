@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, check, lib)
+                    SL_C_BF16, SL_C_F16PAIR, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16,
+                    ATTN_Q_F16PAIR, ATTN_KV_F16PAIR, check, lib)
 
 
 def _stream(dev):
@@ -160,7 +161,7 @@ def x3_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
 
 
 def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, drop_seed=0,
-                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0, pre_bf16=False, grad_hi=False):
+                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0, pre_bf16=False, grad_hi=False, c_planes=False):
     """C = epi(x @ Wl.T + bias) with Wl given as its strip pack.  ln = (gamma, beta) -> (C, pre_ln, mean, rstd).
     x3 = 2 / 4: the split-operand form (fp32 tensors, wpack from x3_strip_pack with the same element type)."""
     _need_cuda(x, wpack)
@@ -172,7 +173,7 @@ def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, g
     d.M, d.N, d.K = M, N, K
     d.flags = (SL_X_BF16 if x.dtype == BF16 else 0) | (SL_C_BF16 if out_dtype == BF16 else 0) | (SL_RELU if relu else 0) \
         | (SL_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0) | (SL_X3_F16 if x3 == 2 else 0) | (SL_X3_BF16 if x3 == 4 else 0) \
-        | (SL_PRE_BF16 if (x3 and pre_bf16 and ln is not None) else 0) | (SL_X3_GRAD_HI if (x3 == 4 and grad_hi) else 0)
+        | (SL_PRE_BF16 if (x3 and pre_bf16 and ln is not None) else 0) | (SL_X3_GRAD_HI if (x3 == 4 and grad_hi) else 0) | (SL_C_F16PAIR if c_planes else 0)
     d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc, d.out_scale, d.gate_scale = Cout.data_ptr(), N, out_scale, gate_scale
@@ -262,7 +263,18 @@ def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True, grad_hi=False):
     return dW, db
 
 
-def _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed):
+def to_planes(x):
+    """fp32 [..., cols] (contiguous, cols % 64 == 0) -> the f16-pair plane form of the same shape (hftt_x3_to_planes): per 64-column group the
+    64 fp16 hi halves, then the 64 lo halves, in the group's 256 bytes.  A float32 tensor whose BYTES are the planes."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 64 == 0
+    out = torch.empty_like(x)
+    cols = x.shape[-1]
+    check(lib().hftt_x3_to_planes(x.data_ptr(), cols, out.data_ptr(), cols, x.numel() // cols, cols, _stream(x.device)), 'x3_to_planes')
+    return out
+
+
+def _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed, planes=False):
     n_seq, Lq, dm = q.shape
     Lk = k.shape[1]
     d = AttnDesc()
@@ -271,20 +283,21 @@ def _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed):
     d.k, d.k_seq_stride, d.ldk = k.data_ptr(), k.stride(0), k.stride(1)
     d.v, d.v_seq_stride, d.ldv = v.data_ptr(), v.stride(0), v.stride(1)
     d.drop_p, d.drop_site, d.drop_seed = drop_p, drop_site, drop_seed
-    d.io_flags = (ATTN_Q_BF16 if q.dtype == BF16 else 0) | (ATTN_KV_BF16 if k.dtype == BF16 else 0)
+    d.io_flags = (ATTN_Q_BF16 if q.dtype == BF16 else 0) | (ATTN_KV_BF16 if k.dtype == BF16 else 0) | ((ATTN_Q_F16PAIR | ATTN_KV_F16PAIR) if planes else 0)
     assert k.dtype == v.dtype
     return d
 
 
-def attn_fwd(q, k, v, n_heads, npass=3, want_probs=False, drop_p=0.0, drop_site=0, drop_seed=0, out_dtype=torch.float32):
-    """q [n_seq, Lq, d], k/v [n_seq, Lk, d] (any row/seq strides) -> out [n_seq, Lq, d], row stats [n_seq, H, Lq, 2](, probs)."""
+def attn_fwd(q, k, v, n_heads, npass=3, want_probs=False, drop_p=0.0, drop_site=0, drop_seed=0, out_dtype=torch.float32, planes=False):
+    """q [n_seq, Lq, d], k/v [n_seq, Lk, d] (any row/seq strides) -> out [n_seq, Lq, d], row stats [n_seq, H, Lq, 2](, probs).
+    planes (npass 2): q, k, v hold f16-pair planes (to_planes / a projection with SL_C_F16PAIR) instead of fp32 values."""
     _need_cuda(q, k, v)
     n_seq, Lq, dm = q.shape
     Lk = k.shape[1]
     out = torch.empty(n_seq, Lq, dm, device=q.device, dtype=out_dtype)
     lse = torch.empty(n_seq, n_heads, Lq, 2, device=q.device)     # (row max, 1/row sum)
     probs = torch.empty(n_seq, n_heads, Lq, Lk, device=q.device) if want_probs else None
-    d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed)
+    d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed, planes)
     d.out, d.o_seq_stride, d.ldo = out.data_ptr(), out.stride(0), out.stride(1)
     d.lse = lse.data_ptr()
     d.probs = probs.data_ptr() if want_probs else 0
@@ -294,7 +307,7 @@ def attn_fwd(q, k, v, n_heads, npass=3, want_probs=False, drop_p=0.0, drop_site=
 
 
 def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0, drop_seed=0, dq_dtype=torch.float32, dkv_dtype=torch.float32,
-             grads_out=None):
+             grads_out=None, planes=False):
     """grads_out = (dq, dk, dv): preallocated (possibly strided, e.g. interleaved [S, 3d]) gradient tensors to write into."""
     _need_cuda(q, k, v, out, dout)
     if grads_out is not None:
@@ -304,7 +317,7 @@ def attn_bwd(q, k, v, out, lse, dout, n_heads, npass=3, drop_p=0.0, drop_site=0,
         dq = torch.empty(q.shape, device=q.device, dtype=dq_dtype)
         dk = torch.empty(k.shape, device=q.device, dtype=dkv_dtype)
         dv = torch.empty(v.shape, device=q.device, dtype=dkv_dtype)
-    d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed)
+    d = _attn_desc(q, k, v, n_heads, npass, drop_p, drop_site, drop_seed, planes)
     d.out, d.o_seq_stride, d.ldo = out.data_ptr(), out.stride(0), out.stride(1)
     d.lse = lse.data_ptr()
     assert dout.stride() == out.stride() and dout.dtype == out.dtype

@@ -257,6 +257,91 @@ def test_attention_shared_query_and_dropout(dev):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# q / k / v as f16-pair planes (round 4): written once by the projection, staged by LDS-DMA in the forward (csrc/x3_attn_pl.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def _planes_ref(x):
+    """the plane form of an fp32 tensor [..., cols] with torch's own fp16 rounding: per 64-column group 64 hi halves, then 64 lo halves"""
+    g = x.reshape(-1, x.shape[-1] // 64, 64)
+    hi = g.clamp(-65504.0, 65504.0).half()
+    lo = (g - hi.float()).half()
+    return torch.cat([hi, lo], -1).contiguous().view(torch.float32).reshape(x.shape)
+
+
+def test_to_planes_and_the_projection_epilogue_write_the_same_bytes(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 256, generator=g) * torch.logspace(-5, 3, 256).unsqueeze(0)
+    pl = ops.to_planes(x.to(dev))
+    assert torch.equal(pl.cpu().view(torch.int32), _planes_ref(x).view(torch.int32))
+    # hftt_strip_linear with HFTT_SL_C_F16PAIR == to_planes(the same launch's fp32 result), N = 256 / 512 / 768, ragged last block
+    for M, N in ((384, 256), (1056, 768), (640, 512), (40000, 768)):
+        xx = torch.randn(M, 256, generator=g); W = torch.randn(N, 256, generator=g) / 16.0; b = torch.randn(N, generator=g)
+        wp = ops.x3_strip_pack(W.to(dev), 2, order=1)
+        full = ops.strip_linear(xx.to(dev), wp, N, b.to(dev), x3=2)
+        pln = ops.strip_linear(xx.to(dev), wp, N, b.to(dev), x3=2, c_planes=True)
+        assert torch.equal(pln.view(torch.int32), ops.to_planes(full).view(torch.int32)), (M, N)
+
+
+PLANE_GEOMS = [(5, 4, 256, 256), (37, 4, 256, 256), (5, 4, 88, 256), (300, 4, 88, 256), (5, 4, 88, 88), (6, 4, 128, 128), (700, 2, 128, 128), (3, 2, 48, 48),
+               (3, 1, 16, 16), (3, 2, 12, 40), (2, 1, 100, 70), (2, 2, 200, 250)]
+
+
+@pytest.mark.parametrize('drop', [0.0, 0.1])
+@pytest.mark.parametrize('n,H,Lq,Lk', PLANE_GEOMS)
+def test_attention_on_planes_equals_attention_on_fp32_operands(dev, n, H, Lq, Lk, drop):
+    """The plane forms run the SAME arithmetic in the same order on the same halves: forward outputs, row statistics and the attention map are
+    bit-identical to the fp32-operand kernels' (themselves held against fp64 above); the backward's bf16 pairs are formed from hi + lo instead
+    of the fp32 value (2^-23 apart: a bf16 pair's last bit, 2^-17, may round the other way), so its gradients agree to the pair's precision.  More (sequence, head) items than persistent workgroups, key padding,
+    ragged query blocks, idle waves (88 queries on 4 waves), the shared query of layer zero."""
+    ops = _ops()
+    dh, d = 64, 64 * H
+    g = torch.Generator().manual_seed(Lq * 1000 + Lk + n)
+    if Lq == Lk:
+        qkv = (torch.randn(n, Lq, 3 * d, generator=g) * 1.5).to(dev)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        pq = ops.to_planes(qkv)
+        qp, kp, vp = pq[..., :d], pq[..., d:2 * d], pq[..., 2 * d:]
+    else:
+        q = (torch.randn(n, Lq, d, generator=g) * 1.5).to(dev)
+        kv = (torch.randn(n, Lk, 2 * d, generator=g) * 1.5).to(dev)
+        k, v = kv[..., :d], kv[..., d:]
+        qp = ops.to_planes(q); pkv = ops.to_planes(kv)
+        kp, vp = pkv[..., :d], pkv[..., d:]
+    kw = dict(drop_p=drop, drop_site=7, drop_seed=99)
+    for want in (False, True):
+        ref = ops.attn_fwd(q, k, v, H, npass=2, want_probs=want, **kw)
+        got = ops.attn_fwd(qp, kp, vp, H, npass=2, want_probs=want, planes=True, **kw)
+        for a, b_ in zip(ref, got):
+            assert torch.equal(a, b_), (want, max_err(a, b_))
+    out, lse = ref[0], ref[1]
+    do = (torch.randn(n, Lq, d, generator=g) * 1e-5).to(dev)
+    r_dq, r_dk, r_dv = ops.attn_bwd(q, k, v, out, lse, do, H, npass=2, **kw)
+    g_dq, g_dk, g_dv = ops.attn_bwd(qp, kp, vp, out, lse, do, H, npass=2, planes=True, **kw)
+    for a, b_ in ((r_dq, g_dq), (r_dk, g_dk), (r_dv, g_dv)):
+        assert rel_err(b_, a.double().cpu()) < 4e-5
+
+
+def test_attention_on_planes_shared_query(dev):
+    """layer zero (model_spec2midi.py:154-155): one query block for all sequences (sequence stride 0), as planes from hftt_x3_to_planes"""
+    ops = _ops()
+    n, H, Lq, Lk, d = 9, 4, 88, 256, 256
+    g = torch.Generator().manual_seed(8)
+    q1 = torch.randn(1, Lq, d, generator=g).to(dev); kv = torch.randn(n, Lk, 2 * d, generator=g).to(dev)
+    qd = q1.expand(n, Lq, d); qp = ops.to_planes(q1).expand(n, Lq, d)
+    pkv = ops.to_planes(kv)
+    kw = dict(drop_p=0.1, drop_site=3, drop_seed=5)
+    ref = ops.attn_fwd(qd, kv[..., :d], kv[..., d:], H, npass=2, want_probs=True, **kw)
+    got = ops.attn_fwd(qp, pkv[..., :d], pkv[..., d:], H, npass=2, want_probs=True, planes=True, **kw)
+    for a, b_ in zip(ref, got):
+        assert torch.equal(a, b_)
+    do = (torch.randn(n, Lq, d, generator=g) * 1e-5).to(dev)
+    r = ops.attn_bwd(qd, kv[..., :d], kv[..., d:], ref[0], ref[1], do, H, npass=2, **kw)
+    t = ops.attn_bwd(qp, pkv[..., :d], pkv[..., d:], ref[0], ref[1], do, H, npass=2, planes=True, **kw)
+    for a, b_ in zip(r, t):
+        assert rel_err(b_, a.double().cpu()) < 4e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # strip kernels of the x3 mode (csrc/x3_strip.hip): token strips as (hi, lo) register pairs, split weight fragments through the ring
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('elem', [2, 4])
