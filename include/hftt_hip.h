@@ -173,7 +173,7 @@ int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_p
 /* split modes, LayerNorm forms (hftt_strip_linear with ln_gamma, hftt_ffn_res_ln_fwd): pre_ln_out is bf16 [M, 256] -- it is read only by
  * hftt_ln_bwd (HFTT_LNB_R_BF16), as xhat = (r - mean) * rstd against the fp32 statistics. */
 #define HFTT_SL_PRE_BF16 128u
-/* HFTT_SL_X3_F16 without LayerNorm, K == 256 (the output-tile-major kernel): C is written as f16-pair planes per 64-column group (see
+/* HFTT_SL_X3_F16 without LayerNorm, K == 256 (the output-tile-major kernel): C is written as f16-pair planes per 32-column group (see
  * HFTT_ATTN_Q_F16PAIR) -- the q / k / v projections of the attention layers (model_spec2midi.py:328-330) */
 #define HFTT_SL_C_F16PAIR 512u
 /* C[M,N] = epi(x[M,K] . Wl[N,K]^T + bias): same epilogue order as hftt_gemm_nt (relu, out_scale, gate, dropout, residual,
@@ -255,8 +255,8 @@ int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream);
 #define HFTT_ATTN_O_BF16 4u       /* out, dout */
 #define HFTT_ATTN_DQ_BF16 8u      /* dq */
 #define HFTT_ATTN_DKV_BF16 16u    /* dk, dv */
-/* npass 2 only, dh == 64: q / k, v are "f16-pair planes" -- the 64 fp32 slots (256 bytes) of one (row, head) hold the 64 fp16 hi halves
- * followed by the 64 fp16 lo halves of the split operand (x = hi + lo to 2^-22), written ONCE by the projection that produced them
+/* npass 2 only, dh == 64: q / k, v are "f16-pair planes" -- the 32 fp32 slots (128 bytes) of every aligned 32-column group of a row hold
+ * the group's 32 fp16 hi halves followed by its 32 fp16 lo halves (x = hi + lo to 2^-22), written ONCE by the projection that produced them
  * (hftt_strip_linear with HFTT_SL_C_F16PAIR, hftt_x3_to_planes) instead of being split by every kernel that reads them; pointers and
  * strides keep their fp32 meaning.  Both flags or neither.  The forward then stages K / V by LDS-DMA (csrc/x3_attn_pl.hip: persistent
  * workgroups, ceil(Lq / 32) <= 8 at Lk > 128 and <= 4 below); results are bit-identical to the fp32-operand form's. */
@@ -285,7 +285,7 @@ typedef struct {
 } hftt_attn_desc;
 int hftt_attn_fwd(const hftt_attn_desc* d, void* stream);
 int hftt_attn_bwd(const hftt_attn_desc* d, void* stream);
-/* fp32 [rows, cols] (row stride lds) -> f16-pair planes [rows, cols] (row stride ldd, both in fp32 slots), per 64-column group; cols % 64 == 0,
+/* fp32 [rows, cols] (row stride lds) -> f16-pair planes [rows, cols] (row stride ldd, both in fp32 slots), per 32-column group; cols % 32 == 0,
  * dst != src.  For operands no strip kernel produces (the shared query of DecoderLayer_Zero, model_spec2midi.py:154-155; tests). */
 int hftt_x3_to_planes(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows, int32_t cols, void* stream);
 

@@ -364,12 +364,12 @@ int dispatch_xf(const hftt_attn_desc& d, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------------------
-// f16-pair planes (HFTT_ATTN_*_F16PAIR, dh == 64: x3_attn_pl.hip): four consecutive elements of one (row, head) = 8 bytes of the hi plane
-// + 8 bytes of the lo plane, 128 bytes apart; hi + lo is exact in fp32 (at most 23 significant bits)
+// f16-pair planes (HFTT_ATTN_*_F16PAIR, dh == 64: x3_attn_pl.hip): every aligned 32-column group of a row = 32 hi halves (64 B), then 32 lo
+// halves.  Four consecutive elements 4*c4 .. of one (row, head) = 8 bytes of each; hi + lo is exact in fp32 (at most 23 significant bits)
 __device__ __forceinline__ void pl_load4(const float* head_row, int c4, uint2& hi, uint2& lo) {
-  const unsigned char* p = reinterpret_cast<const unsigned char*>(head_row) + c4 * 8;
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(head_row) + (c4 >> 3) * 128 + (c4 & 7) * 8;
   hi = *reinterpret_cast<const uint2*>(p);
-  lo = *reinterpret_cast<const uint2*>(p + 128);
+  lo = *reinterpret_cast<const uint2*>(p + 64);
 }
 __device__ __forceinline__ float4 pl_vals4(const uint2& hi, const uint2& lo) {
   float h0, h1, h2, h3, l0, l1, l2, l3;
@@ -379,9 +379,9 @@ __device__ __forceinline__ float4 pl_vals4(const uint2& hi, const uint2& lo) {
 }
 // eight consecutive elements (one MFMA fragment): 16 bytes of each plane
 __device__ __forceinline__ void pl_load8(const float* head_row, int e0, bf16x8& hi, bf16x8& lo) {
-  const unsigned char* p = reinterpret_cast<const unsigned char*>(head_row) + e0 * 2;
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(head_row) + (e0 >> 5) * 128 + (e0 & 31) * 2;
   hi = *reinterpret_cast<const bf16x8*>(p);
-  lo = *reinterpret_cast<const bf16x8*>(p + 128);
+  lo = *reinterpret_cast<const bf16x8*>(p + 64);
 }
 __device__ __forceinline__ void pl_vals8(const bf16x8& hi, const bf16x8& lo, float* v) {
   const uint4 h = __builtin_bit_cast(uint4, hi), l = __builtin_bit_cast(uint4, lo);

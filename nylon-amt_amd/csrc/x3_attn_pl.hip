@@ -2,8 +2,11 @@
 // the projection that produced them (hftt_strip_linear with HFTT_SL_C_F16PAIR, or hftt_x3_to_planes), not as fp32 that every consumer
 // splits again.  Contract: include/hftt_hip.h (hftt_attn_fwd, npass 2, HFTT_ATTN_Q_F16PAIR | HFTT_ATTN_KV_F16PAIR, dh == 64).
 //
-// Plane layout ("f16 pair"): the 64 fp32 slots (256 bytes) of one (row, head) hold 64 fp16 hi halves (128 B) followed by 64 fp16 lo
-// halves (128 B); every stride of the descriptor keeps its fp32 meaning.  x = hi + lo to 2^-22 (x3_common.h).
+// Plane layout ("f16 pair"): the 32 fp32 slots (128 bytes) of every aligned 32-column group of a row hold the group's 32 fp16 hi halves
+// (64 B) followed by its 32 fp16 lo halves (64 B); every stride of the descriptor keeps its fp32 meaning.  x = hi + lo to 2^-22
+// (x3_common.h).  The group is the strip kernels' output tile: a projection's epilogue still writes one whole 128-byte segment per row and
+// tile, exactly as for fp32 results (a per-head layout, 64 hi then 64 lo, made every store instruction touch 16 half lines instead of 8
+// lines and cost the QKV projection 20 %); the consumers fetch 16-byte pieces at computed addresses anyway.
 //
 // What this buys (x3_attn.hip staged K / V through the vector ALU: fp32 loads, split, ds_write; 453 us per encoder launch with the
 // load phase and the compute phase of a workgroup strictly one after the other, one workgroup per CU):
@@ -80,8 +83,8 @@ __device__ __forceinline__ void pl_dma_tensor(const unsigned char* base, long ld
     const int plane = idx >= PIECES ? 1 : 0, pc = idx - plane * PIECES;
     const int row = 8 * pc + r8;
     const int rowc = row < Lk ? row : Lk - 1;
-    const int c = (lane & 7) ^ pl_swz(row);
-    pl_glds16(base + (long)rowc * ld_bytes + plane * 128 + c * 16, lds_base + (unsigned)(plane * PLANE + pc * 1024));
+    const int c = (lane & 7) ^ pl_swz(row);                     // 16-byte chunk of the head's 64 halves: group c >> 2, piece c & 3
+    pl_glds16(base + (long)rowc * ld_bytes + plane * 64 + (c >> 2) * 128 + (c & 3) * 16, lds_base + (unsigned)(plane * PLANE + pc * 1024));
   }
 }
 
@@ -125,9 +128,9 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
     const int qrc = qr < Lq ? qr : Lq - 1;
     const unsigned char* qp = reinterpret_cast<const unsigned char*>(g.q + (long)seq * g.q_seq_stride + (long)qrc * g.ldq + head * DH) + 16 * (ln >> 5);
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-      qh[s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s);
-      ql[s] = *reinterpret_cast<const bf16x8*>(qp + 128 + 32 * s);
+    for (int s = 0; s < KS; s++) {                             // elements 16s + 8lh ..: group s >> 1, byte 32 * (s & 1) + 16 * lh of its hi half
+      qh[s] = *reinterpret_cast<const bf16x8*>(qp + 128 * (s >> 1) + 32 * (s & 1));
+      ql[s] = *reinterpret_cast<const bf16x8*>(qp + 128 * (s >> 1) + 32 * (s & 1) + 64);
     }
   };
 
@@ -431,7 +434,7 @@ int launch_pf2(const hftt_attn_desc& d, hipStream_t st) {
   return d.probs != nullptr ? launch_pf3<KT, NW, true>(d, st) : launch_pf3<KT, NW, false>(d, st);
 }
 
-// fp32 [rows, cols] -> f16-pair planes, per 64-column group: one thread per 8 consecutive elements
+// fp32 [rows, cols] -> f16-pair planes, per 32-column group: one thread per 8 consecutive elements
 __global__ __launch_bounds__(256) void x3_to_planes_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, int rows, int cols) {
   const int per_row = cols >> 3;
   const long total = (long)rows * per_row;
@@ -442,10 +445,10 @@ __global__ __launch_bounds__(256) void x3_to_planes_kernel(const float* __restri
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     bf16x8 hi, lo;
     x3_split8<X3_F16>(v, hi, lo);
-    const int grp = c8 >> 3, w = c8 & 7;                       // 64-column group, 8-element piece inside it
-    unsigned char* o = reinterpret_cast<unsigned char*>(dst + (long)r * ldd + grp * 64);
+    const int grp = c8 >> 2, w = c8 & 3;                       // 32-column group, 8-element piece inside it
+    unsigned char* o = reinterpret_cast<unsigned char*>(dst + (long)r * ldd + grp * 32);
     *reinterpret_cast<bf16x8*>(o + w * 16) = hi;
-    *reinterpret_cast<bf16x8*>(o + 128 + w * 16) = lo;
+    *reinterpret_cast<bf16x8*>(o + 64 + w * 16) = lo;
   }
 }
 
@@ -476,7 +479,7 @@ int hftt_x3p_attn_fwd_try(const hftt_attn_desc& d0, hipStream_t st) {
 }
 
 extern "C" int hftt_x3_to_planes(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows, int32_t cols, void* stream) {
-  HFTT_REQUIRE(src != nullptr && dst != nullptr && rows > 0 && cols > 0 && cols % 64 == 0, "x3_to_planes: cols must be a multiple of 64 (got %d x %d)", rows, cols);
+  HFTT_REQUIRE(src != nullptr && dst != nullptr && rows > 0 && cols > 0 && cols % 32 == 0, "x3_to_planes: cols must be a multiple of 32 (got %d x %d)", rows, cols);
   HFTT_REQUIRE(lds % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "x3_to_planes: rows must be 16-byte aligned");
   HFTT_REQUIRE(src != dst, "x3_to_planes: not an in-place operation (a thread's 16-byte outputs overlap its neighbours' 32-byte inputs)");
   const long total = (long)rows * (cols / 8);

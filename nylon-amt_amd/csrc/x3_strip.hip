@@ -244,19 +244,16 @@ __device__ __forceinline__ void tile_store_rows_bf16(float* stage, const float* 
   }
 }
 // The same tile as an f16 PAIR (HFTT_SL_C_F16PAIR: the q / k / v projections, read by the attention kernels as MFMA operands without any
-// further conversion -- x3_attn_pl.hip): the tile's 32 columns are one half of a 64-column head group whose 256 bytes per row hold the 64
-// hi halves, then the 64 lo halves.  ghi: byte address of this tile's 64-byte hi segment in row 0 of the wave's strip (group base +
-// 64 * (tile & 1)); the lo segment sits 128 bytes behind it.  Through the same patch (rows of 144 B: hi 64 | lo 64 | pad), 8 rows x (4 + 4)
-// 16-byte pieces per store instruction.
-__device__ __forceinline__ void tile_store_rows_f16pair(float* stage, const float* v, int j, int h, int lane, unsigned char* ghi, long ld_bytes, bool ok) {
-  unsigned char* st8 = reinterpret_cast<unsigned char*>(stage);
+// further conversion -- x3_attn_pl.hip): the tile's 128 bytes per row hold its 32 hi halves (64 B), then its 32 lo halves -- the same
+// whole-line row segments as the fp32 form, through the same patch.
+__device__ __forceinline__ void tile_store_rows_f16pair(float* stage, const float* v, int j, int h, int lane, float* gtile, long ld, bool ok) {
   bf16x8 hi0, lo0, hi1, lo1;
   x3_split8<X3_F16>(v, hi0, lo0);
   x3_split8<X3_F16>(v + 8, hi1, lo1);
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     if ((j >> 4) == half) {
-      unsigned char* w = st8 + (j & 15) * (STG_RS * 4) + 32 * h;
+      unsigned char* w = reinterpret_cast<unsigned char*>(stage + (j & 15) * STG_RS) + 32 * h;
       *reinterpret_cast<bf16x8*>(w) = hi0;
       *reinterpret_cast<bf16x8*>(w + 16) = hi1;
       *reinterpret_cast<bf16x8*>(w + 64) = lo0;
@@ -264,9 +261,9 @@ __device__ __forceinline__ void tile_store_rows_f16pair(float* stage, const floa
     }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      const int r = (lane >> 3) + 8 * k, pc = lane & 7;
-      const uint4 t = *reinterpret_cast<const uint4*>(st8 + r * (STG_RS * 4) + pc * 16);
-      if (ok) *reinterpret_cast<uint4*>(ghi + (long)(half * 16 + r) * ld_bytes + (pc & 3) * 16 + (pc >> 2) * 128) = t;
+      const int r = (lane >> 3) + 8 * k;
+      const float4 t = *reinterpret_cast<const float4*>(stage + r * STG_RS + (lane & 7) * 4);
+      if (ok) *reinterpret_cast<float4*>(gtile + (long)(half * 16 + r) * ld + (lane & 7) * 4) = t;
     }
   }
 }
@@ -560,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] += r[q];
       }
-      if (PLN) tile_store_rows_f16pair(stage, v, j, hb, lane, reinterpret_cast<unsigned char*>(cwave) + (t >> 1) * 256 + (t & 1) * 64, g.ldc * 4, wave_ok && !dbg_nostore);
+      if (PLN) tile_store_rows_f16pair(stage, v, j, hb, lane, cwave + t * 32, g.ldc, wave_ok && !dbg_nostore);
       else tile_store_rows(stage, v, j, hb, lane, cwave + t * 32, g.ldc, wave_ok && !dbg_nostore);
     });
   }

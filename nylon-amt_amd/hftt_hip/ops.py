@@ -264,10 +264,10 @@ def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True, grad_hi=False):
 
 
 def to_planes(x):
-    """fp32 [..., cols] (contiguous, cols % 64 == 0) -> the f16-pair plane form of the same shape (hftt_x3_to_planes): per 64-column group the
-    64 fp16 hi halves, then the 64 lo halves, in the group's 256 bytes.  A float32 tensor whose BYTES are the planes."""
+    """fp32 [..., cols] (contiguous, cols % 32 == 0) -> the f16-pair plane form of the same shape (hftt_x3_to_planes): per 32-column group the
+    32 fp16 hi halves, then the 32 lo halves, in the group's 128 bytes.  A float32 tensor whose BYTES are the planes."""
     _need_cuda(x)
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 64 == 0
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 32 == 0
     out = torch.empty_like(x)
     cols = x.shape[-1]
     check(lib().hftt_x3_to_planes(x.data_ptr(), cols, out.data_ptr(), cols, x.numel() // cols, cols, _stream(x.device)), 'x3_to_planes')

@@ -260,8 +260,8 @@ def test_attention_shared_query_and_dropout(dev):
 # q / k / v as f16-pair planes (round 4): written once by the projection, staged by LDS-DMA in the forward (csrc/x3_attn_pl.hip)
 # ---------------------------------------------------------------------------------------------------------------------
 def _planes_ref(x):
-    """the plane form of an fp32 tensor [..., cols] with torch's own fp16 rounding: per 64-column group 64 hi halves, then 64 lo halves"""
-    g = x.reshape(-1, x.shape[-1] // 64, 64)
+    """the plane form of an fp32 tensor [..., cols] with torch's own fp16 rounding: per 32-column group 32 hi halves, then 32 lo halves"""
+    g = x.reshape(-1, x.shape[-1] // 32, 32)
     hi = g.clamp(-65504.0, 65504.0).half()
     lo = (g - hi.float()).half()
     return torch.cat([hi, lo], -1).contiguous().view(torch.float32).reshape(x.shape)
