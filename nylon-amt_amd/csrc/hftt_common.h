@@ -207,6 +207,11 @@ __device__ __forceinline__ float xor32_max(float v) {
 // Accumulator layouts put adjacent COLUMNS in lanes 2i / 2i+1 and two ROWS (a, b) in one lane.  pair_rows_to_cols() turns that
 // into one packed bf16 pair of adjacent columns per lane: the even lane gets row a = [own a | partner a], the odd lane row b =
 // [partner b | own b].  One cvt_pk + one DPP move + one byte permute for two elements.
+// the same from an already packed pair pk = [a | b] (lo16 = row a, hi16 = row b of this lane's column)
+__device__ __forceinline__ unsigned packed_rows_to_cols(unsigned pk, bool odd) {
+  const unsigned q = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0xB1, 0xF, 0xF, true);   // partner's pair
+  return __builtin_amdgcn_perm(pk, q, odd ? 0x07060302u : 0x01000504u);
+}
 __device__ __forceinline__ unsigned pair_rows_to_cols(float a, float b, bool odd) {
   typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
   typedef float f2_t __attribute__((ext_vector_type(2)));

@@ -1,0 +1,448 @@
+// Attention backward of the split-operand ("x3") mode (gfx950), shared by x3_attn.hip (fp32 operands) and x3_attn_pl.hip (q, k, v as f16-pair
+// planes): the kernel template and its dispatch.  Included INSIDE an anonymous namespace, after hftt_common.h / x3_common.h / hftt_host.h.
+#pragma once
+#ifndef XABL
+#ifdef HFTT_X3_ATTN_ABLATE
+#define XABL(g, bit) (((g).pad & (bit)) != 0)
+#else
+#define XABL(g, bit) false
+#endif
+#endif
+constexpr float XB_LOG2E = 1.4426950408889634f;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------------
+// f16-pair planes (HFTT_ATTN_*_F16PAIR, dh == 64: x3_attn_pl.hip): every aligned 32-column group of a row = 32 hi halves (64 B), then 32 lo
+// halves.  Four consecutive elements 4*c4 .. of one (row, head) = 8 bytes of each; hi + lo is exact in fp32 (at most 23 significant bits)
+__device__ __forceinline__ void pl_load4(const float* head_row, int c4, uint2& hi, uint2& lo) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(head_row) + (c4 >> 3) * 128 + (c4 & 7) * 8;
+  hi = *reinterpret_cast<const uint2*>(p);
+  lo = *reinterpret_cast<const uint2*>(p + 64);
+}
+__device__ __forceinline__ float4 pl_vals4(const uint2& hi, const uint2& lo) {
+  float h0, h1, h2, h3, l0, l1, l2, l3;
+  X3<X3_F16>::unpk(hi.x, h0, h1); X3<X3_F16>::unpk(hi.y, h2, h3);
+  X3<X3_F16>::unpk(lo.x, l0, l1); X3<X3_F16>::unpk(lo.y, l2, l3);
+  return make_float4(h0 + l0, h1 + l1, h2 + l2, h3 + l3);
+}
+// eight consecutive elements (one MFMA fragment): 16 bytes of each plane
+__device__ __forceinline__ void pl_load8(const float* head_row, int e0, bf16x8& hi, bf16x8& lo) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(head_row) + (e0 >> 5) * 128 + (e0 & 31) * 2;
+  hi = *reinterpret_cast<const bf16x8*>(p);
+  lo = *reinterpret_cast<const bf16x8*>(p + 64);
+}
+__device__ __forceinline__ void pl_vals8(const bf16x8& hi, const bf16x8& lo, float* v) {
+  const uint4 h = __builtin_bit_cast(uint4, hi), l = __builtin_bit_cast(uint4, lo);
+  const unsigned hh[4] = {h.x, h.y, h.z, h.w}, ll[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    float a0, a1, b0, b1;
+    X3<X3_F16>::unpk(hh[q], a0, a1); X3<X3_F16>::unpk(ll[q], b0, b1);
+    v[2 * q] = a0 + b0; v[2 * q + 1] = a1 + b1;
+  }
+}
+
+template <int KT, int DH>
+struct XbCfg {
+  static constexpr int LKP = KT * 32;
+  static constexpr int RSK = (DH == 64) ? 96 : 32;    // K image (bf16 pair) for dQ: tr-read friendly (64 mod 128 bytes)
+  static constexpr int RSQ = DH + 8;                  // Q / dO blocks: b128-read friendly
+  static constexpr int RSS = LKP + 8;                 // dS block [query][key]
+  static constexpr int K_PL = LKP * RSK;
+  static constexpr int Q_PL = 32 * RSQ;
+  static constexpr int S_PL = 32 * RSS;
+  // K image (bf16 hi, lo) | Q fp16 (hi, lo) | Q bf16 (hi, lo) | dO bf16 (hi, lo) | dS bf16 (hi, lo) | row statistics
+  static constexpr int ELEMS = 2 * K_PL + 6 * Q_PL + 2 * S_PL;
+  static constexpr int LDS_LOOP = ELEMS * 2 + 96 * 4;
+  static constexpr int RSE = DH + 4;                  // epilogue patch rows (floats)
+  static constexpr int LDS_EPI = KT * 2 * 32 * RSE * 4;
+  static constexpr int LDS_BYTES = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+  static constexpr int NTHR = KT * 64;
+};
+
+// PL: q, k, v are f16-pair planes (dh == 64): the fp16 halves the score recomputation needs are the stored bytes (the forward's, bit for
+// bit); the bf16 pairs of the gradient products are formed from hi + lo
+// DM: the dropout form (0 none, 1 one hash per aligned key quad, 2 per element), chosen by the host (as in x3_attn_pl.hip: three forms
+// instantiated side by side inside the query-block loop cost registers and scratch)
+template <int KT, int DH, bool PL, int DM>
+__global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_desc g) {
+  static_assert(!PL || DH == 64, "f16-pair planes: dh == 64");
+  using Cfg = XbCfg<KT, DH>;
+  constexpr int EF = X3_F16, EB = X3_BF16;
+  constexpr int RSK = Cfg::RSK, RSQ = Cfg::RSQ, RSS = Cfg::RSS, LKP = Cfg::LKP, NTHR = Cfg::NTHR;
+  constexpr int K_PL = Cfg::K_PL, Q_PL = Cfg::Q_PL, S_PL = Cfg::S_PL;
+  constexpr int KS = DH / 16, NT = DH / 32, F4R = DH / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* Kb = reinterpret_cast<unsigned short*>(smem);       // bf16 hi | lo
+  unsigned short* Qf = Kb + 2 * K_PL;                                   // fp16 hi | lo   (scores)
+  unsigned short* Qb = Qf + 2 * Q_PL;                                   // bf16 hi | lo   (dK)
+  unsigned short* Ob = Qb + 2 * Q_PL;                                   // dO, bf16 hi | lo
+  unsigned short* Sb = Ob + 2 * Q_PL;                                   // dS, bf16 hi | lo
+  float* lse_s = reinterpret_cast<float*>(smem + (size_t)Cfg::ELEMS * 2);
+  float* delta_s = lse_s + 32;
+  float* inv_s = lse_s + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr0 = lane & 31, lh0 = lane >> 5;
+  const int gi0 = lane >> 4, qq0 = (lane & 15) >> 2, pp0 = lane & 3;
+  const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
+  const int Lq = g.Lq, Lk = g.Lk;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float c2 = scale * XB_LOG2E;
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = hftt_keep_scale(g.drop_p);
+  const float keep_inv = g.drop_p > 0.f ? (float)thr * (1.0f / 256.0f) : 1.0f;      // 1 / inv_keep, exactly
+
+  const long kofs = (long)seq * g.k_seq_stride + head * DH;
+  const long vofs = (long)seq * g.v_seq_stride + head * DH;
+  // ---- stage all of K (row-major, bf16 pair) for the dQ product ----
+  {
+    constexpr int KCNT = (LKP * F4R + NTHR - 1) / NTHR;
+    float4 kst[KCNT];
+#pragma unroll
+    for (int u = 0; u < KCNT; u++) {
+      const int i = tid + NTHR * u;
+      const int ic = i < LKP * F4R ? i : LKP * F4R - 1;
+      const int key = ic / F4R, c4 = ic % F4R;
+      const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
+      if (PL) {
+        uint2 ph_, pl_;
+        pl_load4(g.k + kofs + (long)kc * g.ldk, c4, ph_, pl_);
+        kst[u] = pl_vals4(ph_, pl_);
+      } else {
+        kst[u] = *reinterpret_cast<const float4*>(g.k + kofs + (long)kc * g.ldk + c4 * 4);
+      }
+      if (key >= Lk) kst[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < KCNT; u++) {
+      const int i = tid + NTHR * u;
+      if (i < LKP * F4R) {
+        const int key = i / F4R, c4 = i % F4R;
+        uint2 hi, lo;
+        x3_split4<EB>(kst[u], hi, lo);
+        *reinterpret_cast<uint2*>(Kb + key * RSK + c4 * 4) = hi;
+        *reinterpret_cast<uint2*>(Kb + K_PL + key * RSK + c4 * 4) = lo;
+      }
+    }
+  }
+  // ---- this wave's K rows (fp16 pair: the scores) and V rows (bf16 pair: dP) as B-operand fragments (B[k = dh][col = key]) ----
+  const int mykey = wave * 32 + lr0;
+  const int mykey_c = mykey < Lk ? mykey : Lk - 1;
+  bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    if (PL) {
+      bf16x8 th, tl;
+      pl_load8(g.k + kofs + (long)mykey_c * g.ldk, 16 * s + 8 * lh0, kfh[s], kfl[s]);
+      pl_load8(g.v + vofs + (long)mykey_c * g.ldv, 16 * s + 8 * lh0, th, tl);
+      float vv[8];
+      pl_vals8(th, tl, vv);
+      if (mykey >= Lk) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        kfh[s] = z; kfl[s] = z;
+#pragma unroll
+        for (int e = 0; e < 8; e++) vv[e] = 0.f;
+      }
+      x3_split8<EB>(vv, vfh[s], vfl[s]);
+      continue;
+    }
+    const float* kp = g.k + kofs + (long)mykey_c * g.ldk + 16 * s + 8 * lh0;
+    const float* vp = g.v + vofs + (long)mykey_c * g.ldv + 16 * s + 8 * lh0;
+    const float4 a0 = *reinterpret_cast<const float4*>(kp), a1 = *reinterpret_cast<const float4*>(kp + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(vp), b1 = *reinterpret_cast<const float4*>(vp + 4);
+    float kv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    float vv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    if (mykey >= Lk) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
+    }
+    x3_split8<EF>(kv, kfh[s], kfl[s]);
+    x3_split8<EB>(vv, vfh[s], vfl[s]);
+  }
+  f32x16 dKT[NT], dVT[NT];
+#pragma unroll
+  for (int n = 0; n < NT; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dKT[n][r] = 0.f; dVT[n][r] = 0.f; }
+
+  const long qofs = (long)seq * g.q_seq_stride + head * DH;
+  const long oofs = (long)seq * g.o_seq_stride + head * DH;
+  const long dqofs = (long)seq * g.dq_seq_stride + head * DH;
+  const long sh = (long)seq * g.n_heads + head;
+  const int nqb = (Lq + 31) / 32;
+
+  // Q / dO / O rows (+ row statistics) of the NEXT query block are fetched into registers while the current block is processed
+  constexpr int QCNT = (32 * F4R + NTHR - 1) / NTHR;
+  float4 pq[QCNT], pdo[QCNT], po[QCNT];
+  float2 pl[QCNT];
+  auto qload = [&](int qb) {
+    int tid_q = tid;
+    asm volatile("" : "+v"(tid_q));                    // (row / column offsets are formed per call, not kept in registers across the loop)
+#pragma unroll
+    for (int u = 0; u < QCNT; u++) {
+      const int i = tid_q + NTHR * u;
+      const int ic = i < 32 * F4R ? i : 32 * F4R - 1;
+      const int row = ic / F4R, cs = ic % F4R;
+      const int q = qb * 32 + row;
+      const int qc = q < Lq ? q : Lq - 1;          // clamped address: loads stay unconditional (rows past Lq are zeroed at consumption)
+      if (PL) {                                    // (hi, lo) pairs of the four elements, carried in the same four registers
+        uint2 ph_, pl_;
+        pl_load4(g.q + qofs + (long)qc * g.ldq, cs, ph_, pl_);
+        pq[u] = make_float4(__uint_as_float(ph_.x), __uint_as_float(ph_.y), __uint_as_float(pl_.x), __uint_as_float(pl_.y));
+      } else {
+        pq[u] = *reinterpret_cast<const float4*>(g.q + qofs + (long)qc * g.ldq + cs * 4);
+      }
+      pdo[u] = *reinterpret_cast<const float4*>(g.dout + oofs + (long)qc * g.ldo + cs * 4);
+      po[u] = *reinterpret_cast<const float4*>(g.out + oofs + (long)qc * g.ldo + cs * 4);
+      pl[u] = *reinterpret_cast<const float2*>(g.lse + (sh * Lq + qc) * 2);
+    }
+  };
+  qload(0);
+
+  for (int qb = 0; qb < nqb; qb++) {
+    // lane-derived indices as values the optimiser cannot see through: every LDS / global address below is then formed where it is used.
+    // Left visible, LICM hoists dozens of loop-invariant addresses out of this loop and keeps them live across it (spills at KT = 8, dh = 64).
+    int lr = lr0, lh = lh0, gi = gi0, qq = qq0, pp = pp0;
+    asm volatile("" : "+v"(lr), "+v"(lh), "+v"(gi), "+v"(qq), "+v"(pp));
+    // wave-uniform floats live in vector registers on this ISA (no scalar float ALU): pinned to scalar registers by v_readfirstlane
+    const float keep_inv_s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(keep_inv)));
+    const float sk_s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(scale * inv_keep)));
+    // ---- (a) registers -> LDS: the Q block (both forms) and the dO block, delta = rowsum(dO*O), row statistics ----
+    int tid_a = tid;
+    asm volatile("" : "+v"(tid_a));
+#pragma unroll
+    for (int u = 0; u < QCNT; u++) {
+      const int i = tid_a + NTHR * u;
+      if (i < 32 * F4R) {                           // wave-uniform (32*F4R and NTHR are multiples of 64)
+        const int row = i / F4R, cs = i % F4R;
+        if (qb * 32 + row >= Lq) { pq[u] = make_float4(0.f, 0.f, 0.f, 0.f); pdo[u] = pq[u]; po[u] = pq[u]; pl[u] = make_float2(0.f, 0.f); }
+        uint2 hi, lo;
+        if (!XABL(g, 1)) {
+        if (PL) {                                     // the stored fp16 pair IS the score operand; its sum feeds the bf16 pair of dK
+          hi = make_uint2(__float_as_uint(pq[u].x), __float_as_uint(pq[u].y));
+          lo = make_uint2(__float_as_uint(pq[u].z), __float_as_uint(pq[u].w));
+          pq[u] = pl_vals4(hi, lo);
+        } else {
+          x3_split4<EF>(pq[u], hi, lo);
+        }
+        *reinterpret_cast<uint2*>(Qf + row * RSQ + cs * 4) = hi;
+        *reinterpret_cast<uint2*>(Qf + Q_PL + row * RSQ + cs * 4) = lo;
+        x3_split4<EB>(pq[u], hi, lo);
+        *reinterpret_cast<uint2*>(Qb + row * RSQ + cs * 4) = hi;
+        *reinterpret_cast<uint2*>(Qb + Q_PL + row * RSQ + cs * 4) = lo;
+        x3_split4<EB>(pdo[u], hi, lo);
+        *reinterpret_cast<uint2*>(Ob + row * RSQ + cs * 4) = hi;
+        *reinterpret_cast<uint2*>(Ob + Q_PL + row * RSQ + cs * 4) = lo;
+        }
+        float dot = pdo[u].x * po[u].x + pdo[u].y * po[u].y + pdo[u].z * po[u].z + pdo[u].w * po[u].w;
+        dot = group_sum<F4R>(dot);
+        if (cs == 0) {
+          // per-row constants of the softmax backward, with everything that is constant along a row folded in once (one lane per row
+          // instead of one multiply per score): with s = 1/sqrt(dh), k = the dropout scale (1 / keep probability),
+          //   p_k = P * s * k = 2^((S - max) * c2) * (1/sum * s * k),   dS = P * (M * dPd - delta) * s = p_k * ((kept ? dPd : 0) - delta / k),
+          //   Pd = P * M = (kept ? p_k : 0) / s:  the dV accumulators are multiplied by 1/s once, in the epilogue
+          // (ONE address, immediate offsets, scalar constants: as three hoisted addresses + two constants in vector registers these five
+          // values were spilled and reloaded from scratch, one s_waitcnt vmcnt(0) each, in every query block)
+          float* st_ = lse_s + row;
+          st_[0] = pl[u].x;                              // the RAW row maximum the forward subtracted
+          st_[32] = dot * keep_inv_s;                    // delta_s
+          st_[64] = pl[u].y * sk_s;                      // inv_s
+        }
+      }
+    }
+    __syncthreads();   // (b)
+    if (qb + 1 < nqb) qload(qb + 1);
+
+    // ---- (c) S tile and (d) dP tile: rows = queries (registers), column = this lane's key ----
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { sacc[r] = 0.f; pacc[r] = 0.f; }
+    if (!XABL(g, 2))
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int off = lr * RSQ + 16 * s + 8 * lh;
+      const bf16x8 qh = lds_read_b128(Qf + off), ql = lds_read_b128(Qf + Q_PL + off);
+      // the forward's order of partial sums (it multiplied K as the A operand): K_lo.Q_hi, then K_hi.Q_lo, then K_hi.Q_hi
+      sacc = X3<EF>::mma(qh, kfl[s], sacc);
+      sacc = X3<EF>::mma(ql, kfh[s], sacc);
+      sacc = X3<EF>::mma(qh, kfh[s], sacc);
+      pacc = x3_mma<EB>(lds_read_b128(Ob + off), lds_read_b128(Ob + Q_PL + off), vfh[s], vfl[s], pacc);
+      __builtin_amdgcn_sched_barrier(0);              // one k-step's fragments at a time (all KS up front spill at KT = 8, dh = 64)
+    }
+    const bool key_ok = mykey < Lk;
+    const bool pad_wave = (wave * 32 + 32) > Lk;         // (wave-uniform) this wave's key tile has padding columns
+    // The 16 registers of a lane are 16 query rows: rows 8j + 4*lh + {0,1,2,3} for j = r >> 2 -> one 16-byte LDS read per statistic and j.
+    // On exit sacc = (kept ? p_k : 0) (the B operand of dV, scaled by s: see the staging above), pacc = dS * s (for dK, dQ).
+    {
+      constexpr bool DROP = DM != 0, PAIR = DM == 1;
+      const long row0 = sh * Lq + (long)qb * 32 + 4 * lh;                  // element row of register 0
+      const uint64_t ebase = (uint64_t)(row0 * (long)Lk + mykey);
+      // PAIR (quad form): lanes 4i .. 4i+3 hold the four keys of one hash quad and registers 4j .. 4j+3 four adjacent rows.  Lane 4i+a hashes
+      // the quad of row(4j + a); a DPP quad broadcast hands every lane each row's word, of which it takes its own key's byte.
+      const int sub = lane & 3;
+      const uint32_t fsh = 8u * (uint32_t)sub;
+      const uint64_t hk = hftt_hash_key(g.drop_seed, g.drop_site);
+      const uint32_t quarter = (uint32_t)(Lk >> 2);
+      const uint32_t qlo = (uint32_t)(row0 + sub) * quarter + (uint32_t)(mykey >> 2);
+#pragma unroll
+      for (int j4 = 0; j4 < 4; j4++) {
+        const float4 m4 = *reinterpret_cast<const float4*>(lse_s + 8 * j4 + 4 * lh);
+        const float4 i4 = *reinterpret_cast<const float4*>(inv_s + 8 * j4 + 4 * lh);
+        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 8 * j4 + 4 * lh);
+        const float rs_m[4] = {m4.x, m4.y, m4.z, m4.w}, rs_i[4] = {i4.x, i4.y, i4.z, i4.w}, rs_d[4] = {d4.x, d4.y, d4.z, d4.w};
+        uint32_t wq[4] = {0u, 0u, 0u, 0u};
+        if (DROP && PAIR) {
+          const uint32_t w = hftt_hash_mix(hk, qlo + (uint32_t)(8 * j4) * quarter, 0u);      // row(4*j4) - row(0) = 8*j4 rows
+          wq[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x00, 0xF, 0xF, true);
+          wq[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x55, 0xF, 0xF, true);
+          wq[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xAA, 0xF, 0xF, true);
+          wq[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xFF, 0xF, 0xF, true);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = 4 * j4 + e;
+          float p = __builtin_amdgcn_exp2f((sacc[r] - rs_m[e]) * c2) * rs_i[e];      // p_k
+          if (pad_wave && !key_ok) p = 0.f;
+          float pd = p, dp = pacc[r];
+          if (DROP) {
+            bool kept;
+            if (PAIR) kept = ((wq[e] >> fsh) & 0xFFu) < thr;
+            else kept = hftt_keep(g.drop_seed, g.drop_site, ebase + (uint64_t)((e + 8 * j4) * Lk), thr);
+            pd = kept ? p : 0.f;                                // one decision, two selects
+            dp = kept ? dp : 0.f;
+          }
+          sacc[r] = pd;
+          pacc[r] = p * (dp - rs_d[e]);
+        }
+      }
+    }
+    // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS ----
+    if (!XABL(g, 8))
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      __builtin_amdgcn_sched_barrier(0);
+      float pv[8], sv[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { pv[e] = sacc[8 * s2 + e]; sv[e] = pacc[8 * s2 + e]; }
+      bf16x8 ph, plo, shh, shl;
+      x3_split8<EB>(pv, ph, plo);
+      x3_split8<EB>(sv, shh, shl);
+      // ---- (g) dS -> LDS [query][key], bf16 pair, from the SAME packed halves (word w of shh / shl = registers 2rp, 2rp + 1, rp = 4*s2 + w:
+      // two query rows of this lane's key).  Lanes 2i / 2i+1 hold adjacent keys: one packed pair (ds_write_b32) per register pair ----
+      if (!XABL(g, 16)) {
+        const bool odd = lane & 1;
+        const uint4 hw = __builtin_bit_cast(uint4, shh), lw = __builtin_bit_cast(uint4, shl);
+        const unsigned hws[4] = {hw.x, hw.y, hw.z, hw.w}, lws[4] = {lw.x, lw.y, lw.z, lw.w};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const int rp = 4 * s2 + w;
+          const int o = acc_row32(2 * rp + (odd ? 1 : 0), lh) * RSS + wave * 32 + (lr & ~1);
+          *reinterpret_cast<unsigned*>(Sb + o) = packed_rows_to_cols(hws[w], odd);
+          *reinterpret_cast<unsigned*>(Sb + S_PL + o) = packed_rows_to_cols(lws[w], odd);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < NT; n++) {
+        const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
+        const int r0 = 16 * s2 + 4 * lh + qq;
+        const unsigned short* po_ = Ob + r0 * RSQ + col;
+        const bf16x8 oh = join4(lds_read_tr16(po_), lds_read_tr16(po_ + 8 * RSQ));
+        const bf16x8 ol = join4(lds_read_tr16(po_ + Q_PL), lds_read_tr16(po_ + Q_PL + 8 * RSQ));
+        dVT[n] = x3_mma<EB>(oh, ol, ph, plo, dVT[n]);
+        const unsigned short* pq_ = Qb + r0 * RSQ + col;
+        const bf16x8 qh = join4(lds_read_tr16(pq_), lds_read_tr16(pq_ + 8 * RSQ));
+        const bf16x8 ql = join4(lds_read_tr16(pq_ + Q_PL), lds_read_tr16(pq_ + Q_PL + 8 * RSQ));
+        dKT[n] = x3_mma<EB>(qh, ql, shh, shl, dKT[n]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();   // (h)
+
+    // ---- (i) dQ block = dS . K with 16x16 tiles spread over the waves ----
+    constexpr int CT = DH / 16;
+    for (int t = wave; t < 2 * CT && !XABL(g, 16); t += KT) {
+      const int qh2 = t / CT, ct = t % CT;
+      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int ks = 0; ks < KT; ks++) {
+        const unsigned short* ps = Sb + (qh2 * 16 + (lane & 15)) * RSS + ks * 32 + 8 * gi;
+        const bf16x8 ah = lds_read_b128(ps), al = lds_read_b128(ps + S_PL);
+        const int krow = ks * 32 + 8 * gi + qq;
+        const int kcol = ct * 16 + 4 * pp;
+        const unsigned short* pk = Kb + krow * RSK + kcol;
+        const bf16x8 bh = join4(lds_read_tr16(pk), lds_read_tr16(pk + 4 * RSK));
+        const bf16x8 bl = join4(lds_read_tr16(pk + K_PL), lds_read_tr16(pk + K_PL + 4 * RSK));
+        a4 = x3_mma16<EB>(ah, al, bh, bl, a4);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int q = qb * 32 + qh2 * 16 + gi * 4 + r;
+        if (q < Lq && !XABL(g, 32)) g.dq[dqofs + (long)q * g.lddq + ct * 16 + (lane & 15)] = a4[r];
+      }
+    }
+    // no barrier needed here: the next iteration's staging touches only Qf / Qb / Ob / statistics, which no wave reads in (i);
+    // barrier (b) of the next iteration orders (i) before the next (g).
+  }
+
+  // ---- epilogue: dK, dV (this wave's 32 keys) leave through LDS as whole row segments (DH fp32 = 128 / 256 bytes per key row) ----
+  constexpr int RSE = Cfg::RSE;
+  const float rscale = sqrtf((float)DH);                       // dV was accumulated from probabilities scaled by 1/sqrt(dh) (8: exact at dh = 64)
+  __syncthreads();                                             // every wave is done with the loop's LDS images
+  float* ek = reinterpret_cast<float*>(smem) + wave * (2 * 32 * RSE);
+  float* ev = ek + 32 * RSE;
+#pragma unroll
+  for (int n = 0; n < NT; n++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int dh0 = n * 32 + 8 * c + 4 * lh0;
+      *reinterpret_cast<float4*>(ek + lr0 * RSE + dh0) = make_float4(dKT[n][4 * c], dKT[n][4 * c + 1], dKT[n][4 * c + 2], dKT[n][4 * c + 3]);
+      *reinterpret_cast<float4*>(ev + lr0 * RSE + dh0) = make_float4(dVT[n][4 * c] * rscale, dVT[n][4 * c + 1] * rscale, dVT[n][4 * c + 2] * rscale, dVT[n][4 * c + 3] * rscale);
+    }
+  __syncthreads();
+  constexpr int CPR = DH / 4;                                  // 16-byte chunks per row
+  constexpr int RPP = 64 / CPR;                                // rows per pass of the wave
+  float* dkp = g.dk + (long)seq * g.dk_seq_stride + head * DH;
+  float* dvp = g.dv + (long)seq * g.dv_seq_stride + head * DH;
+#pragma unroll
+  for (int ps = 0; ps < 32 / RPP; ps++) {
+    const int row = ps * RPP + lane / CPR, ch = lane % CPR;
+    const int key = wave * 32 + row;
+    if (key < Lk) {
+      *reinterpret_cast<float4*>(dkp + (long)key * g.lddk + ch * 4) = *reinterpret_cast<const float4*>(ek + row * RSE + ch * 4);
+      *reinterpret_cast<float4*>(dvp + (long)key * g.lddv + ch * 4) = *reinterpret_cast<const float4*>(ev + row * RSE + ch * 4);
+    }
+  }
+}
+
+template <int KT, int DH, bool PL, int DM>
+int launch_xb(const hftt_attn_desc& d, hipStream_t st) {
+  using Cfg = XbCfg<KT, DH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3_attn_bwd_kernel<KT, DH, PL, DM>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) { hftt_set_error("x3_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((x3_attn_bwd_kernel<KT, DH, PL, DM>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, d);
+  HFTT_CHECK_LAUNCH("x3_attn_bwd");
+  return 0;
+}
+template <int KT, int DH, bool PL>
+int launch_xb3(const hftt_attn_desc& d, hipStream_t st) {
+  if (!(d.drop_p > 0.f)) return launch_xb<KT, DH, PL, 0>(d, st);
+  const bool quad_ok = (d.Lk & 3) == 0 && (((uint64_t)d.n_seq * (uint64_t)d.n_heads * (uint64_t)d.Lq * (uint64_t)d.Lk) >> 34) == 0;
+  return quad_ok ? launch_xb<KT, DH, PL, 1>(d, st) : launch_xb<KT, DH, PL, 2>(d, st);
+}
+template <int DH, bool PL>
+int dispatch_xb(const hftt_attn_desc& d, hipStream_t st) {
+  const int kt = (d.Lk + 31) / 32;
+  if (kt <= 1) return launch_xb3<1, DH, PL>(d, st);
+  if (kt <= 2) return launch_xb3<2, DH, PL>(d, st);
+  if (kt <= 3) return launch_xb3<3, DH, PL>(d, st);
+  if (kt <= 4) return launch_xb3<4, DH, PL>(d, st);
+  return launch_xb3<8, DH, PL>(d, st);
+}
+

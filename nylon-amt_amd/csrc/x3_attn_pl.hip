@@ -46,12 +46,18 @@ constexpr float LOG2E = 1.4426950408889634f;
 //     of the swizzle) the 64-byte half of the row -> 4 x 64 B on 64 different banks.
 __device__ __forceinline__ int pl_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 
+// LDS image of one tensor (K or V) of a (sequence, head): groups of FOUR rows, each group 1 KiB = [4 rows x 128 B of hi halves | 4 rows x 128 B
+// of lo halves].  One DMA piece fills one group, and its 64 lanes fetch whole 128-byte lines: the 16 lanes of a row take the row's two
+// 32-column groups, each 64 B of hi + 64 B of lo (hi-plane-only pieces fetched half lines and ran 10 % slower).
+__device__ __forceinline__ int pl_row_off(int row) { return (row >> 2) * 1024 + (row & 3) * 128; }
+constexpr int PL_LO = 512;                                    // lo halves of a row: 512 bytes behind its hi halves
+
 template <int KT>
 struct PfCfg {
   static constexpr int LKP = KT * 32;
-  static constexpr int PLANE = LKP * 128;                     // bytes of one plane image (rows of 64 fp16)
-  static constexpr int PIECES = 4 * KT;                       // 1-KiB DMA pieces per plane
-  static constexpr int LDS_BYTES = 4 * PLANE + 8 * 32 * 4;    // K hi | K lo | V hi | V lo | one 1/sum per query row and wave
+  static constexpr int IMG = LKP * 256;                       // bytes of one tensor's image (hi + lo)
+  static constexpr int PIECES = 8 * KT;                       // 1-KiB DMA pieces per tensor
+  static constexpr int LDS_BYTES = 2 * IMG + 8 * 32 * 4;      // K | V | one 1/sum per query row and wave
 };
 
 // one LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + 16 * lane (M0 carries the LDS base)
@@ -65,26 +71,25 @@ __device__ __forceinline__ void pl_glds16(const void* gsrc, unsigned lds_dst) {
       : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// both planes of one tensor (K or V) of one (sequence, head): 2 * PIECES pieces dealt over the NW waves (PER per wave, a static count: the
-// waits below count them).  base: row 0 of the sequence, this head's hi plane; rows past Lk re-fetch row Lk - 1 (finite values; their
-// scores are masked to -inf, their probabilities are exactly 0).
+// one tensor (K or V) of one (sequence, head): PIECES pieces dealt over the NW waves (PER per wave, a static count: the waits below count
+// them).  base: row 0 of the sequence, this head's first 32-column group; rows past Lk re-fetch row Lk - 1 (finite values; their scores are
+// masked to -inf, their probabilities are exactly 0).
 template <int KT, int NW>
 __device__ __forceinline__ void pl_dma_tensor(const unsigned char* base, long ld_bytes, int Lk, unsigned lds_base, int wave, int lane) {
-  constexpr int PIECES = PfCfg<KT>::PIECES, PLANE = PfCfg<KT>::PLANE;
-  constexpr int PER = 2 * PIECES / NW;
-  static_assert((2 * PIECES) % NW == 0, "pieces must divide over the waves");
-  // (opaque: left visible, LICM hoists every piece's LDS address and plane / piece number out of the item loop and parks them in scalar
+  constexpr int PIECES = PfCfg<KT>::PIECES;
+  constexpr int PER = PIECES / NW;
+  static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+  // (opaque: left visible, LICM hoists every piece's LDS address and piece number out of the item loop and parks them in scalar
   // registers for the whole kernel, and the per-piece lane offsets in 2 x PER vector registers -- both files spilled)
   asm volatile("" : "+s"(wave), "+v"(lane));
-  const int r8 = lane >> 3;
+  const int plane = lane >> 5, r4 = (lane >> 3) & 3;
 #pragma unroll
   for (int u = 0; u < PER; u++) {
-    const int idx = wave + NW * u;                              // wave-uniform
-    const int plane = idx >= PIECES ? 1 : 0, pc = idx - plane * PIECES;
-    const int row = 8 * pc + r8;
+    const int pc = wave + NW * u;                               // wave-uniform: rows 4*pc .. 4*pc + 3
+    const int row = 4 * pc + r4;
     const int rowc = row < Lk ? row : Lk - 1;
     const int c = (lane & 7) ^ pl_swz(row);                     // 16-byte chunk of the head's 64 halves: group c >> 2, piece c & 3
-    pl_glds16(base + (long)rowc * ld_bytes + plane * 64 + (c >> 2) * 128 + (c & 3) * 16, lds_base + (unsigned)(plane * PLANE + pc * 1024));
+    pl_glds16(base + (long)rowc * ld_bytes + (c >> 2) * 128 + plane * 64 + (c & 3) * 16, lds_base + (unsigned)(pc * 1024));
   }
 }
 
@@ -95,12 +100,12 @@ template <int KT, int NW, bool MAP, int DM>
 __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kernel(const hftt_attn_desc g, const int n_items) {
   using Cfg = PfCfg<KT>;
   constexpr int E = X3_F16, DH = 64, KS = 4, NT = 2;
-  constexpr int PLANE = Cfg::PLANE, LKP = Cfg::LKP;
-  constexpr int PER = 2 * Cfg::PIECES / NW;                    // DMA pieces per wave and tensor
+  constexpr int IMG = Cfg::IMG, LKP = Cfg::LKP;
+  constexpr int PER = Cfg::PIECES / NW;                        // DMA pieces per wave and tensor
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
-  const unsigned char* Kimg = smem;                            // hi plane, lo plane at + PLANE
-  const unsigned char* Vimg = smem + 2 * PLANE;
+  const unsigned char* Kimg = smem;
+  const unsigned char* Vimg = smem + IMG;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
   int item = blockIdx.x;
   bf16x8 qh[KS], ql[KS];
   pl_dma_tensor<KT, NW>(k_base(item), ldk_b, Lk, lds0, wave, lane);
-  pl_dma_tensor<KT, NW>(v_base(item), ldv_b, Lk, lds0 + 2 * PLANE, wave, lane);
+  pl_dma_tensor<KT, NW>(v_base(item), ldv_b, Lk, lds0 + IMG, wave, lane);
   q_load(item, qh, ql);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
     {
       const int lr_ = lane_s & 31, lh_ = lane_s >> 5;
 #pragma unroll
-      for (int s = 0; s < KS; s++) koff[s] = lr_ * 128 + (((2 * s + lh_) ^ pl_swz(lr_)) << 4);
+      for (int s = 0; s < KS; s++) koff[s] = pl_row_off(lr_) + (((2 * s + lh_) ^ pl_swz(lr_)) << 4);
     }
     // ---- S^T = K . Q^T  (rows = keys in registers, column = this lane's query) ----
     f32x16 sacc[KT];
@@ -167,8 +172,8 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
       for (int kt = 0; kt < KT; kt++)
 #pragma unroll
         for (int s = 0; s < KS; s++) {
-          const unsigned short* p = reinterpret_cast<const unsigned short*>(Kimg + kt * 4096 + koff[s]);
-          sacc[kt] = x3_mma<E>(lds_read_b128(p), lds_read_b128(p + PLANE / 2), qh[s], ql[s], sacc[kt]);
+          const unsigned short* p = reinterpret_cast<const unsigned short*>(Kimg + kt * 8192 + koff[s]);
+          sacc[kt] = x3_mma<E>(lds_read_b128(p), lds_read_b128(p + PL_LO / 2), qh[s], ql[s], sacc[kt]);
         }
     }
     __syncthreads();                                           // every wave is done with the K image
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
 #pragma unroll
         for (int sec = 0; sec < 2; sec++) {
           const int row = 4 * lh_ + qq_ + 8 * sec;
-          voff[n][sec] = row * 128 + (((4 * n + 2 * (gi_ & 1) + (pp_ >> 1)) ^ pl_swz(row)) << 4) + (pp_ & 1) * 8;
+          voff[n][sec] = pl_row_off(row) + (((4 * n + 2 * (gi_ & 1) + (pp_ >> 1)) ^ pl_swz(row)) << 4) + (pp_ & 1) * 8;
         }
     }
     const long sh = (long)seq * H + head;
@@ -263,11 +268,11 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
               x3_split8_nc<E>(pt + 8 * s2, ph, pl);                // probabilities: 0 .. 1, no saturation step
 #pragma unroll
               for (int n = 0; n < NT; n++) {
-                const unsigned char* vb = Vimg + (kt * 32 + 16 * s2) * 128;
+                const unsigned char* vb = Vimg + (kt * 32 + 16 * s2) * 256;
                 const unsigned short* p0 = reinterpret_cast<const unsigned short*>(vb + voff[n][0]);
                 const unsigned short* p1 = reinterpret_cast<const unsigned short*>(vb + voff[n][1]);
                 const bf16x8 vh = join4(lds_read_tr16(p0), lds_read_tr16(p1));
-                const bf16x8 vl = join4(lds_read_tr16(p0 + PLANE / 2), lds_read_tr16(p1 + PLANE / 2));
+                const bf16x8 vl = join4(lds_read_tr16(p0 + PL_LO / 2), lds_read_tr16(p1 + PL_LO / 2));
                 oacc[n] = x3_mma<E>(ph, pl, vh, vl, oacc[n]);
               }
             }
@@ -332,11 +337,11 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
             x3_split8<E>(pv, ph, pl);
 #pragma unroll
             for (int n = 0; n < NT; n++) {
-              const unsigned char* vb = Vimg + (kt * 32 + 16 * s2) * 128;
+              const unsigned char* vb = Vimg + (kt * 32 + 16 * s2) * 256;
               const unsigned short* p0 = reinterpret_cast<const unsigned short*>(vb + voff[n][0]);
               const unsigned short* p1 = reinterpret_cast<const unsigned short*>(vb + voff[n][1]);
               const bf16x8 vh = join4(lds_read_tr16(p0), lds_read_tr16(p1));
-              const bf16x8 vl = join4(lds_read_tr16(p0 + PLANE / 2), lds_read_tr16(p1 + PLANE / 2));
+              const bf16x8 vl = join4(lds_read_tr16(p0 + PL_LO / 2), lds_read_tr16(p1 + PL_LO / 2));
               oacc[n] = x3_mma<E>(ph, pl, vh, vl, oacc[n]);
             }
           }
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
     for (int s = 0; s < KS; s++) asm volatile("" : "+v"(qnh[s]), "+v"(qnl[s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!PABL(g, 4)) pl_dma_tensor<KT, NW>(v_base(nxt), ldv_b, Lk, lds0 + 2 * PLANE, wave, lane);
+    if (!PABL(g, 4)) pl_dma_tensor<KT, NW>(v_base(nxt), ldv_b, Lk, lds0 + IMG, wave, lane);
 
     // ---- epilogue of this item: row statistics and the output rows ----
     if (active && !PABL(g, 8)) {
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
       const long oofs = (long)seq * g.o_seq_stride + head * DH;
       if (!MAP) {
         // the output tile has the QUERY on its register index (row acc_row32(r, lh)): 1/sum of those rows comes through 128 bytes of LDS
-        float* invs = reinterpret_cast<float*>(smem + 4 * PLANE) + wave * 32;
+        float* invs = reinterpret_cast<float*>(smem + 2 * IMG) + wave * 32;
         if (lh == 0) invs[lr] = inv * inv_keep;                   // (the kept probabilities entered P.V unscaled)
 #pragma unroll
         for (int j4 = 0; j4 < 4; j4++) {
@@ -452,7 +457,17 @@ __global__ __launch_bounds__(256) void x3_to_planes_kernel(const float* __restri
   }
 }
 
+#include "x3_attn_bwd.h"
+
 }  // namespace
+
+int hftt_x3p_attn_bwd(const hftt_attn_desc& d, hipStream_t st) {
+  const unsigned both = HFTT_ATTN_Q_F16PAIR | HFTT_ATTN_KV_F16PAIR;
+  HFTT_REQUIRE((d.io_flags & both) == both && d.dh == 64, "attn_bwd: f16-pair planes need both flags and dh == 64");
+  HFTT_REQUIRE(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.q_seq_stride % 4 == 0 && d.k_seq_stride % 4 == 0 && d.v_seq_stride % 4 == 0,
+               "attn_bwd: f16-pair planes must be 16-byte aligned");
+  return dispatch_xb<64, true>(d, st);
+}
 
 // -1: not this kernel's case (x3_attn.hip handles fp32 operands); otherwise the launch status.  Called by hftt_x3_attn_fwd.
 int hftt_x3p_attn_fwd_try(const hftt_attn_desc& d0, hipStream_t st) {

@@ -5,6 +5,7 @@
 #include "../../include/hftt_hip.h"
 int hftt_x3_attn_fwd(const hftt_attn_desc& d, hipStream_t st);      // x3_attn.hip
 int hftt_x3_attn_bwd(const hftt_attn_desc& d, hipStream_t st);
+int hftt_x3p_attn_bwd(const hftt_attn_desc& d, hipStream_t st);          // x3_attn_pl.hip: the backward on f16-pair planes
 int hftt_x3p_attn_fwd_try(const hftt_attn_desc& d, hipStream_t st);      // x3_attn_pl.hip: -1 when the operands are not f16-pair planes
 int hftt_x3_strip_linear(const hftt_strip_desc& d, hipStream_t st);  // x3_strip.hip
 int hftt_x3_strip_mlp(const hftt_ffn_desc& d, hipStream_t st);
