@@ -259,17 +259,29 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     f32x16 sacc, pacc;
 #pragma unroll
     for (int r = 0; r < 16; r++) { sacc[r] = 0.f; pacc[r] = 0.f; }
-    if (!XABL(g, 2))
+    if (!XABL(g, 2)) {
+      // the fragments of k-step s + 1 are requested before the six MFMAs of step s (one step ahead: with both waves of a SIMD in this phase
+      // together nobody else covers the LDS round trip; all KS steps up front spill at KT = 8, dh = 64)
+      const int off0 = lr * RSQ + 8 * lh;
+      bf16x8 fq[2], fo[2];
+      fq[0] = lds_read_b128(Qf + off0); fq[1] = lds_read_b128(Qf + Q_PL + off0);
+      fo[0] = lds_read_b128(Ob + off0); fo[1] = lds_read_b128(Ob + Q_PL + off0);
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-      const int off = lr * RSQ + 16 * s + 8 * lh;
-      const bf16x8 qh = lds_read_b128(Qf + off), ql = lds_read_b128(Qf + Q_PL + off);
-      // the forward's order of partial sums (it multiplied K as the A operand): K_lo.Q_hi, then K_hi.Q_lo, then K_hi.Q_hi
-      sacc = X3<EF>::mma(qh, kfl[s], sacc);
-      sacc = X3<EF>::mma(ql, kfh[s], sacc);
-      sacc = X3<EF>::mma(qh, kfh[s], sacc);
-      pacc = x3_mma<EB>(lds_read_b128(Ob + off), lds_read_b128(Ob + Q_PL + off), vfh[s], vfl[s], pacc);
-      __builtin_amdgcn_sched_barrier(0);              // one k-step's fragments at a time (all KS up front spill at KT = 8, dh = 64)
+      for (int s = 0; s < KS; s++) {
+        bf16x8 nq[2], no[2];
+        if (s + 1 < KS) {
+          const int off = off0 + 16 * (s + 1);
+          nq[0] = lds_read_b128(Qf + off); nq[1] = lds_read_b128(Qf + Q_PL + off);
+          no[0] = lds_read_b128(Ob + off); no[1] = lds_read_b128(Ob + Q_PL + off);
+        }
+        // the forward's order of partial sums (it multiplied K as the A operand): K_lo.Q_hi, then K_hi.Q_lo, then K_hi.Q_hi
+        sacc = X3<EF>::mma(fq[0], kfl[s], sacc);
+        sacc = X3<EF>::mma(fq[1], kfh[s], sacc);
+        sacc = X3<EF>::mma(fq[0], kfh[s], sacc);
+        pacc = x3_mma<EB>(fo[0], fo[1], vfh[s], vfl[s], pacc);
+        if (s + 1 < KS) { fq[0] = nq[0]; fq[1] = nq[1]; fo[0] = no[0]; fo[1] = no[1]; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     const bool key_ok = mykey < Lk;
     const bool pad_wave = (wave * 32 + 32) > Lk;         // (wave-uniform) this wave's key tile has padding columns
