@@ -402,6 +402,18 @@ def main():
         ts.engine.profiler = None
         sync()
 
+    overlap = None
+    if grad_sync is not None and dev.type == 'cuda':
+        # two more steps with an event behind every bucket's all-reduce and one at the end of the backward: did the early buckets (time
+        # decoder, frequency decoder) finish under the encoder's backward, as the design says?  (every rank runs them: they all-reduce)
+        grad_sync.timing = True
+        for i in range(2):
+            x, lab = batch(i)
+            ts(x, *lab)
+        sync()
+        overlap = grad_sync.overlap_report()
+        grad_sync.timing = False
+
     result = None
     if rank == 0:
         value = B * world * args.steps / dt
@@ -547,6 +559,9 @@ def main():
             result['hbm_bytes_per_step'] = step_bytes
             result['hbm_frac_of_peak'] = step_bytes / (dt / args.steps) / (PEAK_HBM_GBS * 1e9)
             result['hbm_bytes_source'] = step_src
+        if collective is not None and overlap is not None:
+            collective['buckets'] = overlap
+            collective['early_buckets_hidden'] = all(b['ms_before_backward_end'] > 0.0 for b in overlap[:-1])
         result.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(cfg, config_name=args.config)

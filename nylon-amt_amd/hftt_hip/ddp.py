@@ -53,11 +53,16 @@ class FlatGradSync:
         self.slices = [(i, min(n, i + step)) for i in range(0, n, step)]
         self.scale = 1.0 / world
         self.launched = []                     # flat ranges already reduced (or in flight) for the current step
+        # timing=True: an event behind every bucket's all-reduce (side stream) and one at the end of the backward (compute stream), so a
+        # caller can check that the early buckets really finish under the rest of the backward (overlap_report; bench.py, the rehearsal test)
+        self.timing = False
+        self._bucket_events, self._bwd_end_event, self._last_report = [], None, None
 
     def begin_step(self):
         """called before every backward: ranges reported by a backward that was never followed by __call__ (gradient accumulation,
         an exception) must not be mistaken for this step's"""
         self.launched = []
+        self._bucket_events, self._bwd_end_event = [], None
 
     def bucket_ready(self, lo, hi):
         """flat_grads[lo:hi] is final on the current stream: start its all-reduce now."""
@@ -70,12 +75,28 @@ class FlatGradSync:
             self.stream.wait_stream(torch.cuda.current_stream(g.device))
             with torch.cuda.stream(self.stream):
                 _all_reduce_sum(g[lo:hi])
+                if self.timing:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(self.stream)
+                    self._bucket_events.append(((lo, hi), ev))
         self.launched.append((lo, hi))
+
+    def overlap_report(self):
+        """after a step with timing=True (and a device synchronize): per bucket, in the order the backward released them, the milliseconds
+        by which its all-reduce finished BEFORE the end of the backward (negative: it was still running -- exposed)"""
+        if self._bwd_end_event is None or not self._bucket_events:
+            return self._last_report
+        rep = [{'range': [int(lo), int(hi)], 'ms_before_backward_end': float(ev.elapsed_time(self._bwd_end_event))} for (lo, hi), ev in self._bucket_events]
+        self._last_report = rep
+        return rep
 
     def __call__(self, flat_grads):
         if self.launched:                      # overlapped mode: every range was handed over by bucket_ready
             done, self.launched = sorted(self.launched), []
             if self.cuda:                           # join the side stream first: also on the error paths below
+                if self.timing:                      # the last backward kernel has been enqueued on the compute stream: mark its end
+                    self._bwd_end_event = torch.cuda.Event(enable_timing=True)
+                    self._bwd_end_event.record(torch.cuda.current_stream(flat_grads.device))
                 torch.cuda.current_stream(flat_grads.device).wait_stream(self.stream)
             pos = 0
             for lo, hi in done:

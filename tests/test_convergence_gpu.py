@@ -64,6 +64,7 @@ def train_device(cfg, precision, dropout, data, held, dev, B, lr):
     n = spec.shape[0]
     curve = []
     acc = 0.0
+    f1s = []
     for s in range(STEPS):
         idx = [(s * B + i) % n for i in range(B)]
         loss = ts(spec[idx].to(dev), *[t[idx].to(dev).contiguous() for t in labels])
@@ -71,10 +72,19 @@ def train_device(cfg, precision, dropout, data, held, dev, B, lr):
         if (s + 1) % EVERY == 0:
             curve.append(acc / EVERY); acc = 0.0
             print('  %s step %d loss %.4f' % (precision, s + 1, curve[-1]), flush=True)
-    model.eval()
-    with torch.no_grad():
-        out = model(held[0].to(dev))
-    return curve, frame_f1(out[7].cpu(), held[1][2]), frame_f1(out[2].cpu(), held[1][2]), model
+            if s + 1 > STEPS - 3 * EVERY:             # held-out frame-F1 at the last three checkpoints (the dropout counter only moves in training mode)
+                model.eval()
+                with torch.no_grad():
+                    out = model(held[0].to(dev))
+                f1s.append((frame_f1(out[7].cpu(), held[1][2]), frame_f1(out[2].cpu(), held[1][2])))
+                model.train()
+    # The thresholded decisions of ONE instant of a 1,500-step trajectory are noisy at this size: over three initialisations the final
+    # F1_B of one and the same mode moved between 0.55 and 0.70, and a last-bit change of the arithmetic (q / k / v handed over as fp16
+    # pairs instead of fp32: gradients equal to 4e-5) moved a seed's final value from 0.58 to 0.36 while its loss stayed within 2 %.
+    # The median over the last three checkpoints is what the comparisons below use.
+    med = lambda v: sorted(v)[len(v) // 2]
+    print('  %s held-out F1 (B, A) at the last checkpoints: %s' % (precision, [(round(a, 3), round(b, 3)) for a, b in f1s]), flush=True)
+    return curve, med([a for a, _ in f1s]), med([b for _, b in f1s]), model
 
 
 def train_oracle(cfg, data, held, B, lr):
@@ -85,7 +95,7 @@ def train_oracle(cfg, data, held, B, lr):
     opt = torch.optim.Adam(list(sd.values()), lr=lr)
     spec, labels = data
     n = spec.shape[0]
-    curve, acc = [], 0.0
+    curve, acc, f1s = [], 0.0, []
     for s in range(STEPS):
         idx = [(s * B + i) % n for i in range(B)]
         opt.zero_grad()
@@ -96,9 +106,12 @@ def train_oracle(cfg, data, held, B, lr):
         if (s + 1) % EVERY == 0:
             curve.append(acc / EVERY); acc = 0.0
             print('  oracle step %d loss %.4f' % (s + 1, curve[-1]), flush=True)
-    with torch.no_grad():
-        out = O.model_forward(sd, held[0], cfg)
-    return curve, frame_f1(out[7], held[1][2]), frame_f1(out[2], held[1][2])
+            if s + 1 > STEPS - 3 * EVERY:
+                with torch.no_grad():
+                    out = O.model_forward(sd, held[0], cfg)
+                f1s.append((frame_f1(out[7], held[1][2]), frame_f1(out[2], held[1][2])))
+    med = lambda v: sorted(v)[len(v) // 2]
+    return curve, med([a for a, _ in f1s]), med([b for _, b in f1s])
 
 
 @pytest.mark.parametrize('dropout', [0.0, 0.1])

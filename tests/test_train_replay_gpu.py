@@ -393,4 +393,31 @@ def test_one_rank_rccl_rehearsal_of_the_bench_ddp_branch(dev):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['value'] > 0 and line['n_gpus'] == 1
-    assert line['collective'] == {'backend': 'nccl', 'ranks': 1, 'devices': line['collective']['devices']} and len(line['collective']['devices']) == 1
+    col = line['collective']
+    assert col['backend'] == 'nccl' and col['ranks'] == 1 and len(col['devices']) == 1
+    # the three gradient buckets in release order (time decoder + heads B, frequency decoder + heads A, encoder): the all-reduces of the
+    # first two were enqueued on the side stream while the backward still had the encoder to go, and finished before its last kernel
+    assert len(col['buckets']) == 3 and col['buckets'][0]['range'][0] > col['buckets'][1]['range'][0] > col['buckets'][2]['range'][0] == 0
+    assert col['buckets'][0]['ms_before_backward_end'] > 0.0 and col['buckets'][1]['ms_before_backward_end'] > 0.0, col['buckets']
+    assert col['early_buckets_hidden'] is True
+
+
+def test_two_rank_bench_on_one_gpu(dev):
+    """bench.py under torch.distributed.run with TWO ranks sharing this box's GPU (HFTT_BENCH_SHARE_GPU=1: gloo collectives, both ranks on
+    cuda:0): the launch contract of the driver's N > 1 runs -- RANK / LOCAL_RANK / WORLD_SIZE from the environment, the barrier + max-over-
+    ranks timing, one JSON line from rank 0 with the all-gathered device list -- fails here for a reason instead of on the 8-GPU node."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HFTT_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = str(41000 + (os.getpid() % 2000))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', port,
+                        os.path.join(util.ROOT, 'bench.py'), '--gpus', '2', '--config', 'tiny', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-extras', '--no-profile'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines                      # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['config']['global_batch'] == 16 and line['config']['parallelism'] == 'dp2'
+    assert line['collective']['ranks'] == 2 and sorted(d['rank'] for d in line['collective']['devices']) == [0, 1]

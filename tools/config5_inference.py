@@ -16,23 +16,11 @@ from model.amt import AMT
 from evaluation.metrics import note_metrics, frame_metrics
 
 precision = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+from corpus import synth_audio as SA
 sr, dur, hop = 16000, 60.0, 256
-rng = np.random.RandomState(1234)
-notes, t = [], 0.25
-while t < dur - 2.0:
-    notes.append({'pitch': int(rng.randint(40, 89)), 'onset': t, 'offset': t + float(rng.uniform(0.3, 1.2)), 'velocity': int(rng.randint(40, 110))})
-    t += float(rng.uniform(0.08, 0.35))
-tt = torch.arange(int(sr * dur), dtype=torch.float32) / sr
-wave = torch.zeros_like(tt)
-for n in notes:                                     # decaying harmonic pluck
-    f0 = 440.0 * 2.0 ** ((n['pitch'] - 69) / 12.0)
-    env = torch.exp(-3.0 * (tt - n['onset']).clamp(min=0)) * ((tt >= n['onset']) & (tt < n['offset'] + 0.3))
-    for h, a in ((1, 1.0), (2, 0.5), (3, 0.25)):
-        if f0 * h < sr / 2:
-            wave += (n['velocity'] / 127.0) * 0.1 * a * torch.sin(2 * np.pi * f0 * h * tt) * env
-config = json.loads('{"feature": {"sr": 16000, "hop_sample": 256, "mel_bins": 256, "n_bins": 256, "fft_bins": 2048, "window_length": 2048,'
-                    ' "log_offset": 1e-8, "window": "hann", "pad_mode": "constant"}, "input": {"margin_b": 32, "margin_f": 32, "num_frame": 128,'
-                    ' "min_value": -18.420681}, "midi": {"note_min": 21, "note_max": 108, "num_note": 88, "num_velocity": 128}}')
+notes = SA.pluck_notes(1234, dur)                   # the seed-1234 note list (corpus/synth_audio.py)
+wave = SA.pluck_wave(notes, dur, sr)
+config = SA.default_config()
 model = bench.build_model(bench.CONFIGS['paper'], 1234, 0.1, 'cpu')
 model.hftt_precision = precision
 tmp = tempfile.mkdtemp()
