@@ -173,6 +173,11 @@ int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_p
 /* split modes, LayerNorm forms (hftt_strip_linear with ln_gamma, hftt_ffn_res_ln_fwd): pre_ln_out is bf16 [M, 256] -- it is read only by
  * hftt_ln_bwd (HFTT_LNB_R_BF16), as xhat = (r - mean) * rstd against the fp32 statistics. */
 #define HFTT_SL_PRE_BF16 128u
+/* Small widths (split modes): K, N <= 192, multiples of 32, with K x N in {64x64, 64x128, 64x192, 128x64, 192x64} (LayerNorm form: 64x64) and
+ * the fused block at d == 64, p == 128 -- the reference's default model (training/m_training.py:56-61).  `w` is then an
+ * hftt_x3_strip_pack stream of order 2 ("compact": the (hi, lo) pair of (k chunk c, output tile t) at pair index slot_offset + c * NT + t with
+ * NT = slot_stride = N / 32, 2 KB per pair; fused block: first matrix at pairs 0 .. 15, second at 16 .. 31): the whole matrix sits in LDS for the
+ * launch (csrc/x3s_strip.h). */
 /* HFTT_SL_X3_F16 without LayerNorm, K == 256 (the output-tile-major kernel): C is written as f16-pair planes per 32-column group (see
  * HFTT_ATTN_Q_F16PAIR) -- the q / k / v projections of the attention layers (model_spec2midi.py:328-330) */
 #define HFTT_SL_C_F16PAIR 512u

@@ -635,7 +635,8 @@ extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
     HFTT_REQUIRE((((uintptr_t)d->x | (uintptr_t)d->C | (uintptr_t)d->w | (uintptr_t)d->residual | (uintptr_t)d->pre_ln_out) & 15) == 0, "strip_linear: operands must be 16-byte aligned");
     HFTT_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && d->res_mod >= 0, "strip_linear: drop_p / res_mod out of range");
     HFTT_REQUIRE((long)d->M * d->N < (1L << 33), "strip_linear: M*N too large for the 32-bit dropout pair index");
-    HFTT_REQUIRE(d->ln_gamma == nullptr || (d->N == 256 && d->ln_beta != nullptr && d->ldc == 256 && !(d->flags & HFTT_SL_RELU)), "strip_linear: LayerNorm needs N == 256 == ldc, beta, no ReLU");
+    HFTT_REQUIRE(d->ln_gamma == nullptr || ((d->N == 256 || d->N == 64) && d->ln_beta != nullptr && d->ldc == d->N && !(d->flags & HFTT_SL_RELU)),
+                 "strip_linear: LayerNorm needs N == ldc == 256 (or 64: the small-width family), beta, no ReLU");
     return hftt_x3_strip_linear(*d, reinterpret_cast<hipStream_t>(stream));
   }
   HFTT_REQUIRE(d->M > 0 && d->N >= 256 && d->N % 256 == 0 && d->N <= 2048, "strip_linear: N=%d must be a multiple of 256", d->N);
@@ -681,7 +682,7 @@ extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
 
 int check_ffn_x3(const hftt_ffn_desc* d, int mode, const char* what) {
   HFTT_REQUIRE(d->mode == mode, "%s: descriptor mode %d", what, d->mode);
-  HFTT_REQUIRE(d->M > 0 && d->d == 256, "%s: needs d == 256 (got M=%d d=%d)", what, d->M, d->d);
+  HFTT_REQUIRE(d->M > 0 && (d->d == 256 || (d->d == 64 && d->p == 128)), "%s: needs d == 256, or d == 64 with p == 128 (got M=%d d=%d p=%d)", what, d->M, d->d, d->p);
   HFTT_REQUIRE((long)d->M * d->p < (1L << 33), "%s: M*p too large for the 32-bit dropout pair index", what);
   HFTT_REQUIRE(d->x != nullptr && d->w != nullptr && d->y != nullptr, "%s: null operand", what);
   HFTT_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && (d->h_out == nullptr || d->ldh % 4 == 0) && (d->residual == nullptr || d->ldr % 4 == 0) && (d->gate == nullptr || d->ldg % 4 == 0),
@@ -695,7 +696,7 @@ int check_ffn_x3(const hftt_ffn_desc* d, int mode, const char* what) {
 extern "C" int hftt_ffn_res_ln_fwd(const hftt_ffn_desc* d, void* stream) {
   if (d != nullptr && (d->flags & (HFTT_SL_X3_F16 | HFTT_SL_X3_BF16))) {
     if (int rc = check_ffn_x3(d, 0, "ffn_res_ln_fwd")) return rc;
-    HFTT_REQUIRE(d->ln_gamma != nullptr && d->ln_beta != nullptr && d->ldy == 256, "ffn_res_ln_fwd: needs gamma, beta and ldy == 256");
+    HFTT_REQUIRE(d->ln_gamma != nullptr && d->ln_beta != nullptr && d->ldy == d->d, "ffn_res_ln_fwd: needs gamma, beta and ldy == d");
     return hftt_x3_strip_mlp(*d, reinterpret_cast<hipStream_t>(stream));
   }
   if (int rc = check_ffn(d, 0, "ffn_res_ln_fwd")) return rc;

@@ -42,6 +42,7 @@ __host__ __device__ inline int x3_i_of_c(int c) { const int g = c & 15, hh = c >
 // Slots of 16 fragments.  order 0 ("linear"): slot = (tile >> 3) * (K / 16) + chunk, fragment = 2 * (tile & 7) + plane;
 // order 1 ("tile-major", K == 256): slot = 2 * tile + (chunk >> 3), fragment = 2 * (chunk & 7) + plane.
 // Stream position of a slot: slot_offset + slot_stride * (slot >> 1) + (slot & 1)   (slots come in pairs; the fused FFN interleaves pairs).
+// order 2 ("compact", small widths: x3s_strip.h): no slots -- the (hi, lo) pair of (chunk, tile) at pair index slot_offset + chunk * NT + tile.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int E>
 __global__ __launch_bounds__(256) void x3_strip_pack_kernel(const float* __restrict__ params, unsigned short* __restrict__ dst,
@@ -68,11 +69,16 @@ __global__ __launch_bounds__(256) void x3_strip_pack_kernel(const float* __restr
     // feature k of the logical row sits at chunk 2*pt + u with pt = k >> 5, lane half hk = (k >> 4) & 1, u = (k >> 3) & 1
     const int pt = k >> 5, hk2 = (k >> 4) & 1, u = (k >> 3) & 1;
     const int ch = 2 * pt + u;
-    long slot, frag;
-    if (e.order == 0) { slot = (long)(tile >> 3) * (e.K >> 4) + ch; frag = 2 * (tile & 7); }
-    else { slot = 2 * tile + (ch >> 3); frag = 2 * (ch & 7); }
-    const long pos = e.slot_offset + (long)e.slot_stride * (slot >> 1) + (slot & 1);
-    const long off = (pos * 16 + frag) * 512 + (hk2 * 32 + i) * 8;
+    long off;
+    if (e.order == 2) {                                 // compact (x3s_strip.h): pair (chunk, tile) at slot_offset + chunk * NT + tile, NT = slot_stride
+      off = (e.slot_offset + (long)ch * e.slot_stride + tile) * 1024 + (hk2 * 32 + i) * 8;
+    } else {
+      long slot, frag;
+      if (e.order == 0) { slot = (long)(tile >> 3) * (e.K >> 4) + ch; frag = 2 * (tile & 7); }
+      else { slot = 2 * tile + (ch >> 3); frag = 2 * (ch & 7); }
+      const long pos = e.slot_offset + (long)e.slot_stride * (slot >> 1) + (slot & 1);
+      off = (pos * 16 + frag) * 512 + (hk2 * 32 + i) * 8;
+    }
     bf16x8 hi, lo;
     x3_split8<E>(v, hi, lo);
     *reinterpret_cast<bf16x8*>(dst + e.dst_off + off) = hi;
@@ -812,6 +818,8 @@ int launch_xm(const hftt_ffn_desc& d, hipStream_t st) {
   return 0;
 }
 
+#include "x3s_strip.h"
+
 template <int E>
 int dispatch_xl(const hftt_strip_desc& d, hipStream_t st) {
   const int passes = d.N / 256, kch = d.K / 256;
@@ -850,6 +858,14 @@ static int x3_debug() { static const int v = [] { const char* e = getenv("HFTT_X
 int hftt_x3_strip_linear(const hftt_strip_desc& d0, hipStream_t st) {
   hftt_strip_desc d = d0;
   d.pad = x3_debug();
+  if (d.K <= 192 && d.N <= 192) {                     // the small-width family (weights resident in LDS, compact pack): x3s_strip.h
+    HFTT_REQUIRE(d.K % 32 == 0 && d.N % 32 == 0 && d.M % 32 == 0 && d.K > 0 && d.N > 0, "x3s_strip_linear: needs K %% 32 == 0, N %% 32 == 0, M %% 32 == 0 (M=%d N=%d K=%d)", d.M, d.N, d.K);
+    HFTT_REQUIRE(d.gate == nullptr && !(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16 | HFTT_SL_X3_GRAD_HI | HFTT_SL_C_F16PAIR)),
+                 "x3s_strip_linear: fp32 tensors, no gate / gradient-rounding / plane forms");
+    HFTT_REQUIRE(d.ldx % 4 == 0 && d.ldc % 4 == 0 && (d.residual == nullptr || d.ldr % 4 == 0), "x3s_strip_linear: rows must be 16-byte aligned");
+    HFTT_REQUIRE(((uintptr_t)d.w & 15) == 0, "x3s_strip_linear: the weight stream must be 16-byte aligned");
+    return (d.flags & HFTT_SL_X3_BF16) ? dispatch_xs<X3_BF16>(d, st) : dispatch_xs<X3_F16>(d, st);
+  }
   HFTT_REQUIRE(d.K % 256 == 0 && d.N % 256 == 0 && d.M % 32 == 0, "x3_strip_linear: needs K %% 256 == 0, N %% 256 == 0, M %% 32 == 0 (M=%d N=%d K=%d)", d.M, d.N, d.K);
   HFTT_REQUIRE(d.gate == nullptr, "x3_strip_linear: no gate form (the fused block hftt_ffn_bwd_dx carries the gate)");
   HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_linear: tensors are fp32 in the split modes");
@@ -867,6 +883,18 @@ int hftt_x3_strip_linear(const hftt_strip_desc& d0, hipStream_t st) {
 int hftt_x3_strip_mlp(const hftt_ffn_desc& d0, hipStream_t st) {
   hftt_ffn_desc d = d0;
   d.pad = x3_debug();
+  if (d.d == 64 && d.p == 128) {                      // the reference's default width: x3s_strip.h
+    HFTT_REQUIRE(d.M % 32 == 0, "x3s_strip_mlp: needs M %% 32 == 0 (M=%d)", d.M);
+    HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16 | HFTT_SL_X3_GRAD_HI)), "x3s_strip_mlp: fp32 tensors, no gradient-rounding form");
+    HFTT_REQUIRE(d.mode == 1 || d.residual == nullptr, "x3s_strip_mlp: the forward block's residual is its input");
+    HFTT_REQUIRE(((d.flags & HFTT_SL_X3_BF16) != 0) == (d.mode == 1), "x3s_strip_mlp: mode 0 takes fp16 halves (HFTT_SL_X3_F16), mode 1 bf16 halves");
+    HFTT_REQUIRE(d.ldx % 4 == 0 && d.ldy % 4 == 0 && ((uintptr_t)d.w & 15) == 0, "x3s_strip_mlp: rows / weight stream must be 16-byte aligned");
+    if (d.flags & HFTT_SL_H_BF16) {
+      HFTT_REQUIRE((d.h_out == nullptr || d.ldh % 8 == 0) && (d.gate == nullptr || d.ldg % 8 == 0), "x3s_strip_mlp: bf16 hidden rows must be 16-byte aligned");
+      return d.mode == 0 ? launch_xsm<0, true>(d, st) : launch_xsm<1, true>(d, st);
+    }
+    return d.mode == 0 ? launch_xsm<0, false>(d, st) : launch_xsm<1, false>(d, st);
+  }
   HFTT_REQUIRE(d.p == 512 && d.M % 32 == 0, "x3_strip_mlp: needs p == 512 and M %% 32 == 0 (M=%d p=%d)", d.M, d.p);
   HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_mlp: tensors are fp32 in the split modes");
   HFTT_REQUIRE(d.mode == 1 || d.residual == nullptr, "x3_strip_mlp: the forward block's residual is its input");

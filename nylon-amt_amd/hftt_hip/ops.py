@@ -160,6 +160,33 @@ def x3_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
     return out
 
 
+def x3s_pack(w: torch.Tensor, elem=2, transpose=False, nt=None, out=None, pair_offset=0):
+    """fp32 [rows, cols] -> COMPACT split-operand pack (order 2) of the logical matrix Wl = w (or w.T) for the small-width strip kernels
+    (csrc/x3s_strip.h): the (hi, lo) pair of (k chunk c, output tile t) at pair index pair_offset + c * nt + t, 1024 int16 elements per pair."""
+    _need_cuda(w)
+    w = w.contiguous().float()
+    rows, cols = w.shape
+    K, N = (rows, cols) if transpose else (cols, rows)
+    nt = nt or N // 32
+    if out is None:
+        out = torch.zeros((pair_offset + (K // 16) * nt) * 1024, dtype=torch.int16, device=w.device)
+    table, n = strip_pack_table([(0, 0, rows, cols, cols, 1 if transpose else 0, 0, 0, K, 2, nt, pair_offset)], w.device)
+    check(lib().hftt_x3_strip_pack(w.data_ptr(), out.data_ptr(), table.data_ptr(), n, elem, _stream(w.device)), 'x3_strip_pack')
+    return out
+
+
+def x3s_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
+    """the fused block's two matrices at d = 64, p = 128: pairs 0 .. 15 the first GEMM's, 16 .. 31 the second's"""
+    out = torch.zeros(32 * 1024, dtype=torch.int16, device=w1.device)
+    if not backward:
+        x3s_pack(w1, 2, False, 4, out, 0)        # fc_1.weight [p, d]
+        x3s_pack(w2, 2, False, 2, out, 16)       # fc_2.weight [d, p]
+    else:
+        x3s_pack(w2, 4, True, 4, out, 0)         # fc_2.weight^T [p, d]
+        x3s_pack(w1, 4, True, 2, out, 16)        # fc_1.weight^T [d, p]
+    return out
+
+
 def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, drop_seed=0,
                  residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0, pre_bf16=False, grad_hi=False, c_planes=False):
     """C = epi(x @ Wl.T + bias) with Wl given as its strip pack.  ln = (gamma, beta) -> (C, pre_ln, mean, rstd).

@@ -455,3 +455,89 @@ def test_fused_ffn_forward_and_dx(dev, M, hbf):
     dh_r = torch.where(hid.cpu().double() > 0, (dy.bfloat16().double() @ W2.double()) * 1.25, torch.zeros((), dtype=torch.float64))
     assert rel_err(dh2.float(), dh_r) < (4e-3 if hbf else 6e-5)
     assert rel_err(dx2, dh_r.float().bfloat16().double() @ W1.double() + res.double()) < 1.5e-3      # (dh is rounded from the device's fp32 value, not from this fp64 one: ties fall either way)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the small-width family (csrc/x3s_strip.h): the reference's default model, d = 64 / ff = 128 (training/m_training.py:56-61)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('elem', [2, 4])
+@pytest.mark.parametrize('M,N,K', [(384, 64, 64), (1056, 192, 64), (640, 128, 64), (416, 64, 128), (992, 64, 192), (100000, 192, 64), (33024, 64, 192)])
+def test_small_strip_linear(dev, M, N, K, elem):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    wp = ops.x3s_pack(W.to(dev), elem)
+    ref = x.double() @ W.double().T + b.double()
+    if K == 64:
+        out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), x3=elem)
+        assert rel_err(out, ref) < TOL[elem]
+    if N == 64:
+        out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), relu=True, out_scale=0.5, residual=res.to(dev), x3=elem)
+        assert rel_err(out, torch.relu(ref) * 0.5 + res.double()) < TOL[elem]
+        p, site, seed = 0.1, 3, 4242
+        mask = keep_mask_t(seed, site, (M, N), p).double()
+        out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res[:7].contiguous().to(dev), res_mod=7, x3=elem)
+        assert rel_err(out, ref * mask * keep_scale(p) + res.double()[torch.arange(M) % 7]) < TOL[elem]
+    # a transposed pack (the dX kernels): Wl = W^T
+    if elem == 4 and K == 64:
+        dy = torch.randn(M, N, generator=g) * 1e-5
+        wt = ops.x3s_pack(W.to(dev), 4, transpose=True)            # logical [K, N]: maps [M, N] -> [M, K]
+        if N in (64, 128, 192) and K == 64:
+            out = ops.strip_linear(dy.to(dev), wt, K, None, x3=4)
+            assert rel_err(out, dy.double() @ W.double()) < TOL[4]
+
+
+@pytest.mark.parametrize('elem', [2, 4])
+def test_small_strip_linear_layernorm(dev, elem):
+    ops = _ops()
+    M, N, K = 1120, 64, 64
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) * 3.0; gam = torch.randn(N, generator=g); bet = torch.randn(N, generator=g)
+    p, site, seed = 0.1, 11, 99
+    mask = keep_mask_t(seed, site, (M, N), p).double()
+    wp = ops.x3s_pack(W.to(dev), elem)
+    out, pre, mean, rstd = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res.to(dev),
+                                            ln=(gam.to(dev), bet.to(dev)), x3=elem)
+    r = (x.double() @ W.double().T + b.double()) * mask * keep_scale(p) + res.double()
+    assert rel_err(pre, r) < TOL[elem]
+    assert rel_err(out, F.layer_norm(r, (N,), gam.double(), bet.double(), 1e-5)) < 1e-4
+    assert rel_err(mean, r.mean(1)) < 1e-4
+    assert rel_err(rstd, 1.0 / torch.sqrt(r.var(1, unbiased=False) + 1e-5)) < 1e-4
+    out3, pre3, mean3, rstd3 = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res.to(dev),
+                                                ln=(gam.to(dev), bet.to(dev)), x3=elem, pre_bf16=True)
+    assert pre3.dtype == torch.bfloat16 and rel_err(pre3.float(), r) < 4e-3
+    assert max_err(out3, out) == 0.0 and max_err(mean3, mean) == 0.0 and max_err(rstd3, rstd) == 0.0
+
+
+@pytest.mark.parametrize('hbf', [False, True])
+@pytest.mark.parametrize('M', [256, 4096 + 96, 90112])
+def test_small_fused_ffn_forward_and_dx(dev, M, hbf):
+    ops = _ops()
+    d, pf = 64, 128
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, d, generator=g); W1 = torch.randn(pf, d, generator=g) / 8.0; W2 = torch.randn(d, pf, generator=g) / 11.0
+    b1 = torch.randn(pf, generator=g) * 0.3; b2 = torch.randn(d, generator=g) * 0.3; gam = torch.randn(d, generator=g); bet = torch.randn(d, generator=g)
+    p, sh, so, seed = 0.1, 21, 22, 777
+    wf = ops.x3s_ffn_pack(W1.to(dev), W2.to(dev))
+    y, hid, pre, mean, rstd = ops.ffn_res_ln_fwd(x.to(dev), wf, pf, b1.to(dev), b2.to(dev), gam.to(dev), bet.to(dev), drop_p=p, site_h=sh, site_o=so, seed=seed, x3=True,
+                                                 hidden_bf16=hbf, pre_bf16=hbf)
+    h = torch.relu(x.double() @ W1.double().T + b1.double()) * keep_mask_t(seed, sh, (M, pf), p).double() * keep_scale(p)
+    o = (h @ W2.double().T + b2.double()) * keep_mask_t(seed, so, (M, d), p).double() * keep_scale(p)
+    r = x.double() + o
+    assert hid.dtype == (torch.bfloat16 if hbf else torch.float32)
+    assert rel_err(hid.float(), h) < (4e-3 if hbf else 4e-6)
+    assert rel_err(pre.float(), r) < (4e-3 if hbf else 4e-6)
+    assert rel_err(y, F.layer_norm(r, (d,), gam.double(), bet.double(), 1e-5)) < 1e-4
+    assert rel_err(mean, r.mean(1)) < 1e-4
+    y2 = ops.ffn_res_ln_fwd(x.to(dev), wf, pf, b1.to(dev), b2.to(dev), gam.to(dev), bet.to(dev), drop_p=p, site_h=sh, site_o=so, seed=seed,
+                            save_hidden=False, save_pre=False, x3=True)[0]
+    assert max_err(y2, y) == 0.0
+    dy = torch.randn(M, d, generator=g) * 1e-5; res = torch.randn(M, d, generator=g) * 1e-5
+    wb = ops.x3s_ffn_pack(W1.to(dev), W2.to(dev), backward=True)
+    dx, dh = ops.ffn_bwd_dx(dy.to(dev), wb, pf, hid, gate_scale=1.25, residual=res.to(dev), x3=True)
+    dh_ref = torch.where(hid.cpu().double() > 0, (dy.double() @ W2.double()) * 1.25, torch.zeros((), dtype=torch.float64))
+    assert dh.dtype == hid.dtype
+    assert rel_err(dh.float(), dh_ref) < (4e-3 if hbf else 6e-5)
+    assert rel_err(dx, dh_ref @ W1.double() + res.double()) < 6e-5
