@@ -118,6 +118,10 @@ class HfttEngine:
         # strip kernels (csrc/strip_gemm.hip): bf16 mode at the paper's width.  Then the WHOLE activation stream between kernels is
         # bf16 (residual stream, pre-LayerNorm sums, hidden), fp32 lives only inside a kernel (accumulators, LayerNorm statistics).
         self.strip = getattr(self, 'strip_opt', True) and self.d == 256 and ((self.sb and self.p % 64 == 0) or (self.npass == 2 and self.p == 512))
+        # the reference's default width (training/m_training.py:56-61: d = 64, ff = 128) in the x3 mode: the same launch sequence on the
+        # small-width strip family (csrc/x3s_strip.h: every weight matrix of a launch resident in LDS, compact packs)
+        self.strip_small = getattr(self, 'strip_opt', True) and self.npass == 2 and self.d == 64 and self.p == 128
+        self.strip = self.strip or self.strip_small
         # bfs: the bf16 activation / gradient STREAM of the bf16 strip plans.  The x3 strip plans run the same launch sequence on fp32 tensors.
         self.bfs = self.strip and self.sb
         self.x3 = self.npass == 2
@@ -130,7 +134,7 @@ class HfttEngine:
         # instead of three: +3.5 % (260 against 251 clips/s on one box), every gradient tensor's cosine against the exact-fp32 mode still
         # >= 0.9999 at paper size, but the gradients move from 2e-4 to 3e-3 .. 6e-3 of the fp32 reference's (relative to the tensor's maximum) --
         # outside the 1e-3 the default mode keeps for gradients too, hence opt-in.
-        self.g8 = self.x3 and os.environ.get('HFTT_X3_GRAD_HI', '0') == '1'
+        self.g8 = self.x3 and os.environ.get('HFTT_X3_GRAD_HI', '0') == '1' and not self.strip_small
         self._prepared_frozen = False
         if getattr(self, '_bound', None) is not None:
             self._build_prep()
@@ -267,7 +271,41 @@ class HfttEngine:
                 (sentries_t if (x3 and transpose) else sentries).append((self.poff[name], base, rows, cols, cols, 1 if transpose else 0, n0, k0, Ktot, order, stride, offset))
             return base
 
+        def spack_s(key, parts, Ktot, Ntot, transpose=False, pair_offset=0, base=None, total_pairs=None):
+            """compact pack of the small-width family (order 2): the (hi, lo) pair of (k chunk c, tile t) at pair index pair_offset + c * NT + t,
+            1024 int16 elements per pair"""
+            if base is None:
+                base = sl.add(key, (total_pairs or (Ktot // 16) * (Ntot // 32)) * 1024, 512)
+                W['s.' + key] = base
+            for name, n0, k0 in parts:
+                rows, cols = self.pshape[name]
+                (sentries_t if transpose else sentries).append((self.poff[name], base, rows, cols, cols, 1 if transpose else 0, n0, k0, Ktot, 2, Ntot // 32, pair_offset))
+            return base
+
+        def strip_attn_s(pre, key, cross):
+            wq, wk, wv, wo = (pre + n + '.weight' for n in ('fc_q', 'fc_k', 'fc_v', 'fc_o'))
+            if cross:
+                spack_s(key + '.q', [(wq, 0, 0)], d, d)
+                spack_s(key + '.kv', [(wk, 0, 0), (wv, d, 0)], d, 2 * d)
+                spack_s(key + '.q_t', [(wq, 0, 0)], d, d, transpose=True)
+                spack_s(key + '.kv_t', [(wk, 0, 0), (wv, 0, d)], 2 * d, d, transpose=True)
+            else:
+                spack_s(key + '.qkv', [(wq, 0, 0), (wk, d, 0), (wv, 2 * d, 0)], d, 3 * d)
+                spack_s(key + '.qkv_t', [(wq, 0, 0), (wk, 0, d), (wv, 0, 2 * d)], 3 * d, d, transpose=True)
+            spack_s(key + '.o', [(wo, 0, 0)], d, d)
+            spack_s(key + '.o_t', [(wo, 0, 0)], d, d, transpose=True)
+
+        def strip_ffn_s(pre, key):
+            w1, w2 = pre + 'fc_1.weight', pre + 'fc_2.weight'          # [p, d], [d, p]
+            n1, n2 = (d // 16) * (p // 32), (p // 16) * (d // 32)
+            base = spack_s(key + '.ffn', [(w1, 0, 0)], d, p, total_pairs=n1 + n2)
+            spack_s(key + '.ffn', [(w2, 0, 0)], p, d, pair_offset=n1, base=base)
+            base = spack_s(key + '.ffn_t', [(w2, 0, 0)], d, p, transpose=True, total_pairs=n1 + n2)       # fc_2.weight^T [p, d]
+            spack_s(key + '.ffn_t', [(w1, 0, 0)], p, d, transpose=True, pair_offset=n1, base=base)       # fc_1.weight^T [d, p]
+
         def strip_attn(pre, key, cross):
+            if self.strip_small:
+                return strip_attn_s(pre, key, cross)
             wq, wk, wv, wo = (pre + n + '.weight' for n in ('fc_q', 'fc_k', 'fc_v', 'fc_o'))
             tm = 1 if x3 else 0                       # x3: the K == 256 linears without LayerNorm take the tile-major pack (csrc/x3_strip.hip)
             if cross:
@@ -282,6 +320,8 @@ class HfttEngine:
             spack(key + '.o_t', [(wo, 0, 0)], d, transpose=True, order=tm, numel=d * d)
 
         def strip_ffn(pre, key):
+            if self.strip_small:
+                return strip_ffn_s(pre, key)
             w1, w2 = pre + 'fc_1.weight', pre + 'fc_2.weight'          # [p, d], [d, p]
             base = spack(key + '.ffn', [(w1, 0, 0)], d, order=1, stride=2, offset=0, numel=2 * d * p)
             spack(key + '.ffn', [(w2, 0, 0)], p, order=0, stride=2, offset=1, base=base)
@@ -541,7 +581,9 @@ class HfttEngine:
               and ((ln is not None and kch <= 3) or (ln is None and (kch, passes) in ((1, 1), (1, 2), (1, 3), (2, 1), (3, 1)))))
         kname = ('strip_linear2_kernel<%s, %d, %d, %s>' % (tf(ln is not None), 1 if ln is not None else passes, kch, tf(bool(residual)))) if v2 \
             else 'strip_linear_kernel<%s, %s, %s>' % (tf(x_bf), tf(c_bf), tf(ln is not None))
-        if self.x3:
+        if self.x3 and self.strip_small:
+            kname = 'x3s_linear_kernel<%d, %d, %d, %s, %s>' % (4 if self._in_backward else 2, K // 32, N // 32, tf(ln is not None), tf(bool(residual)))
+        elif self.x3:
             xe = (5 if self.g8 else 4) if self._in_backward else 2
             kname = 'x3_linear_kernel<%d, %s, %d, %d, %s>' % (xe, tf(ln is not None), passes, kch, tf(bool(residual)))
             if ln is None and kch == 1:
@@ -578,7 +620,9 @@ class HfttEngine:
         hsz = 2.0 if (self.hh or not self.x3) else 4.0
         nbytes = esz * M * d * (2 + (1 if residual else 0)) + (hsz * M * d if pre_saved else 0) + (hsz * M * p if h_out else 0) + (hsz * M * p if gate else 0) + 2 * esz * d * p
         v2 = os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and p == 512 and M % 32 == 0 and not (mode == 0 and residual)
-        meta = {'kernel': (('x3_mlp_kernel<%%d, 16, %s, %s>' % ('true' if self.hh else 'false', 'true' if (mode == 1 and self.g8) else 'false')) if self.x3 else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>')) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
+        xname = ('x3s_mlp_kernel<%%d, %s>' % ('true' if self.hh else 'false')) if self.strip_small else \
+            ('x3_mlp_kernel<%%d, 16, %s, %s>' % ('true' if self.hh else 'false', 'true' if (mode == 1 and self.g8) else 'false'))
+        meta = {'kernel': (xname if self.x3 else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>')) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
                 'shape': (M, d, p), 'saves': bool(h_out or pre_saved)}
         plan.append((self.lib.hftt_ffn_res_ln_fwd if mode == 0 else self.lib.hftt_ffn_bwd_dx, (C.byref(dsc),), 'ffn_fwd' if mode == 0 else 'ffn_bwd_dx', meta))
         return dsc

@@ -159,6 +159,8 @@ def test_golden_fixture(dev, name, precision):
 _OTHER = dict(n_margin=4, n_frame=16, n_bin=32, cnn_channel=4, cnn_kernel=5, n_note=8, n_velocity=16)
 OTHER_CONFIGS = {'d256_ff1024': O.HfttConfig(hid_dim=256, pf_dim=1024, enc_layer=1, dec_layer=2, enc_head=4, dec_head=4, **_OTHER),      # x3: block GEMMs at the strip width
                  'd128_ff256': O.HfttConfig(hid_dim=128, pf_dim=256, enc_layer=2, dec_layer=1, enc_head=4, dec_head=2, **_OTHER),
+                 # the reference's default width (m_training.py:56-61): x3 runs it on the small-width strip family (csrc/x3s_strip.h)
+                 'd64_ff128': O.HfttConfig(hid_dim=64, pf_dim=128, enc_layer=2, dec_layer=2, enc_head=2, dec_head=2, **_OTHER),
                  'd256_ff512': O.HfttConfig(hid_dim=256, pf_dim=512, enc_layer=1, dec_layer=1, enc_head=4, dec_head=4, **_OTHER),        # strip plans, odd batch
                  # 15 frames x 8 notes x batch 3 = 360 note tokens: not a multiple of the strip kernels' 32 -> this workspace falls back to the block plans
                  'd256_ff512_t15': O.HfttConfig(hid_dim=256, pf_dim=512, enc_layer=1, dec_layer=2, enc_head=4, dec_head=4, **dict(_OTHER, n_frame=15))}
@@ -189,6 +191,8 @@ def test_other_configurations_forward_and_gradients(dev, name, precision):
     print(name, precision, 'strip' if eng._ws[B]['strip'] else 'block', json.dumps({k: float('%.2g' % v) for k, v in rep.items()}))
     for n, e in rep.items():
         assert e < TOL_OUT, (n, e)
+    if name == 'd64_ff128' and precision == 'x3':
+        assert eng.strip_small and eng._ws[B]['strip'] and any('x3s_mlp_kernel' in (m or {}).get('kernel', '') for _, _, _, m in eng._ws[B]['fwd'])
     if name == 'd256_ff512_t15':
         assert eng._ws[B]['strip'] is False and (eng.strip or precision != 'x3')      # x3: strip engine, block plans for this token count
     assert abs(loss[0].item() - ref_loss) < 1e-4 * abs(ref_loss)
