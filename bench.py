@@ -220,6 +220,59 @@ def pmc_busy(kernel_key, kind='bench'):
     return None
 
 
+_LIVE_PMC = None        # set by measure_pmc(): {'kernels': {symbol: bytes per launch}, 'bytes_per_step': ..., 'source': ...} of THIS run
+
+
+def measure_pmc(args, timeout_s=170):
+    """HBM traffic of this very command, measured now: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE:
+    separate passes, FETCH_SIZE doubled for gfx950 -- MI355X_MICROARCH.md) over 1 warm-up + 2 timed steps with no instrumentation of its own.
+    Returns None when rocprofv3 is missing or a pass fails (the line then quotes the newest committed profile and says so)."""
+    import collections, csv, glob, re, shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix='hftt_pmc_', dir='/tmp')
+    child = [sys.executable if os.path.basename(sys.executable).startswith('python') else 'python3', os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--batch', str(args.batch),
+             '--config', args.config, '--precision', args.precision, '--dropout', str(args.dropout), '--data', args.data,
+             '--no-cpu-baseline', '--no-profile', '--no-extras', '--no-pmc']
+    env = dict(os.environ, TMPDIR='/tmp')
+    env.pop('RANK', None); env.pop('WORLD_SIZE', None); env.pop('LOCAL_RANK', None)
+
+    def key_of(n):
+        m = re.search(r'::([a-z_0-9]+(?:<[^>]*>)?)\(', n)
+        return m.group(1) if m else n
+
+    per = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([exe, '--kernel-trace', '--pmc', counter, '-d', out, '-o', 'b', '--output-format', 'csv', '--'] + child,
+                               cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, '**', 'b_counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            acc = collections.defaultdict(lambda: [0.0, 0])
+            for row in csv.DictReader(open(files[0])):
+                if row['Counter_Name'] != counter:
+                    continue
+                n = row['Kernel_Name']
+                k = key_of(n) if ('namespace)::' in n and 'at::' not in n) else '(other) ' + n[:60]
+                acc[k][0] += float(row['Counter_Value']) * 1024.0 * (2.0 if counter == 'FETCH_SIZE' else 1.0)      # counter values are KB
+                acc[k][1] += 1
+            per[counter] = acc
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    kernels, total = {}, 0.0
+    for k in set(per['FETCH_SIZE']) | set(per['WRITE_SIZE']):
+        f, w = per['FETCH_SIZE'].get(k, [0.0, 0]), per['WRITE_SIZE'].get(k, [0.0, 0])
+        n = max(f[1], w[1], 1)
+        kernels[k] = (f[0] + w[0]) / n
+        total += f[0] + w[0]
+    return {'kernels': kernels, 'bytes_per_step': total / 3.0, 'source': 'this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of the same command (1 + 2 steps)'}
+
+
 def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench', mfma_passes=1):
     """roofline object of one kernel symbol from the profiling pass: ALGORITHMIC flops / bytes of its launches (engine plan meta, DESIGN.md
     section 5) over the measured launch durations; the bound is the side of the ridge its arithmetic intensity falls on."""
@@ -234,6 +287,8 @@ def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench', mfma_passes=
     # (PMC figures are per-launch averages over ALL launches of the kernel symbol in the profiled command: `kind` picks the training step's
     # files or the inference plan's)
     traffic, src = pmc_traffic_bytes(key, kind)
+    if kind == 'bench' and _LIVE_PMC is not None and key in _LIVE_PMC['kernels']:
+        traffic, src = _LIVE_PMC['kernels'][key], _LIVE_PMC['source']
     # two unambiguous fractions of the dense bf16 MFMA peak, whatever `bound` says: the ALGORITHMIC one (one multiply-add per product of the
     # reference's arithmetic -- what north_star's ">= 40 % on the FFN GEMMs" is priced in) and the matrix pipe's own (the split-operand mode
     # executes `mfma_passes` bf16-rate passes per product, so the pipe is mfma_passes x as busy as the algorithmic figure says)
@@ -279,6 +334,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-launch HIP-event pass (roofline objects become null)')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference / parity-mode / compatibility-path legs')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes (HBM traffic of this run; N = 1 only)')
     args = ap.parse_args()
 
     import gc
@@ -413,6 +469,10 @@ def main():
         sync()
         overlap = grad_sync.overlap_report()
         grad_sync.timing = False
+
+    if rank == 0 and world == 1 and not force_ddp and not args.no_pmc and not args.no_profile:
+        global _LIVE_PMC
+        _LIVE_PMC = measure_pmc(args)
 
     result = None
     if rank == 0:
@@ -554,6 +614,8 @@ def main():
             'collective': collective,
         }
         step_bytes, step_src = pmc_step_bytes()
+        if _LIVE_PMC is not None:
+            step_bytes, step_src = _LIVE_PMC['bytes_per_step'], _LIVE_PMC['source']
         if step_bytes is not None:
             # whole-step HBM traffic (PMC sum over every kernel of a profiled run of this same command) over THIS run's step time
             result['hbm_bytes_per_step'] = step_bytes

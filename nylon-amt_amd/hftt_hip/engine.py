@@ -653,7 +653,7 @@ class HfttEngine:
         return dsc
 
     def _attn(self, plan, ws, bwd, n_seq, H, Lq, Lk, q, qss, ldq, k, kss, ldk, v, vss, ldv, out, oss, ldo, lse, probs=0,
-              drop_site=0, dout=0, dq=0, dqss=0, lddq=0, dk=0, dkss=0, lddk=0, dv=0, dvss=0, lddv=0, flags=0, planes=False):
+              drop_site=0, dout=0, dq=0, dqss=0, lddq=0, dk=0, dkss=0, lddk=0, dv=0, dvss=0, lddv=0, flags=0, planes=False, map_out=False):
         flags = (flags if self.sb else 0) | ((ATTN_Q_F16PAIR | ATTN_KV_F16PAIR) if planes else 0)
         dsc = AttnDesc()
         dsc.io_flags = flags
@@ -674,25 +674,27 @@ class HfttEngine:
         dh = self.d // H
         kt = (Lk + 31) // 32
         kt = kt if kt <= 4 else 8
+        # dropout form of the x3 kernels (a template parameter, chosen by the C side from drop_p and the shape): 0 none, 1 per key quad, 2 per element
+        dm = 0 if (not (drop_site and self.dropout > 0.0) or getattr(self, '_building_inference', False)) else (1 if (Lk % 4 == 0 and (n_seq * H * Lq * Lk) >> 34 == 0) else 2)
         eq = 2.0 if flags & 1 else 4.0
         ekv = 2.0 if flags & 2 else 4.0
         eo = 2.0 if flags & 4 else 4.0
         qkv_bytes = n_seq * (eq * Lq + 2 * ekv * Lk) * self.d
         if bwd:
             hb = 'true' if (flags & 7) == 7 else 'false'
-            meta = {'kernel': ('x3_attn_bwd_kernel<%d, %d, %s>' % (kt, dh, 'true' if planes else 'false')) if self.npass == 2 else 'attn_bwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
+            meta = {'kernel': ('x3_attn_bwd_kernel<%d, %d, %s, %d>' % (kt, dh, 'true' if planes else 'false', dm)) if self.npass == 2 else 'attn_bwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb), 'flops': 10.0 * n_seq * H * Lq * Lk * dh,
                     'bytes': qkv_bytes + n_seq * ((2.0 if flags & 8 else 4.0) * Lq + 2 * (2.0 if flags & 16 else 4.0) * Lk) * self.d + 2 * eo * n_seq * Lq * self.d
                     + 8.0 * n_seq * H * Lq, 'shape': (n_seq, H, Lq, Lk, dh)}
         else:
             hb = 'true' if (flags & 7) == 7 else 'false'
             long_rows = (hb == 'true' and dh == 64 and self.npass == 1 and 128 < Lk <= 256 and 128 < Lq <= 256 and not probs
                          and os.environ.get('HFTT_ATTN_FWD8', '1')[:1] != '0')                   # csrc/attn_fwd8.hip: hftt_attn_fwd8_try
-            x3name = ('x3p_attn_fwd_kernel<%d, %d, %s>' % (kt, 8 if (kt == 8 and Lq > 128) else 4, 'true' if probs else 'false')) if planes else \
-                ('x3_attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, 8 if kt == 8 else 4, 'true' if probs else 'false'))
+            x3name = ('x3p_attn_fwd_kernel<%d, %d, %s, %d>' % (kt, 8 if (kt == 8 and Lq > 128) else 4, 'true' if (probs or map_out) else 'false', dm)) if planes else \
+                ('x3_attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, 8 if kt == 8 else 4, 'true' if (probs or map_out) else 'false'))
             meta = {'kernel': 'attn_fwd8_kernel' if long_rows else (x3name if self.npass == 2 else
                                                                      'attn_fwd_kernel<%d, %d, %d, %s>' % (kt, dh, self.npass, hb)), 'flops': 4.0 * n_seq * H * Lq * Lk * dh,
                     # q, k, v, out + the row statistics (max, 1/sum) + the attention map where it is a model output (fp32, mandatory)
-                    'bytes': qkv_bytes + eo * n_seq * Lq * self.d + 8.0 * n_seq * H * Lq + (4.0 * n_seq * H * Lq * Lk if probs else 0.0),
+                    'bytes': qkv_bytes + eo * n_seq * Lq * self.d + 8.0 * n_seq * H * Lq + (4.0 * n_seq * H * Lq * Lk if (probs or map_out) else 0.0),
                     'shape': (n_seq, H, Lq, Lk, dh)}
         plan.append((self.lib.hftt_attn_bwd if bwd else self.lib.hftt_attn_fwd, (C.byref(dsc),), 'attn_bwd' if bwd else 'attn_fwd', meta))
         return dsc
@@ -745,7 +747,11 @@ class HfttEngine:
             if self.strip:                           # inference plan: same buffers, nothing saved for a backward
                 n_sites = self._site
                 self._site = 0
-                self._build_forward(ws, save=False)
+                self._building_inference = True        # (kernel symbols of the plan meta: the eval forward runs without dropout)
+                try:
+                    self._build_forward(ws, save=False)
+                finally:
+                    self._building_inference = False
                 assert self._site == n_sites
             self._in_backward = True
             try:
@@ -915,7 +921,7 @@ class HfttEngine:
                 self._nt(plan, ws, Se, 2 * d, d, enc, d, self.Wp(tag + '.ca.kv'), self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d, c_bf=True)
             kk = ckv.data_ptr()
             ad = self._attn(plan, ws, False, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
-                            cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a, flags=1 | 2 | 4, planes=plc)
+                            cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a, flags=1 | 2 | 4, planes=plc, map_out=(j == self.Ld - 1))
             if j == self.Ld - 1:
                 ws.setdefault('attn_out_descs', []).append(ad)
             if st:

@@ -7,6 +7,7 @@ with fp32 accumulate: posteriors 2.5e-2, velocity logits 1.8e-1, attention 6.8e-
 stream, which is what this build's bf16 mode stores): 2.8e-2 / 2.0e-1 / 6.8e-3.  Those were one seed; the budgets below are the
 autocast row with 1.4x headroom for other seeds / inputs, and every test prints what it measured."""
 import json
+import os
 import pickle
 
 import numpy as np
@@ -212,53 +213,48 @@ def test_x3_mode_paper_b8_against_fp32_mfma_mode(dev):
 
 
 def test_config5_paper_size_inference(dev, tmp_path):
-    """BASELINE config 5 on one GPU: 60 s synthetic plucked-string audio -> HIP log-mel -> 30 paper-size clips through AMT.transcript
-    in the benchmarked bf16 mode: deterministic, within budget of the parity mode on the same features, decodes to a MIDI file."""
+    """BASELINE config 5 on one GPU: 60 s synthetic plucked-string audio (corpus/synth_audio.py, seed 1234) -> HIP log-mel -> 30 paper-size
+    clips through AMT.transcript in the DEFAULT, benchmarked mode (x3): deterministic, every posterior within north_star's 1e-3 of the exact-fp32
+    mode on the same features and the same frame decisions; the bf16 throughput mode inside its own (wider) band; decodes to a MIDI file."""
     from model.amt import AMT
+    from corpus import synth_audio as SA
     cfg = O.PAPER
     model = util.build_model(cfg, 1234)
     util.perturb(model, 1235)
     f = tmp_path / 'model.pkl'
     with open(f, 'wb') as fh:
         pickle.dump(model, fh, protocol=4)
-    config = json.loads('{"feature": {"sr": 16000, "hop_sample": 256, "mel_bins": 256, "n_bins": 256, "fft_bins": 2048, "window_length": 2048,'
-                        ' "log_offset": 1e-8, "window": "hann", "pad_mode": "constant"}, "input": {"margin_b": 32, "margin_f": 32, "num_frame": 128,'
-                        ' "min_value": -18.420681}, "midi": {"note_min": 21, "note_max": 108, "num_note": 88, "num_velocity": 128}}')
-    amt = AMT(config, str(f), batch_size=32)
-    sr, dur = 16000, 60.0
-    rng = np.random.RandomState(1234)
-    tt = torch.arange(int(sr * dur), dtype=torch.float32) / sr
-    wave = torch.zeros_like(tt)
-    t = 0.25
-    while t < dur - 2.0:
-        pitch, length, vel = int(rng.randint(40, 89)), float(rng.uniform(0.3, 1.2)), int(rng.randint(40, 110))
-        f0 = 440.0 * 2.0 ** ((pitch - 69) / 12.0)
-        lo, hi = int(t * sr), min(len(tt), int((t + length + 0.3) * sr))
-        seg = tt[lo:hi] - t
-        wave[lo:hi] += (vel / 127.0) * 0.1 * torch.exp(-3.0 * seg) * (torch.sin(2 * np.pi * f0 * seg) + 0.5 * torch.sin(4 * np.pi * f0 * seg))
-        t += float(rng.uniform(0.08, 0.35))
-    feat = amt.wave2feature(wave.unsqueeze(0), sr)
+    amt = AMT(SA.default_config(), str(f), batch_size=32)
+    notes = SA.pluck_notes(1234)
+    feat = amt.wave2feature(SA.pluck_wave(notes).unsqueeze(0), SA.SR)
     assert feat.shape == (3751, 256)
-    amt.model.hftt_precision = 'bf16'
-    outs = amt.transcript(feat.numpy())
-    again = amt.transcript(feat.numpy())
-    for a, b in zip(outs, again):
-        assert a.shape == (3840, 88) and np.array_equal(a, b)          # 30 clips, bit-deterministic
+    names = ['onset_A', 'offset_A', 'mpe_A', 'velocity_A', 'onset_B', 'offset_B', 'mpe_B', 'velocity_B']
     amt.model.hftt_precision = 'parity'
     ref = amt.transcript(feat.numpy())
-    rep = {}
-    names = ['onset_A', 'offset_A', 'mpe_A', 'velocity_A', 'onset_B', 'offset_B', 'mpe_B', 'velocity_B']
-    for k, (a, b) in enumerate(zip(outs, ref)):
+    res = {}
+    for mode in ('x3', 'bf16'):
+        amt.model.hftt_precision = mode
+        outs = amt.transcript(feat.numpy())
+        again = amt.transcript(feat.numpy())
+        for a, b in zip(outs, again):
+            assert a.shape == (3840, 88) and np.array_equal(a, b)          # 30 clips, bit-deterministic
+        rep = {}
+        for k, (a, b) in enumerate(zip(outs, ref)):
+            if k % 4 == 3:
+                rep[names[k] + '.argmax_differs'] = float((a != b).mean())
+            else:
+                rep[names[k]] = float(np.abs(a - b).max())
+                rep[names[k] + '.mean'] = float(np.abs(a - b).mean())
+                rep[names[k] + '.decisions_differ'] = int(((a >= 0.5) != (b >= 0.5)).sum())
+        res[mode] = (outs, rep)
+        print('config 5, paper size, %s vs parity mode:' % mode, json.dumps(rep))
+    outs, rep = res['x3']
+    for k, nm in enumerate(names):
         if k % 4 == 3:
-            rep[names[k] + '.argmax_differs'] = float((a != b).mean())
+            assert rep[nm + '.argmax_differs'] < 2e-3, nm          # velocity argmax: near-ties between adjacent classes only
         else:
-            rep[names[k]] = float(np.abs(a - b).max())
-            rep[names[k] + '.mean'] = float(np.abs(a - b).mean())
-    notes = amt.mpe2note(a_onset=outs[4], a_offset=outs[5], a_mpe=outs[6], a_velocity=outs[7])
-    mid = tmp_path / 'out.mid'
-    amt.note2midi(notes, str(mid))
-    assert mid.read_bytes()[:4] == b'MThd'
-    print('config 5, paper size, bf16 vs parity mode:', json.dumps(rep), 'notes decoded:', len(notes))
+            assert rep[nm] <= 1e-3 and rep[nm + '.decisions_differ'] == 0, (nm, rep[nm])        # north_star: 1e-3 on the posteriors
+    _, rep = res['bf16']
     for k, nm in enumerate(names):
         if k % 4 == 3:
             assert rep[nm + '.argmax_differs'] < 0.08, nm
@@ -266,3 +262,40 @@ def test_config5_paper_size_inference(dev, tmp_path):
             # harmonic audio over a silent floor is harder than noise-like clips: most bins sit at the -18.42 floor, the first encoder
             # layer's attention logits reach ~1e4 and a bf16 product (2^-9 relative) re-ranks near-tied keys.  Worst element / mean:
             assert rep[nm] <= 0.12 and rep[nm + '.mean'] <= 5e-3, (nm, rep[nm], rep[nm + '.mean'])
+    est = amt.mpe2note(a_onset=outs[4], a_offset=outs[5], a_mpe=outs[6], a_velocity=outs[7])
+    mid = tmp_path / 'out.mid'
+    amt.note2midi(est, str(mid))
+    assert mid.read_bytes()[:4] == b'MThd'
+
+
+def test_config5_with_trained_weights(dev, tmp_path):
+    """BASELINE config 5 with weights that mean something: tests/golden/config5_tiny_trained.pkl is the reference's default-size model
+    (d = 64, 2 + 2 layers: training/m_training.py:56-61) after six minutes of THIS path's training step on the synthetic plucked-string corpus
+    (tools/train_config5.py; log: profiles/r04_config5_tiny_trained.json).  The scored minute (seed 1234) is not in the training set.
+    Asserted: note-F1 (onset within 50 ms, evaluation/m_transcription.py's criterion) and frame-F1 (mpe >= 0.5, evaluation/m_mpe.py:101)
+    against the GENERATING notes, and -- SURVEY section 7's caveat 'trained weights may behave differently' -- that on trained weights the default
+    x3 mode keeps every posterior within 1e-3 of the exact-fp32 mode with identical frame decisions, the bf16 mode its frame-F1."""
+    from model.amt import AMT
+    from corpus import synth_audio as SA
+    from evaluation.metrics import note_metrics, frame_metrics
+    pkl = os.path.join(util.ROOT, 'tests', 'golden', 'config5_tiny_trained.pkl')
+    notes = SA.pluck_notes(1234)
+    wave = SA.pluck_wave(notes)
+    mpe, rep = {}, {}
+    for mode in ('parity', 'x3', 'bf16'):
+        amt = AMT(SA.default_config(), pkl, batch_size=32)
+        amt.model.hftt_precision = mode
+        feat = amt.wave2feature(wave.unsqueeze(0), SA.SR)
+        outs = amt.transcript(feat.numpy())
+        est = amt.mpe2note(a_onset=outs[4], a_offset=outs[5], a_mpe=outs[6], a_velocity=outs[7])
+        nm = note_metrics(notes, est)
+        fm = frame_metrics(SA.reference_roll(notes, feat.shape[0]), outs[6], threshold=0.5)
+        mpe[mode] = outs
+        rep[mode] = {'note_f1': round(nm['F-measure'], 4), 'frame_f1': round(fm['f1'], 4), 'n_est': len(est)}
+    print('config 5 with trained weights:', json.dumps(rep))
+    assert rep['x3']['note_f1'] > 0.90 and rep['x3']['frame_f1'] > 0.85, rep
+    assert rep['bf16']['note_f1'] > 0.90 and abs(rep['bf16']['frame_f1'] - rep['parity']['frame_f1']) < 5e-3, rep
+    for k in (0, 1, 2, 4, 5, 6):
+        a, b = mpe['x3'][k], mpe['parity'][k]
+        assert float(np.abs(a - b).max()) <= 1e-3 and int(((a >= 0.5) != (b >= 0.5)).sum()) == 0, k
+    assert float((mpe['x3'][7] != mpe['parity'][7]).mean()) < 2e-3 and float((mpe['x3'][3] != mpe['parity'][3]).mean()) < 2e-3
