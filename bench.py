@@ -569,7 +569,8 @@ def main():
                                        'the two velocity-logit tensors against the benchmarked mode "%s" (eval forward)' % (m, args.precision)}
                 if 'roofline_ffn' in inf[m]:
                     extras[key]['roofline_ffn'] = inf[m]['roofline_ffn']
-            if args.precision == 'x3' and args.config == 'paper':
+            from hftt_hip import _capi as _hc
+            if args.precision == 'x3' and args.config == 'paper' and (_hc.lib().hftt_build_options() & 1):      # (only a HFTT_BUILD_GRAD_HI=1 library has it)
                 # the opt-in of DESIGN.md section 3: gradient operands of the backward GEMMs as their bf16 rounding (two MFMA passes)
                 os.environ['HFTT_X3_GRAD_HI'] = '1'
                 model.hftt_precision = 'bf16'; model.hftt_engine()          # (the engine reads the switch when its precision is set)

@@ -33,6 +33,10 @@ extern "C" {
 #define HFTT_ABI_VERSION 5
 
 int hftt_abi_version(void);
+/* bit 0: the library carries the opt-in gradient-rounding forms (HFTT_SL_X3_GRAD_HI, HFTT_TN_DY_HI, HFTT_NT_A_HI: a gradient operand enters a
+ * backward product as its bf16 rounding -- faster, outside the 1e-3 the default keeps for gradients).  They are built only with
+ * HFTT_BUILD_GRAD_HI=1 (nylon-amt_amd/build.py); the default library rejects those flags. */
+int hftt_build_options(void);
 const char* hftt_last_error(void);
 /* number of compute units of the current device (for workspace sizing on the host side) */
 int hftt_device_cus(void);

@@ -28,6 +28,14 @@ if os.environ.get('HFTT_BUILD_EXPERIMENTS') == '1':
     LIB = os.path.join(LIBDIR, 'libhftt_hip_x.so')
 
 
+# HFTT_BUILD_GRAD_HI=1: also build the opt-in gradient-rounding forms (a gradient operand as its bf16 rounding, two MFMA
+# passes; outside the 1e-3 gradient tolerance of the default mode).  They double the x3_linear* instantiations, so the default library leaves
+# them out (hftt_build_options() bit 0 says which build is loaded).
+if os.environ.get('HFTT_BUILD_GRAD_HI') == '1':
+    FLAGS += ['-DHFTT_GRAD_HI_BUILD']
+    LIB = os.path.join(LIBDIR, 'libhftt_hip_g.so' if LIB.endswith('libhftt_hip.so') else 'libhftt_hip_xg.so')
+
+
 def _hipcc():
     for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -43,7 +51,7 @@ def _stale(target, deps):
 
 
 def _compile(src):
-    obj = os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + ('.x.o' if 'HFTT_STRIP_EXPERIMENTS' in ' '.join(FLAGS) else '.o'))
+    obj = os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + (('.x' if 'HFTT_STRIP_EXPERIMENTS' in ' '.join(FLAGS) else '') + ('.g' if 'HFTT_GRAD_HI_BUILD' in ' '.join(FLAGS) else '') + '.o'))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
         cmd = [_hipcc()] + FLAGS + ['-x', 'hip', '-c', path, '-o', obj]

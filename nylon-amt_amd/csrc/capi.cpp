@@ -16,6 +16,14 @@ void hftt_set_error(const char* fmt, ...) {
 
 extern "C" int hftt_abi_version(void) { return HFTT_ABI_VERSION; }
 extern "C" const char* hftt_last_error(void) { return g_err; }
+// bit 0: built with the opt-in gradient-rounding forms (HFTT_BUILD_GRAD_HI=1: HFTT_SL_X3_GRAD_HI / HFTT_TN_DY_HI / HFTT_NT_A_HI)
+extern "C" int hftt_build_options(void) {
+#ifdef HFTT_GRAD_HI_BUILD
+  return 1;
+#else
+  return 0;
+#endif
+}
 extern "C" int hftt_device_cus(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;

@@ -14,7 +14,7 @@ namespace {
 template <int E>
 __device__ __forceinline__ void x3_split1(float x, uint16_t& hi, uint16_t& lo) {
   unsigned h, l;
-  x3_split2<E>(x, 0.f, h, l);
+  x3_split2_checked<E>(x, 0.f, h, l);      // (weight preparation: a NaN / Inf parameter must poison the planes)
   hi = (uint16_t)(h & 0xFFFFu); lo = (uint16_t)(l & 0xFFFFu);
 }
 

@@ -1102,6 +1102,11 @@ extern "C" int hftt_gemm_nt(const hftt_gemm_nt_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->npass == 3) return dispatch_nt<3>(*d, st);
   if (d->npass == 2) return dispatch_nt<2>(*d, st);
-  if (d->npass == 4) return (d->io_flags & HFTT_NT_A_HI) ? dispatch_nt<5>(*d, st) : dispatch_nt<4>(*d, st);
+#ifdef HFTT_GRAD_HI_BUILD
+  if (d->npass == 4 && (d->io_flags & HFTT_NT_A_HI)) return dispatch_nt<5>(*d, st);
+#else
+  HFTT_REQUIRE(!(d->io_flags & HFTT_NT_A_HI), "gemm_nt: this library was built without the gradient-rounding option (HFTT_BUILD_GRAD_HI=1 python nylon-amt_amd/build.py)");
+#endif
+  if (d->npass == 4) return dispatch_nt<4>(*d, st);
   return dispatch_nt_bf16(*d, st);
 }

@@ -145,9 +145,11 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
 
   auto gload = [&](int step, uint4 (&yreg)[Cfg::YL], uint4 (&xreg)[Cfg::XL]) {
     const long mb = mbeg + (long)step * BMT;
+    int tid_g = tid;
+    asm volatile("" : "+v"(tid_g));                  // (per-slot row / column offsets formed per call: hoisted out of the step loop they spill)
 #pragma unroll
     for (int j = 0; j < Cfg::YL; j++) {
-      const int i = tid + 512 * j;
+      const int i = tid_g + 512 * j;
       const int row = i / YSPR;
       const long m = mb + row;
       // unconditional load from a clamped address (a branch around the load would make hipcc wait vmcnt(0) per load); slots that
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
     }
 #pragma unroll
     for (int j = 0; j < Cfg::XL; j++) {
-      const int i = tid + 512 * j;
+      const int i = tid_g + 512 * j;
       const int row = i / XSPR, cs = i % XSPR;
       const long m = mb + row;
       const int col = k0 + cs * XE;
@@ -467,12 +469,17 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
     else if (p.tn == 2) rc = launch_tn<1, 2, 3, false, false>(*d, p, st);
     else rc = launch_tn<1, 1, 3, false, false>(*d, p, st);
   } else if (d->npass == 4 && (d->io_flags & HFTT_TN_DY_HI) && !dyb) {
+#ifndef HFTT_GRAD_HI_BUILD
+    hftt_set_error("gemm_tn: this library was built without the gradient-rounding option (HFTT_BUILD_GRAD_HI=1 python nylon-amt_amd/build.py)");
+    return 1;
+#else
 #define HFTT_TN_GO5(TM_, TN_) (xb ? launch_tn<TM_, TN_, 5, false, true>(*d, p, st) : launch_tn<TM_, TN_, 5, false, false>(*d, p, st))
     if (p.tm == 2) rc = HFTT_TN_GO5(2, 4);
     else if (p.tn == 4) rc = HFTT_TN_GO5(1, 4);
     else if (p.tn == 2) rc = HFTT_TN_GO5(1, 2);
     else rc = HFTT_TN_GO5(1, 1);
 #undef HFTT_TN_GO5
+#endif
   } else if (d->npass == 4) {
 #define HFTT_TN_GO4(TM_, TN_)                                                     \
     (dyb ? launch_tn<TM_, TN_, 4, true, false>(*d, p, st) : (xb ? launch_tn<TM_, TN_, 4, false, true>(*d, p, st) : launch_tn<TM_, TN_, 4, false, false>(*d, p, st)))

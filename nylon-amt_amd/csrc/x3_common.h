@@ -36,9 +36,7 @@ struct X3<X3_F16> {
     const f32x2_t v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
   }
-  // the lo half is NOT clamped: for a finite |x| <= 65504 it is below one fp16 ulp of hi anyway, and a NaN / Inf input -- which v_med3_f32
-  // turns into a finite hi (it returns the minimum of the other two operands for a NaN) -- reappears here as x - hi = NaN / Inf, so a diverged
-  // tensor still poisons every product it enters instead of being laundered into +-65504; 65504 < |x| <= 131008 stays exact
+  // plain conversion (no saturation): the lo halves (below one fp16 ulp of hi once the VALUE was clamped) and values known to be in range
   static __device__ __forceinline__ unsigned pk_lo(float a, float b) {
     const f32x2_t v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
@@ -87,10 +85,28 @@ template <>
 struct X3<X3_BF16H> : X3<X3_BF16> {};
 
 // (a, b) -> packed hi pair + packed lo pair
+// The VALUE is saturated once (fp16: +-65504; bf16: nothing to do), then split: a finite input always gives a finite pair -- no infinities
+// are manufactured inside a GEMM whatever a diverging run feeds it (per pair: 2 x v_med3, cvt_pk, 2 x fma_mix, cvt_pk).  v_med3_f32 returns a
+// finite value for a NaN input too (the minimum of the other two operands), so THIS form does not carry a NaN: on the activation stream the
+// fp32 residual / LayerNorm path next to every GEMM does (tensors stay fp32 between kernels); the per-step weight preparation, whose
+// operands have no such path, uses x3_split2_checked below.
 template <int E>
 __device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsigned& lo) {
-  hi = X3<E>::pk(a, b);
+  if (E == X3_F16) {
+    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+  }
+  hi = X3<E>::pk_lo(a, b);
   lo = X3<E>::lo_of(a, b, hi);
+}
+// the same for the weight-preparation kernels (once per step over the parameters: not a hot path): a NaN or infinite parameter comes out as
+// a NaN lo half, so a diverged optimizer state poisons every product of the next forward instead of being laundered into +-65504
+template <int E>
+__device__ __forceinline__ void x3_split2_checked(float a, float b, unsigned& hi, unsigned& lo) {
+  x3_split2<E>(a, b, hi, lo);
+  const unsigned nan_lo = (E == X3_F16) ? 0x7E00u : 0x7FC0u;
+  if (!(a - a == 0.f)) lo = (lo & 0xFFFF0000u) | nan_lo;
+  if (!(b - b == 0.f)) lo = (lo & 0x0000FFFFu) | (nan_lo << 16);
 }
 // the same for values known to be finite and inside the element type's range (softmax probabilities): no saturation step
 template <int E>
@@ -117,6 +133,14 @@ __device__ __forceinline__ void x3_split8(const float* v, bf16x8& hi, bf16x8& lo
   uint4 h, l;
   x3_split2<E>(v[0], v[1], h.x, l.x); x3_split2<E>(v[2], v[3], h.y, l.y);
   x3_split2<E>(v[4], v[5], h.z, l.z); x3_split2<E>(v[6], v[7], h.w, l.w);
+  hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
+}
+
+template <int E>
+__device__ __forceinline__ void x3_split8_checked(const float* v, bf16x8& hi, bf16x8& lo) {
+  uint4 h, l;
+  x3_split2_checked<E>(v[0], v[1], h.x, l.x); x3_split2_checked<E>(v[2], v[3], h.y, l.y);
+  x3_split2_checked<E>(v[4], v[5], h.z, l.z); x3_split2_checked<E>(v[6], v[7], h.w, l.w);
   hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
 }
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void x3_strip_pack_kernel(const float* __restr
       off = (pos * 16 + frag) * 512 + (hk2 * 32 + i) * 8;
     }
     bf16x8 hi, lo;
-    x3_split8<E>(v, hi, lo);
+    x3_split8_checked<E>(v, hi, lo);                  // (a NaN / Inf parameter poisons its fragment pair)
     *reinterpret_cast<bf16x8*>(dst + e.dst_off + off) = hi;
     *reinterpret_cast<bf16x8*>(dst + e.dst_off + off + 512) = lo;
   }
@@ -211,6 +211,7 @@ __device__ __forceinline__ void store16f(float* p, const float* v) {
 constexpr int STG_RS = 36;                            // floats per staged row (144 B: the 16-byte row pieces of 8 rows fall on 8 different bank quads)
 constexpr int STG_BYTES_PER_WAVE = 16 * STG_RS * 4;
 __device__ __forceinline__ void tile_store_rows(float* stage, const float* v, int j, int h, int lane, float* gtile, long ld, bool ok) {
+  asm volatile("" : "+v"(lane));                    // (row * ld is formed per call: hoisted out of the block loop it is a spilled 64-bit value per row group)
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     if ((j >> 4) == half) {
@@ -230,6 +231,7 @@ __device__ __forceinline__ void tile_store_rows(float* stage, const float* v, in
 // The same tile as bf16 (the saved FFN hidden and its gradient: operands of the weight-gradient products only, HFTT_SL_H_BF16): 64-byte row
 // segments, 16 rows x 4 lanes per store instruction, through the same patch (rows of 40 shorts = 80 B: 16-byte pieces, 8 rows on 8 bank quads).
 __device__ __forceinline__ void tile_store_rows_bf16(float* stage, const float* v, int j, int h, int lane, unsigned short* gtile, long ld, bool ok) {
+  asm volatile("" : "+v"(lane));                    // (row * ld is formed per call: hoisted out of the block loop it is a spilled 64-bit value per row group)
   unsigned short* st16 = reinterpret_cast<unsigned short*>(stage);
   constexpr int RS = 40;
 #pragma unroll
@@ -253,6 +255,7 @@ __device__ __forceinline__ void tile_store_rows_bf16(float* stage, const float* 
 // further conversion -- x3_attn_pl.hip): the tile's 128 bytes per row hold its 32 hi halves (64 B), then its 32 lo halves -- the same
 // whole-line row segments as the fp32 form, through the same patch.
 __device__ __forceinline__ void tile_store_rows_f16pair(float* stage, const float* v, int j, int h, int lane, float* gtile, long ld, bool ok) {
+  asm volatile("" : "+v"(lane));                    // (row * ld is formed per call: hoisted out of the block loop it is a spilled 64-bit value per row group)
   bf16x8 hi0, lo0, hi1, lo1;
   x3_split8<X3_F16>(v, hi0, lo0);
   x3_split8<X3_F16>(v + 8, hi1, lo1);
@@ -368,13 +371,11 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     int hb = h;                                       // opaque per iteration (LICM would hoist per-tile column arithmetic out of the loop: spills)
     asm volatile("" : "+v"(hb));
-    const long tok = blk * 128 + wave * 32 + j;
     const bool wave_ok = (blk * 128 + wave * 32) < g.M;          // M % 32 == 0 (host check)
-    const long tokc = tok_of(blk);
     const long nxt = blk + gridDim.x;
-    const float* xrow = xb + tokc * g.ldx + 16 * hb;
-    const float* xrow_next = xb + (nxt < nblk ? tok_of(nxt) : tokc) * g.ldx + 16 * hb;      // (past the last block: a harmless re-read)
-    const long rrow = g.res_mod > 0 ? (long)((unsigned)tokc % (unsigned)g.res_mod) : tokc;
+    // per-lane row numbers are formed where a step uses them, from a lane number the optimiser cannot see through: as loop-level values
+    // (this block's and the next block's strip rows, the residual row, the dropout row index, 64 bits each) they were spilled to scratch
+    auto lane_tok = [&](long b) { int l_ = lane; asm volatile("" : "+v"(l_)); const long t = b * 128 + wave * 32 + (l_ & 31); return t < g.M ? t : (long)g.M - 1; };
     int zero = 0;
     asm volatile("" : "+s"(zero));
     const float* prm_b = prm + zero;                  // (keeps the LDS parameter reads inside the iteration)
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
         const bool last_step = (pass == PASSES - 1) && (kc == KCH - 1);
         const bool reload = ((KCH > 1) || last_step) && !dbg_noload;
         const bool convert = ((KCH > 1) || (pass == 0)) && !dbg_noconv;
-        const float* nsrc = last_step ? xrow_next : (xrow + ((kc + 1 == KCH) ? 0 : kc + 1) * 256);
+        // (past the last block: a harmless re-read of this block's rows)
+        const float* nsrc = xb + lane_tok(last_step ? (nxt < nblk ? nxt : blk) : blk) * g.ldx + 16 * hb + (last_step ? 0 : ((kc + 1 == KCH) ? 0 : kc + 1) * 256);
         static_for<16>([&](auto c_c) __attribute__((always_inline)) {
           constexpr int c = decltype(c_c)::value;
           constexpr int BUF = c & 3;
@@ -411,8 +413,11 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
         if (((KCH > 1) || last_step) && !dbg_noconv) chunk_convert<E>(xr[0]);
       }
       // ---------------- epilogue of this pass ----------------
+      const long tokc_e = lane_tok(blk);
+      const long tok = blk * 128 + wave * 32 + (tokc_e & 31);                 // (M % 32 == 0: the clamp never changes the low five bits)
       const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;
       float* cwave = cb + (blk * 128 + wave * 32) * g.ldc + pass * 256;      // row 0 of this wave's strip, this pass's columns
+      const long rrow = g.res_mod > 0 ? (long)((unsigned)tokc_e % (unsigned)g.res_mod) : tokc_e;
       const float* rrow_p = rb + (HR ? rrow * g.ldr + pass * 256 + 16 * hb : 0);
       float rnext[16];
       if (HR) load16f(rrow_p, rnext);
@@ -505,15 +510,12 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     int hb = h;
     asm volatile("" : "+v"(hb));
-    const long tok = blk * 128 + wave * 32 + j;
     const bool wave_ok = (blk * 128 + wave * 32) < g.M;
-    const long tokc = tok_of(blk);
     const long nxt = blk + gridDim.x;
-    const float* xrow_next = xb + (nxt < nblk ? tok_of(nxt) : tokc) * g.ldx + 16 * hb;
-    const long rrow = g.res_mod > 0 ? (long)((unsigned)tokc % (unsigned)g.res_mod) : tokc;
-    const float* rrow_p = rb + (HR ? rrow * g.ldr + 16 * hb : 0);
-    float* cwave = cb + (blk * 128 + wave * 32) * g.ldc;        // row 0 of this wave's strip
-    const uint64_t rowq = ((uint64_t)tok * (uint64_t)g.N) >> 2;
+    // per-lane row pointers are formed where a tile uses them, from a lane number the optimiser cannot see through (kept live across the
+    // tile loop -- the next block's strip rows, the residual rows, the dropout row index -- they were the kernel's spills: 2 .. 7 registers)
+    auto lane_tok = [&](long b) { int l_ = lane; asm volatile("" : "+v"(l_)); const long t = b * 128 + wave * 32 + (l_ & 31); return t < g.M ? t : (long)g.M - 1; };
+    float* cwave = cb + (blk * 128 + wave * 32) * g.ldc;        // row 0 of this wave's strip (wave-uniform)
     int zero = 0;
     asm volatile("" : "+s"(zero));
     const float* prm_b = prm + zero;
@@ -540,15 +542,19 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
       x3_slot_chunks<E, 0>(abase + BA * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<BA>();
-        if (i == 4 && HR) load16f(rrow_p + t * 32, r);
+        if (i == 4 && HR) {
+          const long tokc = lane_tok(blk);
+          const long rrow = g.res_mod > 0 ? (long)((unsigned)tokc % (unsigned)g.res_mod) : tokc;
+          load16f(rb + rrow * g.ldr + 16 * hb + t * 32, r);
+        }
         // last tile of the block: a chunk that has fed its three MFMAs takes the next block's values
-        if (LAST && i % 3 == 2) chunk_load(xr[i / 3], xrow_next + chunk_off(i / 3));
+        if (LAST && i % 3 == 2) chunk_load(xr[i / 3], xb + lane_tok(nxt < nblk ? nxt : blk) * g.ldx + 16 * hb + chunk_off(i / 3));
       });
       P.begin_slot();
       x3_slot_chunks<E, 8>(abase + BB * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<BB>();
-        if (LAST && i % 3 == 2) chunk_load(xr[8 + i / 3], xrow_next + chunk_off(8 + i / 3));
+        if (LAST && i % 3 == 2) chunk_load(xr[8 + i / 3], xb + lane_tok(nxt < nblk ? nxt : blk) * g.ldx + 16 * hb + chunk_off(8 + i / 3));
       });
       // ---- this tile's epilogue ----
       float v[16];
@@ -558,7 +564,11 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
         if (relu) a = fmaxf(a, 0.f);
         v[q] = a * g.out_scale;
       }
-      if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.drop_site, rowq + ((t * 32 + 16 * hb) >> 2), thr, inv_keep);
+      if (g.drop_p > 0.f) {
+        int l_ = lane; asm volatile("" : "+v"(l_));
+        const uint64_t rowq = ((uint64_t)(blk * 128 + wave * 32 + (l_ & 31)) * (uint64_t)g.N) >> 2;
+        drop16(v, g.drop_seed, g.drop_site, rowq + ((t * 32 + 16 * hb) >> 2), thr, inv_keep);
+      }
       if (HR) {
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] += r[q];
@@ -876,7 +886,11 @@ int hftt_x3_strip_linear(const hftt_strip_desc& d0, hipStream_t st) {
                  "x3_strip_linear: HFTT_SL_C_F16PAIR is the plain forward projection (HFTT_SL_X3_F16, K == 256, N <= 768, no LayerNorm / residual / ReLU / dropout)");
     HFTT_REQUIRE(((uintptr_t)d.C & 15) == 0, "x3_strip_linear: C must be 16-byte aligned");
   }
+#ifdef HFTT_GRAD_HI_BUILD
   if (d.flags & HFTT_SL_X3_GRAD_HI) return dispatch_xl<X3_BF16H>(d, st);
+#else
+  HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_GRAD_HI), "x3_strip_linear: this library was built without the gradient-rounding option (HFTT_BUILD_GRAD_HI=1 python nylon-amt_amd/build.py)");
+#endif
   return (d.flags & HFTT_SL_X3_BF16) ? dispatch_xl<X3_BF16>(d, st) : dispatch_xl<X3_F16>(d, st);
 }
 
@@ -901,13 +915,22 @@ int hftt_x3_strip_mlp(const hftt_ffn_desc& d0, hipStream_t st) {
   HFTT_REQUIRE(((d.flags & HFTT_SL_X3_BF16) != 0) == (d.mode == 1), "x3_strip_mlp: mode 0 takes fp16 halves (HFTT_SL_X3_F16), mode 1 bf16 halves");
   const bool gh = (d.flags & HFTT_SL_X3_GRAD_HI) != 0;
   HFTT_REQUIRE(!gh || d.mode == 1, "x3_strip_mlp: HFTT_SL_X3_GRAD_HI belongs to the backward form");
+#ifndef HFTT_GRAD_HI_BUILD
+  HFTT_REQUIRE(!gh, "x3_strip_mlp: this library was built without the gradient-rounding option (HFTT_BUILD_GRAD_HI=1 python nylon-amt_amd/build.py)");
+#endif
   if (d.flags & HFTT_SL_H_BF16) {
     HFTT_REQUIRE((d.h_out == nullptr || d.ldh % 8 == 0) && (d.gate == nullptr || d.ldg % 8 == 0), "x3_strip_mlp: bf16 hidden rows must be 16-byte aligned");
     if (d.mode == 0) return launch_xm<0, true>(d, st);
-    return gh ? launch_xm<1, true, true>(d, st) : launch_xm<1, true, false>(d, st);
+#ifdef HFTT_GRAD_HI_BUILD
+    if (gh) return launch_xm<1, true, true>(d, st);
+#endif
+    return launch_xm<1, true, false>(d, st);
   }
   if (d.mode == 0) return launch_xm<0, false>(d, st);
-  return gh ? launch_xm<1, false, true>(d, st) : launch_xm<1, false, false>(d, st);
+#ifdef HFTT_GRAD_HI_BUILD
+  if (gh) return launch_xm<1, false, true>(d, st);
+#endif
+  return launch_xm<1, false, false>(d, st);
 }
 
 extern "C" int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_pack_entry* table_dev, int n_entries, int elem, void* stream) {

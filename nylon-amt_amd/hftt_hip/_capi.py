@@ -9,7 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('HFTT_LIB_PATH') or os.path.join(_HERE, '..', 'lib', 'libhftt_hip_x.so' if os.environ.get('HFTT_BUILD_EXPERIMENTS') == '1' else 'libhftt_hip.so')      # HFTT_LIB_PATH: dev builds (tools/ablate_strip.sh)
+_LIB_NAME = 'libhftt_hip_x' if os.environ.get('HFTT_BUILD_EXPERIMENTS') == '1' else 'libhftt_hip'
+if os.environ.get('HFTT_BUILD_GRAD_HI') == '1':
+    _LIB_NAME += '_g' if _LIB_NAME == 'libhftt_hip' else 'g'
+LIB_PATH = os.environ.get('HFTT_LIB_PATH') or os.path.join(_HERE, '..', 'lib', _LIB_NAME + '.so')      # HFTT_LIB_PATH: dev builds (tools/ablate_strip.sh)
 
 c_f32p = C.c_void_p   # device pointers travel as plain integers
 c_u16p = C.c_void_p
@@ -145,6 +148,7 @@ class LogmelDesc(C.Structure):
 SIGNATURES = {
     'hftt_abi_version': (C.c_int, []),
     'hftt_last_error': (C.c_char_p, []),
+    'hftt_build_options': (C.c_int, []),
     'hftt_device_cus': (C.c_int, []),
     'hftt_prep_weights': (C.c_int, [c_f32p, c_u16p, c_u16p, c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
     'hftt_prep_weights_x3': (C.c_int, [c_f32p, c_u16p, c_u16p, c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
