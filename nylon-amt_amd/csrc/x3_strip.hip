@@ -119,9 +119,33 @@ struct XPipe {
 
 // a strip chunk: 8 features of the lane's token in 8 registers -- raw fp32 (a = first four, b = last four) or converted (a = hi, b = lo)
 struct XChunk { u4v a, b; };
+// Streaming accesses of the strip kernels, with an optional non-temporal hint (-DHFTT_STRIP_NT=1; OFF by default).  Why it exists: the
+// request-size counters (profiles/r04a_pmc_fetch_detail.json: all 128-byte requests, so FETCH_SIZE x 2 is exact here) show the QKV projection
+// fetching 1.58 x its activation bytes and the training FFN 1.49 x -- lines evicted from the 4 MB L2 between their uses (the weight stream
+// every 128-token block re-reads; 16-byte pieces of an activation line taken by different instructions) and fetched again from the fabric,
+// i.e. from the 256 MB Infinity Cache.  Measured with the hint on every strip load and result store (same box, paper-size step): the FFN's
+// fetch fell (225 -> 196 MB) but the QKV projection's rose (250 -> 283 MB) and the K = 768 dX form's rose from 698 to 909 MB -- a
+// non-temporal load does not keep the line for the next instruction's pieces -- and the step went from 266 to 251 clips/s.  Kept as a switch.
+#ifndef HFTT_STRIP_NT
+#define HFTT_STRIP_NT 0
+#endif
+__device__ __forceinline__ u4v stream_load16(const void* p) {
+#if HFTT_STRIP_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
+#else
+  return *reinterpret_cast<const u4v*>(p);
+#endif
+}
+__device__ __forceinline__ void stream_store16(void* p, const u4v& v) {
+#if HFTT_STRIP_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(p));
+#else
+  *reinterpret_cast<u4v*>(p) = v;
+#endif
+}
 __device__ __forceinline__ void chunk_load(XChunk& c, const float* p) {
-  c.a = *reinterpret_cast<const u4v*>(p);
-  c.b = *reinterpret_cast<const u4v*>(p + 4);
+  c.a = stream_load16(p);
+  c.b = stream_load16(p + 4);
 }
 template <int E>
 __device__ __forceinline__ void chunk_convert(XChunk& c) {
@@ -223,7 +247,7 @@ __device__ __forceinline__ void tile_store_rows(float* stage, const float* v, in
     for (int k = 0; k < 2; k++) {
       const int r = (lane >> 3) + 8 * k;
       const float4 t = *reinterpret_cast<const float4*>(stage + r * STG_RS + (lane & 7) * 4);
-      if (ok) *reinterpret_cast<float4*>(gtile + (long)(half * 16 + r) * ld + (lane & 7) * 4) = t;
+      if (ok) stream_store16(gtile + (long)(half * 16 + r) * ld + (lane & 7) * 4, __builtin_bit_cast(u4v, t));
     }
   }
 }
@@ -248,7 +272,7 @@ __device__ __forceinline__ void tile_store_rows_bf16(float* stage, const float* 
     }
     const int r = lane >> 2;
     const uint4 t = *reinterpret_cast<const uint4*>(st16 + r * RS + (lane & 3) * 8);
-    if (ok) *reinterpret_cast<uint4*>(gtile + (long)(half * 16 + r) * ld + (lane & 3) * 8) = t;
+    if (ok) stream_store16(gtile + (long)(half * 16 + r) * ld + (lane & 3) * 8, __builtin_bit_cast(u4v, t));
   }
 }
 // The same tile as an f16 PAIR (HFTT_SL_C_F16PAIR: the q / k / v projections, read by the attention kernels as MFMA operands without any
@@ -272,7 +296,7 @@ __device__ __forceinline__ void tile_store_rows_f16pair(float* stage, const floa
     for (int k = 0; k < 2; k++) {
       const int r = (lane >> 3) + 8 * k;
       const float4 t = *reinterpret_cast<const float4*>(stage + r * STG_RS + (lane & 7) * 4);
-      if (ok) *reinterpret_cast<float4*>(gtile + (long)(half * 16 + r) * ld + (lane & 7) * 4) = t;
+      if (ok) stream_store16(gtile + (long)(half * 16 + r) * ld + (lane & 7) * 4, __builtin_bit_cast(u4v, t));
     }
   }
 }
