@@ -46,7 +46,9 @@ TnPlan tn_plan(int M, int N, int K) {
   p.n_tiles = (N + p.tile_n - 1) / p.tile_n;
   p.k_tiles = (K + p.tile_k - 1) / p.tile_k;
   const int tiles = p.n_tiles * p.k_tiles;
-  int target = (p.tm == 2 || p.tn == 4) ? 256 : 512;
+  static int small_target = -1;
+  if (small_target < 0) { const char* e = getenv("HFTT_TN_SMALL_TARGET"); small_target = e ? atoi(e) : 512; }
+  int target = (p.tm == 2 || p.tn == 4) ? 256 : small_target;
   int splits = target / tiles;
   // the tiles of a split share an XCD (kernel: block -> (tile, split) map), so splits come in groups of eight and one group's
   // tiles must not exceed that XCD's share of the resident workgroups -- 33 workgroups on 32 CUs would run two rounds
