@@ -415,6 +415,65 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const hftt_gemm_tn_
   }
 }
 
+// The same reduce for SMALL outputs (N * K_out <= 65,536: the d = 64 model's 64 x 64 .. 192 x 64 matrices).  One thread per element gives the
+// launch N * K / 256 workgroups -- 16 for a 64 x 64 matrix -- to read a slab of several hundred partial tiles (15 MB): 16 us per call, 31 calls
+// per tiny-model step.  Here a workgroup takes 16 consecutive elements and its 16 thread rows take the splits s = row (mod 16), four loads in
+// flight; the partial sums meet in LDS and are added in a FIXED order (bitwise reproducible).  Bias rows as above.
+__global__ __launch_bounds__(256) void gemm_tn_reduce_small_kernel(const hftt_gemm_tn_desc g, const int splits, const long nws, const long kws,
+                                                                   const int nb_main) {
+  const long total = (long)g.N * g.K_out;
+  const float* ws = reinterpret_cast<const float*>(g.ws);
+  const long sstride = nws * kws;
+  if ((int)blockIdx.x >= nb_main) {
+    const int n = ((int)blockIdx.x - nb_main) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= g.N) return;
+    int sg = -1;
+    for (int s = 0; s < g.n_seg; s++)
+      if (n >= g.seg_row0[s] && n < g.seg_row0[s] + g.seg_rows[s]) sg = s;
+    if (sg < 0 || g.seg_db[sg] == nullptr) return;
+    const float* bs = ws + (long)splits * sstride;
+    float b = 0.f;
+    for (int q = lane; q < splits; q += 64) b += bs[(long)q * nws + n];
+    b = wave_sum(b);
+    if (lane == 0) {
+      float* db = g.seg_db[sg] + (n - g.seg_row0[sg]);
+      const float bv = b * g.out_scale;
+      *db = (g.beta != 0.f) ? (*db * g.beta + bv) : bv;
+    }
+    return;
+  }
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long idx = (long)blockIdx.x * 16 + e;
+  const bool ok = idx < total;
+  const long idc = ok ? idx : total - 1;
+  const int n = (int)(idc / g.K_out), k = (int)(idc % g.K_out);
+  const float* p = ws + (long)n * kws + k;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = sl;
+  for (; s + 48 < splits; s += 64) {
+    const float v0 = p[(long)s * sstride], v1 = p[(long)(s + 16) * sstride], v2 = p[(long)(s + 32) * sstride], v3 = p[(long)(s + 48) * sstride];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; s < splits; s += 16) a0 += p[(long)s * sstride];
+  part[sl][e] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && ok) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += part[i][e];
+    int sg = -1;
+    for (int q = 0; q < g.n_seg; q++)
+      if (n >= g.seg_row0[q] && n < g.seg_row0[q] + g.seg_rows[q]) sg = q;
+    if (sg >= 0) {
+      float* dst = g.seg_dw[sg] + (long)(n - g.seg_row0[sg]) * g.K_out + k;
+      const float v = acc * g.out_scale;
+      *dst = (g.beta != 0.f) ? (*dst * g.beta + v) : v;
+    }
+  }
+}
+
 template <int TM, int TN, int NPASS, bool DYB, bool XB>
 int launch_tn(const hftt_gemm_tn_desc& d, const TnPlan& p, hipStream_t st) {
   using Cfg = TnCfg<TM, TN, NPASS, DYB, XB>;
@@ -507,9 +566,15 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   }
   if (rc != 0) return rc;
   const long total = (long)d->N * d->K_out;
+  const int bias_blocks = (d->N + 3) / 4;
+  if (total <= 65536 && p.splits >= 32) {             // small output, many partial tiles: the wide reduce
+    const int blocks = (int)((total + 15) / 16);
+    hipLaunchKernelGGL(gemm_tn_reduce_small_kernel, dim3(blocks + bias_blocks), dim3(256), 0, st, *d, p.splits, p.nws, p.kws, blocks);
+    HFTT_CHECK_LAUNCH("gemm_tn_reduce");
+    return 0;
+  }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  const int bias_blocks = (d->N + 3) / 4;
   hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks + bias_blocks), dim3(256), 0, st, *d, p.splits, p.nws, p.kws, blocks);
   HFTT_CHECK_LAUNCH("gemm_tn_reduce");
   return 0;
