@@ -46,13 +46,25 @@ __device__ __forceinline__ void pl_vals8(const bf16x8& hi, const bf16x8& lo, flo
 template <int KT, int DH>
 struct XbCfg {
   static constexpr int LKP = KT * 32;
-  static constexpr int RSK = (DH == 64) ? 96 : 32;    // K image (bf16 pair) for dQ: tr-read friendly (64 mod 128 bytes)
-  static constexpr int RSQ = DH + 8;                  // Q / dO blocks: b128-read friendly
-  static constexpr int RSS = LKP + 8;                 // dS block [query][key]
+  // LDS images, dh = 64: UNPADDED rows of 128 bytes whose 16-byte chunks are XOR-swizzled by row bits, chosen (exhaustive search over linear
+  // maps, bank rule of MI355X_MICROARCH.md, LDS) so that every read of the loop is conflict-free: the row reads (ds_read_b128: 16 rows x one
+  // chunk per lane group) AND the transposed reads (ds_read_b64_tr_b16: four / eight rows x 64 / 32 bytes per 32 lanes) of the same image.
+  // The padded rows before (Q / dO 144 bytes, K 192 bytes, dS + 16 bytes) were 2-way on the transposed reads of Q^T / dO^T and K and on the
+  // dS row reads: SQ_LDS_BANK_CONFLICT = 37 % of SQ_LDS_IDX_ACTIVE (profiles/r04b_attn_bwd_lds.txt).  dh = 32 keeps padded rows.
+  static constexpr bool SWZ = DH == 64;
+  static constexpr int RSK = (DH == 64) ? 64 : 32;    // K image (bf16 pair) for dQ: transposed reads only
+  static constexpr int RSQ = SWZ ? DH : DH + 8;       // Q / dO blocks: row reads (scores, dP) and transposed reads (dK, dV)
+  static constexpr int RSS = SWZ ? LKP + 16 : LKP + 8;   // dS block [query][key]: row reads, 32 bytes mod 256 per row
+  // chunk ^= swizzle(row).  Q / dO: bit 0 <- row bit 1, bit 1 <- row bit 2, bit 2 <- row bits 1 ^ 3.   K: bit 1 <- row bit 1, bit 2 <- row bit 3
+  static __device__ __forceinline__ int qsw(int row) { return SWZ ? (((row >> 1) & 3) | ((((row >> 1) ^ (row >> 3)) & 1) << 2)) : 0; }
+  static __device__ __forceinline__ int ksw(int row) { return SWZ ? ((row & 2) | (((row >> 3) & 1) << 2)) : 0; }
+  // element offset (in halves) of column `col` (a multiple of 4) of a row
+  static __device__ __forceinline__ int qoff(int row, int col) { return row * RSQ + ((((col >> 3) ^ qsw(row)) << 3) | (col & 7)); }
+  static __device__ __forceinline__ int koff(int row, int col) { return row * RSK + ((((col >> 3) ^ ksw(row)) << 3) | (col & 7)); }
   static constexpr int K_PL = LKP * RSK;
   static constexpr int Q_PL = 32 * RSQ;
   static constexpr int S_PL = 32 * RSS;
-  // K image (bf16 hi, lo) | Q fp16 (hi, lo) | Q bf16 (hi, lo) | dO bf16 (hi, lo) | dS bf16 (hi, lo) | row statistics
+  // Q fp16 (hi, lo) | Q bf16 (hi, lo) | dO bf16 (hi, lo) | dS bf16 (hi, lo) | row statistics | K image (bf16 hi, lo)
   static constexpr int ELEMS = 2 * K_PL + 6 * Q_PL + 2 * S_PL;
   static constexpr int LDS_LOOP = ELEMS * 2 + 96 * 4;
   static constexpr int RSE = DH + 4;                  // epilogue patch rows (floats)
@@ -74,16 +86,23 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   constexpr int K_PL = Cfg::K_PL, Q_PL = Cfg::Q_PL, S_PL = Cfg::S_PL;
   constexpr int KS = DH / 16, NT = DH / 32, F4R = DH / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* Kb = reinterpret_cast<unsigned short*>(smem);       // bf16 hi | lo
-  unsigned short* Qf = Kb + 2 * K_PL;                                   // fp16 hi | lo   (scores)
+  // the small images first: their byte offsets (planes, k-steps, row groups) then fit the 16-bit immediate of the DS instructions; behind
+  // the 64 KB K image every read of them paid a v_add for its address
+  unsigned short* Qf = reinterpret_cast<unsigned short*>(smem);       // fp16 hi | lo   (scores)
   unsigned short* Qb = Qf + 2 * Q_PL;                                   // bf16 hi | lo   (dK)
   unsigned short* Ob = Qb + 2 * Q_PL;                                   // dO, bf16 hi | lo
   unsigned short* Sb = Ob + 2 * Q_PL;                                   // dS, bf16 hi | lo
-  float* lse_s = reinterpret_cast<float*>(smem + (size_t)Cfg::ELEMS * 2);
+  float* lse_s = reinterpret_cast<float*>(Sb + 2 * S_PL);
+  unsigned short* Kb = reinterpret_cast<unsigned short*>(lse_s + 96);  // bf16 hi | lo (dQ)
   float* delta_s = lse_s + 32;
   float* inv_s = lse_s + 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef HFTT_PRIO_SKEW
+  // waves w and w + 4 share a SIMD and run the same phases between the same barriers: a static priority makes the first finish its matrix
+  // phase while the second waits, after which one is in vector work while the other multiplies
+  if (KT >= 8 && __builtin_amdgcn_readfirstlane(wave) < KT / 2) __builtin_amdgcn_s_setprio(HFTT_PRIO_SKEW);
+#endif
   const int lr0 = lane & 31, lh0 = lane >> 5;
   const int gi0 = lane >> 4, qq0 = (lane & 15) >> 2, pp0 = lane & 3;
   const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
@@ -122,8 +141,8 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         const int key = i / F4R, c4 = i % F4R;
         uint2 hi, lo;
         x3_split4<EB>(kst[u], hi, lo);
-        *reinterpret_cast<uint2*>(Kb + key * RSK + c4 * 4) = hi;
-        *reinterpret_cast<uint2*>(Kb + K_PL + key * RSK + c4 * 4) = lo;
+        *reinterpret_cast<uint2*>(Kb + Cfg::koff(key, c4 * 4)) = hi;
+        *reinterpret_cast<uint2*>(Kb + K_PL + Cfg::koff(key, c4 * 4)) = lo;
       }
     }
   }
@@ -227,14 +246,15 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         } else {
           x3_split4<EF>(pq[u], hi, lo);
         }
-        *reinterpret_cast<uint2*>(Qf + row * RSQ + cs * 4) = hi;
-        *reinterpret_cast<uint2*>(Qf + Q_PL + row * RSQ + cs * 4) = lo;
+        const int so = Cfg::qoff(row, cs * 4);
+        *reinterpret_cast<uint2*>(Qf + so) = hi;
+        *reinterpret_cast<uint2*>(Qf + Q_PL + so) = lo;
         x3_split4<EB>(pq[u], hi, lo);
-        *reinterpret_cast<uint2*>(Qb + row * RSQ + cs * 4) = hi;
-        *reinterpret_cast<uint2*>(Qb + Q_PL + row * RSQ + cs * 4) = lo;
+        *reinterpret_cast<uint2*>(Qb + so) = hi;
+        *reinterpret_cast<uint2*>(Qb + Q_PL + so) = lo;
         x3_split4<EB>(pdo[u], hi, lo);
-        *reinterpret_cast<uint2*>(Ob + row * RSQ + cs * 4) = hi;
-        *reinterpret_cast<uint2*>(Ob + Q_PL + row * RSQ + cs * 4) = lo;
+        *reinterpret_cast<uint2*>(Ob + so) = hi;
+        *reinterpret_cast<uint2*>(Ob + Q_PL + so) = lo;
         }
         float dot = pdo[u].x * po[u].x + pdo[u].y * po[u].y + pdo[u].z * po[u].z + pdo[u].w * po[u].w;
         dot = group_sum<F4R>(dot);
@@ -262,7 +282,9 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     if (!XABL(g, 2)) {
       // the fragments of k-step s + 1 are requested before the six MFMAs of step s (one step ahead: with both waves of a SIMD in this phase
       // together nobody else covers the LDS round trip; all KS steps up front spill at KT = 8, dh = 64)
-      const int off0 = lr * RSQ + 8 * lh;
+      // k-step s = chunks 2s + lh of the row: the swizzle is an XOR, so step s is at off0 ^ 16s (row * RSQ has those bits clear when swizzled)
+      const int off0 = Cfg::qoff(lr, 8 * lh);
+      auto offs = [&](int s) { return Cfg::SWZ ? (off0 ^ (16 * s)) : (off0 + 16 * s); };
       bf16x8 fq[2], fo[2];
       fq[0] = lds_read_b128(Qf + off0); fq[1] = lds_read_b128(Qf + Q_PL + off0);
       fo[0] = lds_read_b128(Ob + off0); fo[1] = lds_read_b128(Ob + Q_PL + off0);
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       for (int s = 0; s < KS; s++) {
         bf16x8 nq[2], no[2];
         if (s + 1 < KS) {
-          const int off = off0 + 16 * (s + 1);
+          const int off = offs(s + 1);
           nq[0] = lds_read_b128(Qf + off); nq[1] = lds_read_b128(Qf + Q_PL + off);
           no[0] = lds_read_b128(Ob + off); no[1] = lds_read_b128(Ob + Q_PL + off);
         }
@@ -330,44 +352,62 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         }
       }
     }
-    // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS ----
-    if (!XABL(g, 8))
+    // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS   (g) dS -> LDS ----
+    // First ALL the vector work of the block (four bf16 splits; the dS copy for dQ from the same packed halves), then ONE matrix phase of 24
+    // MFMAs whose transposed fragment reads run one step ahead.  (Interleaved per half tile, each group of eight reads was waited for in
+    // full right before its six MFMAs, four times per block, with both waves of a SIMD in the same phase: this block cost 293 us of the
+    // kernel's 964 for 768 matrix cycles and ~130 vector instructions per wave.)
+    if (!XABL(g, 8)) {
+      bf16x8 ph[2], plo[2], shh[2], shl[2];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) {
-      __builtin_amdgcn_sched_barrier(0);
-      float pv[8], sv[8];
+      for (int s2 = 0; s2 < 2; s2++) {
+        float pv[8], sv[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { pv[e] = sacc[8 * s2 + e]; sv[e] = pacc[8 * s2 + e]; }
-      bf16x8 ph, plo, shh, shl;
-      x3_split8<EB>(pv, ph, plo);
-      x3_split8<EB>(sv, shh, shl);
-      // ---- (g) dS -> LDS [query][key], bf16 pair, from the SAME packed halves (word w of shh / shl = registers 2rp, 2rp + 1, rp = 4*s2 + w:
-      // two query rows of this lane's key).  Lanes 2i / 2i+1 hold adjacent keys: one packed pair (ds_write_b32) per register pair ----
+        for (int e = 0; e < 8; e++) { pv[e] = sacc[8 * s2 + e]; sv[e] = pacc[8 * s2 + e]; }
+        x3_split8<EB>(pv, ph[s2], plo[s2]);
+        x3_split8<EB>(sv, shh[s2], shl[s2]);
+      }
+      // (g) dS -> LDS [query][key], bf16 pair: word w of shh / shl = registers 2rp, 2rp + 1 (rp = 4*s2 + w), two query rows of this lane's
+      // key.  Lanes 2i / 2i+1 hold adjacent keys: one packed pair (ds_write_b32) per register pair
       if (!XABL(g, 16)) {
         const bool odd = lane & 1;
-        const uint4 hw = __builtin_bit_cast(uint4, shh), lw = __builtin_bit_cast(uint4, shl);
-        const unsigned hws[4] = {hw.x, hw.y, hw.z, hw.w}, lws[4] = {lw.x, lw.y, lw.z, lw.w};
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-          const int rp = 4 * s2 + w;
-          const int o = acc_row32(2 * rp + (odd ? 1 : 0), lh) * RSS + wave * 32 + (lr & ~1);
-          *reinterpret_cast<unsigned*>(Sb + o) = packed_rows_to_cols(hws[w], odd);
-          *reinterpret_cast<unsigned*>(Sb + S_PL + o) = packed_rows_to_cols(lws[w], odd);
+        for (int s2 = 0; s2 < 2; s2++) {
+          const uint4 hw = __builtin_bit_cast(uint4, shh[s2]), lw = __builtin_bit_cast(uint4, shl[s2]);
+          const unsigned hws[4] = {hw.x, hw.y, hw.z, hw.w}, lws[4] = {lw.x, lw.y, lw.z, lw.w};
+#pragma unroll
+          for (int w = 0; w < 4; w++) {
+            const int rp = 4 * s2 + w;
+            const int o = acc_row32(2 * rp + (odd ? 1 : 0), lh) * RSS + wave * 32 + (lr & ~1);
+            *reinterpret_cast<unsigned*>(Sb + o) = packed_rows_to_cols(hws[w], odd);
+            *reinterpret_cast<unsigned*>(Sb + S_PL + o) = packed_rows_to_cols(lws[w], odd);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      // steps (s2, n): A operands dO^T and Q^T of rows 16*s2 .. by transposed reads, B operands the packed halves above
+      // this lane's element (row 4*lh + qq, column 16*(gi & 1) + 4*pp) once; steps and the second row group (+ 8: swizzle bit 2 flips) are
+      // constant row offsets and one XOR of the 32-column bit
+      const int tb0 = Cfg::qoff(4 * lh + qq, 16 * (gi & 1) + 4 * pp);
+      const int tb1 = Cfg::SWZ ? (tb0 ^ 32) : (tb0 + 32);
+      auto frag = [&](int s2, int n, bf16x8 (&f)[4]) {
+        const int o0 = 16 * s2 * RSQ + (n ? tb1 : tb0);
+        const int o1 = (16 * s2 + 8) * RSQ + (Cfg::SWZ ? (n ? tb0 : tb1) : (n ? tb1 : tb0));
+        f[0] = join4(lds_read_tr16(Ob + o0), lds_read_tr16(Ob + o1));
+        f[1] = join4(lds_read_tr16(Ob + Q_PL + o0), lds_read_tr16(Ob + Q_PL + o1));
+        f[2] = join4(lds_read_tr16(Qb + o0), lds_read_tr16(Qb + o1));
+        f[3] = join4(lds_read_tr16(Qb + Q_PL + o0), lds_read_tr16(Qb + Q_PL + o1));
+      };
+      constexpr int NSTEP = 2 * NT;                       // step = s2 * NT + n
+      bf16x8 fc[4], fn[4];
+      frag(0, 0, fc);
 #pragma unroll
-      for (int n = 0; n < NT; n++) {
-        const int col = n * 32 + 16 * (gi & 1) + 4 * pp;
-        const int r0 = 16 * s2 + 4 * lh + qq;
-        const unsigned short* po_ = Ob + r0 * RSQ + col;
-        const bf16x8 oh = join4(lds_read_tr16(po_), lds_read_tr16(po_ + 8 * RSQ));
-        const bf16x8 ol = join4(lds_read_tr16(po_ + Q_PL), lds_read_tr16(po_ + Q_PL + 8 * RSQ));
-        dVT[n] = x3_mma<EB>(oh, ol, ph, plo, dVT[n]);
-        const unsigned short* pq_ = Qb + r0 * RSQ + col;
-        const bf16x8 qh = join4(lds_read_tr16(pq_), lds_read_tr16(pq_ + 8 * RSQ));
-        const bf16x8 ql = join4(lds_read_tr16(pq_ + Q_PL), lds_read_tr16(pq_ + Q_PL + 8 * RSQ));
-        dKT[n] = x3_mma<EB>(qh, ql, shh, shl, dKT[n]);
+      for (int step = 0; step < NSTEP; step++) {
+        const int s2 = step / NT, n = step % NT;
+        if (step + 1 < NSTEP) frag((step + 1) / NT, (step + 1) % NT, fn);
+        dVT[n] = x3_mma<EB>(fc[0], fc[1], ph[s2], plo[s2], dVT[n]);
+        dKT[n] = x3_mma<EB>(fc[2], fc[3], shh[s2], shl[s2], dKT[n]);
+        if (step + 1 < NSTEP) { fc[0] = fn[0]; fc[1] = fn[1]; fc[2] = fn[2]; fc[3] = fn[3]; }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -378,13 +418,13 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     for (int t = wave; t < 2 * CT && !XABL(g, 16); t += KT) {
       const int qh2 = t / CT, ct = t % CT;
       f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+      const unsigned short* ps0 = Sb + (qh2 * 16 + (lane & 15)) * RSS + 8 * gi;
+      const unsigned short* pk0 = Kb + Cfg::koff(8 * gi + qq, ct * 16 + 4 * pp);   // (the swizzle does not depend on ks, nor on the + 4 rows below)
 #pragma unroll 2
       for (int ks = 0; ks < KT; ks++) {
-        const unsigned short* ps = Sb + (qh2 * 16 + (lane & 15)) * RSS + ks * 32 + 8 * gi;
+        const unsigned short* ps = ps0 + ks * 32;
         const bf16x8 ah = lds_read_b128(ps), al = lds_read_b128(ps + S_PL);
-        const int krow = ks * 32 + 8 * gi + qq;
-        const int kcol = ct * 16 + 4 * pp;
-        const unsigned short* pk = Kb + krow * RSK + kcol;
+        const unsigned short* pk = pk0 + ks * 32 * RSK;
         const bf16x8 bh = join4(lds_read_tr16(pk), lds_read_tr16(pk + 4 * RSK));
         const bf16x8 bl = join4(lds_read_tr16(pk + K_PL), lds_read_tr16(pk + K_PL + 4 * RSK));
         a4 = x3_mma16<EB>(ah, al, bh, bl, a4);

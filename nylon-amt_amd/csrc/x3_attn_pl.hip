@@ -110,6 +110,9 @@ __global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kerne
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Lq = g.Lq, Lk = g.Lk, H = g.n_heads;
+#ifdef HFTT_PRIO_SKEW
+  if (NW >= 8 && wave < NW / 2) __builtin_amdgcn_s_setprio(HFTT_PRIO_SKEW);
+#endif
   const int nqb = (Lq + 31) / 32;
   const bool active = wave < nqb;                              // (wave-uniform) this wave owns query block `wave`
   const int qb = wave;
