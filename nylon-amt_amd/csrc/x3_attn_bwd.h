@@ -196,6 +196,13 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   constexpr int QCNT = (32 * F4R + NTHR - 1) / NTHR;
   float4 pq[QCNT], pdo[QCNT], po[QCNT];
   float2 pl[QCNT];
+  // (wave-uniform base pointers + 32-bit byte offsets per lane: one 24-bit multiply per row stride instead of 64-bit address arithmetic
+  // per tensor; a sequence's rows span Lq * ld * 4 bytes, far below 2^32)
+  const unsigned char* qbase = reinterpret_cast<const unsigned char*>(g.q + qofs);
+  const unsigned char* dobase = reinterpret_cast<const unsigned char*>(g.dout + oofs);
+  const unsigned char* obase = reinterpret_cast<const unsigned char*>(g.out + oofs);
+  const unsigned char* lbase = reinterpret_cast<const unsigned char*>(g.lse + sh * Lq * 2);
+  const unsigned ldq_b = (unsigned)g.ldq * 4u, ldo_b = (unsigned)g.ldo * 4u;
   auto qload = [&](int qb) {
     int tid_q = tid;
     asm volatile("" : "+v"(tid_q));                    // (row / column offsets are formed per call, not kept in registers across the loop)
@@ -205,17 +212,18 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       const int ic = i < 32 * F4R ? i : 32 * F4R - 1;
       const int row = ic / F4R, cs = ic % F4R;
       const int q = qb * 32 + row;
-      const int qc = q < Lq ? q : Lq - 1;          // clamped address: loads stay unconditional (rows past Lq are zeroed at consumption)
+      const unsigned qc = (unsigned)(q < Lq ? q : Lq - 1);   // clamped address: loads stay unconditional (rows past Lq are zeroed at consumption)
+      const unsigned rq = __umul24(qc, ldq_b), ro = __umul24(qc, ldo_b) + (unsigned)cs * 16u;
       if (PL) {                                    // (hi, lo) pairs of the four elements, carried in the same four registers
-        uint2 ph_, pl_;
-        pl_load4(g.q + qofs + (long)qc * g.ldq, cs, ph_, pl_);
+        const unsigned char* p_ = qbase + (rq + (unsigned)((cs >> 3) * 128 + (cs & 7) * 8));     // (pl_load4's layout)
+        const uint2 ph_ = *reinterpret_cast<const uint2*>(p_), pl_ = *reinterpret_cast<const uint2*>(p_ + 64);
         pq[u] = make_float4(__uint_as_float(ph_.x), __uint_as_float(ph_.y), __uint_as_float(pl_.x), __uint_as_float(pl_.y));
       } else {
-        pq[u] = *reinterpret_cast<const float4*>(g.q + qofs + (long)qc * g.ldq + cs * 4);
+        pq[u] = *reinterpret_cast<const float4*>(qbase + (rq + (unsigned)cs * 16u));
       }
-      pdo[u] = *reinterpret_cast<const float4*>(g.dout + oofs + (long)qc * g.ldo + cs * 4);
-      po[u] = *reinterpret_cast<const float4*>(g.out + oofs + (long)qc * g.ldo + cs * 4);
-      pl[u] = *reinterpret_cast<const float2*>(g.lse + (sh * Lq + qc) * 2);
+      pdo[u] = *reinterpret_cast<const float4*>(dobase + ro);
+      po[u] = *reinterpret_cast<const float4*>(obase + ro);
+      pl[u] = *reinterpret_cast<const float2*>(lbase + qc * 8u);
     }
   };
   qload(0);
@@ -338,7 +346,6 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         for (int e = 0; e < 4; e++) {
           const int r = 4 * j4 + e;
           float p = __builtin_amdgcn_exp2f((sacc[r] - rs_m[e]) * c2) * rs_i[e];      // p_k
-          if (pad_wave && !key_ok) p = 0.f;
           float pd = p, dp = pacc[r];
           if (DROP) {
             bool kept;
@@ -349,6 +356,15 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
           }
           sacc[r] = pd;
           pacc[r] = p * (dp - rs_d[e]);
+        }
+      }
+      // padding columns (keys past Lk: zero K rows, so S = 0 and p != 0): both products carry the factor p, so they are cleared here, by the
+      // one wave that has such columns, instead of by a select per score in every wave
+      if (pad_wave) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          sacc[r] = key_ok ? sacc[r] : 0.f;
+          pacc[r] = key_ok ? pacc[r] : 0.f;
         }
       }
     }
@@ -429,11 +445,13 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         const bf16x8 bl = join4(lds_read_tr16(pk + K_PL), lds_read_tr16(pk + K_PL + 4 * RSK));
         a4 = x3_mma16<EB>(ah, al, bh, bl, a4);
       }
+      const int q0 = qb * 32 + qh2 * 16 + gi * 4;
+      unsigned char* dq0 = reinterpret_cast<unsigned char*>(g.dq + dqofs);
+      const unsigned lddq_b = (unsigned)g.lddq * 4u;
+      const unsigned dqo = __umul24((unsigned)q0, lddq_b) + (unsigned)(ct * 16 + (lane & 15)) * 4u;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int q = qb * 32 + qh2 * 16 + gi * 4 + r;
-        if (q < Lq && !XABL(g, 32)) g.dq[dqofs + (long)q * g.lddq + ct * 16 + (lane & 15)] = a4[r];
-      }
+      for (int r = 0; r < 4; r++)
+        if (q0 + r < Lq && !XABL(g, 32)) *reinterpret_cast<float*>(dq0 + (dqo + (unsigned)r * lddq_b)) = a4[r];
     }
     // no barrier needed here: the next iteration's staging touches only Qf / Qb / Ob / statistics, which no wave reads in (i);
     // barrier (b) of the next iteration orders (i) before the next (g).
@@ -491,6 +509,11 @@ int launch_xb3(const hftt_attn_desc& d, hipStream_t st) {
 template <int DH, bool PL>
 int dispatch_xb(const hftt_attn_desc& d, hipStream_t st) {
   const int kt = (d.Lk + 31) / 32;
+  // the kernel addresses a sequence's rows with 32-bit byte offsets formed by a 24-bit multiply
+  if (d.ldq <= 0 || d.ldo <= 0 || d.ldq >= (1 << 22) || d.ldo >= (1 << 22) || d.lddq <= 0 || d.lddq >= (1 << 22) || (int64_t)d.Lq * d.lddq >= (1ll << 29) || (int64_t)d.Lq * d.ldq >= (1ll << 29) || (int64_t)d.Lq * d.ldo >= (1ll << 29)) {
+    hftt_set_error("x3_attn_bwd: row strides too large for 32-bit row offsets (Lq %d, ldq %lld, ldo %lld)", d.Lq, (long long)d.ldq, (long long)d.ldo);
+    return 1;
+  }
   if (kt <= 1) return launch_xb3<1, DH, PL>(d, st);
   if (kt <= 2) return launch_xb3<2, DH, PL>(d, st);
   if (kt <= 3) return launch_xb3<3, DH, PL>(d, st);

@@ -13,5 +13,5 @@ seed = int(sys.argv[3]) if len(sys.argv) > 3 else 2025
 import util
 _bm = util.build_model
 util.build_model = lambda cfg, s_, dropout=0.0: _bm(cfg, seed, dropout=dropout)      # (the test builds its model from seed 2025)
-curve, f1b, f1a, _ = T.train_device(T.WIDE, mode, drop, data, held, dev, 4, 3e-4)
+curve, f1b, f1a, _, auc = T.train_device(T.WIDE, mode, drop, data, held, dev, 4, 3e-4)
 print('RESULT', mode, 'seed', seed, 'planes=%s' % os.environ.get('HFTT_X3_PLANES', '1'), [round(c, 4) for c in curve], 'f1_B %.4f f1_A %.4f' % (f1b, f1a))
