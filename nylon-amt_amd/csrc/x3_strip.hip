@@ -90,8 +90,12 @@ __global__ __launch_bounds__(256) void x3_strip_pack_kernel(const float* __restr
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------------
 // the weight ring: stream fetched three slots ahead and ALWAYS (past the workgroup's last slot it wraps to the head: three harmless
-// extra slots, drained before the kernel ends), so "at least eight vector-memory instructions were issued after the fill of the slot
-// about to be consumed" holds at every slot boundary and the wait is the constant s_waitcnt vmcnt(8) (see strip_gemm2.hip).
+// extra slots, drained before the kernel ends).  The barrier that opens slot s vouches for slot s + 1 (not s): every wave has waited for its
+// quarter of fill(s + 1) -- "at least four vector-memory instructions were issued after it" (fill(s + 2)) holds at every slot boundary, so
+// the wait is the constant s_waitcnt vmcnt(4) -- which lets the last two steps of slot s already request the first four fragments of slot
+// s + 1 (x3_slot_*: `pre`).  (With the barrier vouching for slot s itself those four reads came right behind it: their LDS round trip, a few
+// hundred cycles with nothing to issue, was paid four times per hidden tile by a wave alone on its SIMD.)  The refill issued in slot s
+// overwrites the buffer of slot s - 1, which every wave has left before it passed the barrier of slot s.
 struct XPipe {
   const unsigned short* w;
   int S;                        // slots per block
@@ -107,8 +111,10 @@ struct XPipe {
     advance();
   }
   __device__ __forceinline__ void begin_slot() {
-    if (!nobar) { HFTT_WAITVM(8); __builtin_amdgcn_s_barrier(); }
+    if (!nobar) { HFTT_WAITVM(4); __builtin_amdgcn_s_barrier(); }
   }
+  // before the first slot of the kernel: slots 0 AND 1 complete in every wave (fill(2) may still be in flight)
+  __device__ __forceinline__ void prologue_sync() { HFTT_WAITVM(4); __builtin_amdgcn_s_barrier(); }
   template <int BUF>
   __device__ __forceinline__ void refill() {      // BUF: the slot being consumed; the refill goes to (BUF + 3) % 4
     if (!nofill) glds16x4(src_of(fill_pos), ring + (unsigned)((BUF + FILL_AHEAD) & (NSLOT - 1)) * SLOT_BYTES + (unsigned)wave * 4096u);
@@ -178,20 +184,29 @@ __device__ __forceinline__ int chunk_off(int ch) { return (ch >> 1) * 32 + (ch &
 // One ring slot against ONE strip chunk: fragments 2t (hi) and 2t + 1 (lo) of output tile t -> acc[t] += lo.x_hi + hi.x_lo + hi.x_hi.
 // Four fragment reads are in flight ahead of the MFMAs; side(i) (i = 0 .. 23) is called behind MFMA i, so the slot's memory and
 // conversion work sits in program order BETWEEN the MFMAs (a wave alone on its SIMD issues in order).
+// pre: fragments 0 .. 3 of THIS slot on entry (requested by the previous slot, or by slot_head() at the head of a block), of the NEXT slot
+// (`next`, already vouched for by this slot's barrier: XPipe) on exit.
+struct XPre { bf16x8 f[4]; };
+__device__ __forceinline__ void slot_head(const unsigned char* slot, XPre& pre) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) pre.f[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
+}
 template <int E, typename G>
-__device__ __forceinline__ void x3_slot_tiles(const unsigned char* slot, const XChunk& x, f32x16 (&acc)[8], G&& side) {
+__device__ __forceinline__ void x3_slot_tiles(const unsigned char* slot, const unsigned char* next, XPre& pre, const XChunk& x, f32x16 (&acc)[8], G&& side) {
   bf16x8 fr[16];
 #pragma unroll
-  for (int i = 0; i < 4; i++) fr[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
+  for (int i = 0; i < 4; i++) fr[i] = pre.f[i];
   const bf16x8 xh = __builtin_bit_cast(bf16x8, x.a), xl = __builtin_bit_cast(bf16x8, x.b);
   static_for<8>([&](auto t_c) __attribute__((always_inline)) {
     constexpr int t = decltype(t_c)::value;
     acc[t] = X3<E>::mma(fr[2 * t + 1], xh, acc[t]);
     side(std::integral_constant<int, 3 * t>{});
     if (2 * t + 4 < 16) fr[2 * t + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 4) * 1024);
+    else pre.f[2 * t + 4 - 16] = *reinterpret_cast<const bf16x8*>(next + (2 * t + 4 - 16) * 1024);
     if (E != X3_BF16H) acc[t] = X3<E>::mma(fr[2 * t], xl, acc[t]);      // (X3_BF16H: the strip is a gradient, hi half only)
     side(std::integral_constant<int, 3 * t + 1>{});
     if (2 * t + 5 < 16) fr[2 * t + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 5) * 1024);
+    else pre.f[2 * t + 5 - 16] = *reinterpret_cast<const bf16x8*>(next + (2 * t + 5 - 16) * 1024);
     acc[t] = X3<E>::mma(fr[2 * t], xh, acc[t]);
     side(std::integral_constant<int, 3 * t + 2>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -199,19 +214,21 @@ __device__ __forceinline__ void x3_slot_tiles(const unsigned char* slot, const X
 }
 // One ring slot against EIGHT strip chunks (tile-major fc_1 half tile): fragments 2q (hi), 2q + 1 (lo) of chunk x[q] -> one accumulator
 template <int E, int OFF, typename G>
-__device__ __forceinline__ void x3_slot_chunks(const unsigned char* slot, const XChunk (&x)[16], f32x16& acc, G&& side) {
+__device__ __forceinline__ void x3_slot_chunks(const unsigned char* slot, const unsigned char* next, XPre& pre, const XChunk (&x)[16], f32x16& acc, G&& side) {
   bf16x8 fr[16];
 #pragma unroll
-  for (int i = 0; i < 4; i++) fr[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
+  for (int i = 0; i < 4; i++) fr[i] = pre.f[i];
   static_for<8>([&](auto q_c) __attribute__((always_inline)) {
     constexpr int q = decltype(q_c)::value;
     const bf16x8 xh = __builtin_bit_cast(bf16x8, x[OFF + q].a), xl = __builtin_bit_cast(bf16x8, x[OFF + q].b);
     acc = X3<E>::mma(fr[2 * q + 1], xh, acc);
     side(std::integral_constant<int, 3 * q>{});
     if (2 * q + 4 < 16) fr[2 * q + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 4) * 1024);
+    else pre.f[2 * q + 4 - 16] = *reinterpret_cast<const bf16x8*>(next + (2 * q + 4 - 16) * 1024);
     if (E != X3_BF16H) acc = X3<E>::mma(fr[2 * q], xl, acc);
     side(std::integral_constant<int, 3 * q + 1>{});
     if (2 * q + 5 < 16) fr[2 * q + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 5) * 1024);
+    else pre.f[2 * q + 5 - 16] = *reinterpret_cast<const bf16x8*>(next + (2 * q + 5 - 16) * 1024);
     acc = X3<E>::mma(fr[2 * q], xh, acc);
     side(std::integral_constant<int, 3 * q + 2>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
   P.fill<0>(); P.fill<1>(); P.fill<2>();
   static_assert(FILL_AHEAD == 3, "prologue fills");
   wait_lgkm0();
-  __builtin_amdgcn_s_barrier();                       // the parameter rows in LDS are read (by every wave) before the first slot's barrier
+  P.prologue_sync();                       // the parameter rows in LDS are read (by every wave) before the first slot's barrier
   chunk_convert<E>(xr[0]);
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
@@ -412,6 +429,8 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[ot][q] = b[q];
       }
+      XPre pre;
+      slot_head(abase, pre);                          // (every pass starts at ring buffer 0; inside the pass the slots hand `pre` on)
       for (int kc = 0; kc < KCH; kc++) {
         // the chunk set in the registers at this step is k chunk kc; as a chunk is consumed its registers receive the same chunk position
         // of the NEXT step's set (next k chunk, or k chunk 0 of the next pass / block).  KCH == 1: the set is re-used by every pass of
@@ -425,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
           constexpr int c = decltype(c_c)::value;
           constexpr int BUF = c & 3;
           P.begin_slot();
-          x3_slot_tiles<E>(abase + BUF * SLOT_BYTES, xr[c], acc, [&](auto i_c) __attribute__((always_inline)) {
+          x3_slot_tiles<E>(abase + BUF * SLOT_BYTES, abase + ((BUF + 1) & 3) * SLOT_BYTES, pre, xr[c], acc, [&](auto i_c) __attribute__((always_inline)) {
             constexpr int i = decltype(i_c)::value;
             if (i == 1) P.template refill<BUF>();
             if (i == 5 && c > 0) { if (reload) chunk_load(xr[c - 1], nsrc + chunk_off(c - 1)); }
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
   P.fill<0>(); P.fill<1>(); P.fill<2>();
   static_assert(FILL_AHEAD == 3, "prologue fills");
   wait_lgkm0();
-  __builtin_amdgcn_s_barrier();
+  P.prologue_sync();
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = hftt_keep_scale(g.drop_p);
@@ -545,6 +564,8 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
     const float* prm_b = prm + zero;
 #pragma unroll
     for (int c = 0; c < 16; c++) chunk_convert<E>(xr[c]);       // this block's strip (loaded during the previous block's last tile)
+    XPre pre;
+    slot_head(abase, pre);                                      // (every block starts at ring buffer 0)
 
     // a run-time loop over tile PAIRS (the ring buffers repeat every two tiles): fully unrolled, hipcc forms every tile's store / residual
     // address up front and spills them
@@ -563,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
       }
       float r[16];
       P.begin_slot();
-      x3_slot_chunks<E, 0>(abase + BA * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+      x3_slot_chunks<E, 0>(abase + BA * SLOT_BYTES, abase + BB * SLOT_BYTES, pre, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<BA>();
         if (i == 4 && HR) {
@@ -575,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
         if (LAST && i % 3 == 2) chunk_load(xr[i / 3], xb + lane_tok(nxt < nblk ? nxt : blk) * g.ldx + 16 * hb + chunk_off(i / 3));
       });
       P.begin_slot();
-      x3_slot_chunks<E, 8>(abase + BB * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+      x3_slot_chunks<E, 8>(abase + BB * SLOT_BYTES, abase + ((BB + 1) & 3) * SLOT_BYTES, pre, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<BB>();
         if (LAST && i % 3 == 2) chunk_load(xr[8 + i / 3], xb + lane_tok(nxt < nblk ? nxt : blk) * g.ldx + 16 * hb + chunk_off(8 + i / 3));
@@ -652,7 +673,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
   P.fill<0>(); P.fill<1>(); P.fill<2>();
   static_assert(FILL_AHEAD == 3, "prologue fills");
   wait_lgkm0();
-  __builtin_amdgcn_s_barrier();
+  P.prologue_sync();
 
   const uint32_t thr = hftt_keep_thr(g.drop_p);
   const float inv_keep = hftt_keep_scale(g.drop_p);
@@ -684,6 +705,8 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
     float gnext[16];                                  // mode 1: stored hidden (the gate) of the next tile
     if (MODE == 1) { if (HH) load16h(gtb16 + tokc * g.ldg + 16 * hb, gnext); else load16f(gtb + tokc * g.ldg + 16 * hb, gnext); }
 
+    XPre pre;
+    slot_head(abase, pre);
     // (a run-time loop: every hidden tile uses ring buffers 0..3 in order, and the body is ~100 MFMAs -- unrolled 16 times the kernel was
     // 14,000 instructions, far beyond the instruction cache)
     for (int t = 0; t < PT; t++) {
@@ -702,7 +725,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       }
       P.begin_slot();
       if (!XDBG(g, 256))
-      x3_slot_chunks<E, 0>(abase + 0 * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+      x3_slot_chunks<E, 0>(abase + 0 * SLOT_BYTES, abase + 1 * SLOT_BYTES, pre, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<0>();
         if (i == 6 && MODE == 1 && t + 1 < PT) {
@@ -711,7 +734,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       });
       P.begin_slot();
       if (!XDBG(g, 256))
-      x3_slot_chunks<E, 8>(abase + 1 * SLOT_BYTES, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+      x3_slot_chunks<E, 8>(abase + 1 * SLOT_BYTES, abase + 2 * SLOT_BYTES, pre, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<1>();
       });
@@ -740,7 +763,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       // ---- second GEMM, K-slice t (u = 0, 1); the hidden tile's stores ride behind the first MFMAs ----
       P.begin_slot();
       if (!XDBG(g, 512))
-      x3_slot_tiles<E>(abase + 2 * SLOT_BYTES, hf[0], yacc, [&](auto i_c) __attribute__((always_inline)) {
+      x3_slot_tiles<E>(abase + 2 * SLOT_BYTES, abase + 3 * SLOT_BYTES, pre, hf[0], yacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<2>();
         if (i == 4 && st_h) {
@@ -750,7 +773,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
       });
       P.begin_slot();
       if (!XDBG(g, 512))
-      x3_slot_tiles<E>(abase + 3 * SLOT_BYTES, hf[1], yacc, [&](auto i_c) __attribute__((always_inline)) {
+      x3_slot_tiles<E>(abase + 3 * SLOT_BYTES, abase + 0 * SLOT_BYTES, pre, hf[1], yacc, [&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         if (i == 1) P.template refill<3>();
       });
