@@ -224,6 +224,79 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const hftt_ln_bwd_desc g) {
   }
 }
 
+// N = 64 (the reference's default width): a wave takes FOUR rows per step -- 16 lanes x 4 elements per row, one 16-byte (fp32) or 8-byte
+// (bf16) access per lane and tensor, a 16-lane reduction -- instead of one row of 4-byte accesses and a 64-lane reduction: the row-per-wave
+// form above sat at 3.4 TB/s at this width (13 launches, 0.66 ms of the tiny configuration's 5.4 ms step).
+__global__ __launch_bounds__(256) void ln_bwd64_kernel(const hftt_ln_bwd_desc g) {
+  constexpr int N = 64;
+  __shared__ float red[4][2][N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 4, c0 = (lane & 15) * 4;
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = hftt_keep_scale(g.drop_p);
+  const bool dy_bf = g.io_flags & HFTT_LNB_DY_BF16, dr_bf = g.io_flags & HFTT_LNB_DR_BF16, r_bf = g.io_flags & HFTT_LNB_R_BF16;
+  const float4 gm = *reinterpret_cast<const float4*>(g.gamma + c0);
+  const float gam[4] = {gm.x, gm.y, gm.z, gm.w};
+  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long row0 = ((long)blockIdx.x * 4 + wave) * 4; row0 < g.M; row0 += (long)gridDim.x * 16) {
+    const long row = row0 + sub;
+    const bool ok = row < g.M;                       // (uniform over the 16 lanes of a row)
+    const long rc = ok ? row : (long)g.M - 1;
+    const long base = rc * N + c0;
+    const float4 a = hftt_load4(g.dy, dy_bf, base);
+    const float4 b = hftt_load4(g.r, r_bf, base);
+    const float mean = g.mean[rc], rstd = g.rstd[rc];
+    const float dy[4] = {ok ? a.x : 0.f, ok ? a.y : 0.f, ok ? a.z : 0.f, ok ? a.w : 0.f}, r[4] = {b.x, b.y, b.z, b.w};
+    float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      xh[e] = (r[e] - mean) * rstd;
+      gg[e] = dy[e] * gam[e];
+      s1 += gg[e];
+      s2 += gg[e] * xh[e];
+      dg[e] += dy[e] * xh[e];
+      db[e] += dy[e];
+    }
+    s1 = group_sum<16>(s1) * (1.0f / N);
+    s2 = group_sum<16>(s2) * (1.0f / N);
+    float o[4], od[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      o[e] = rstd * (gg[e] - s1 - xh[e] * s2);
+      od[e] = o[e];
+      if (g.dr_drop != nullptr && g.drop_p > 0.f)
+        od[e] = hftt_keep(g.drop_seed, g.drop_site, (uint64_t)(base + e), thr) ? o[e] * inv_keep : 0.f;
+    }
+    if (ok) {
+      hftt_store4(g.dr, dr_bf, base, o[0], o[1], o[2], o[3]);
+      if (g.dr_drop != nullptr) {
+        if (g.drop_bf16) {
+          uint2 u;
+          u.x = f2bf(od[0]) | ((unsigned)f2bf(od[1]) << 16); u.y = f2bf(od[2]) | ((unsigned)f2bf(od[3]) << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.dr_drop) + base) = u;
+        } else {
+          *reinterpret_cast<float4*>(g.dr_drop + base) = make_float4(od[0], od[1], od[2], od[3]);
+        }
+      }
+    }
+  }
+  // the four row groups of the wave hold partial sums of the same columns
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    dg[e] += __shfl_xor(dg[e], 16); dg[e] += __shfl_xor(dg[e], 32);
+    db[e] += __shfl_xor(db[e], 16); db[e] += __shfl_xor(db[e], 32);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) { red[wave][0][c0 + e] = dg[e]; red[wave][1][c0 + e] = db[e]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    const int which = i / N, c = i % N;
+    g.ws[(long)blockIdx.x * 2 * N + i] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
 // N = 256 with dy, r, dr (and the dropped copy) all stored as bf16 -- the bf16 gradient stream of the strip plans.  The row-per-wave form
 // above moves 8 bytes per lane and per tensor and goes through a 64-lane reduction for every row, one row at a time: it sat at 3.7 TB/s.
 // Here a wave takes FOUR rows per step (16 lanes x 16 elements per row: two 16-byte loads per lane and tensor, a 16-lane reduction) and the
@@ -740,6 +813,8 @@ extern "C" int hftt_ln_bwd(const hftt_ln_bwd_desc* d, void* stream) {
   if (fast) hipLaunchKernelGGL(ln_bwd256_bf16_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   else if (d->N == 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   else if (d->N == 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  else if (((((uintptr_t)d->dy | (uintptr_t)d->r | (uintptr_t)d->dr | (uintptr_t)d->dr_drop | (uintptr_t)d->gamma) & 15) == 0))
+    hipLaunchKernelGGL(ln_bwd64_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   HFTT_CHECK_LAUNCH("ln_bwd");
   return 0;

@@ -46,18 +46,19 @@ __device__ __forceinline__ void pl_vals8(const bf16x8& hi, const bf16x8& lo, flo
 template <int KT, int DH>
 struct XbCfg {
   static constexpr int LKP = KT * 32;
-  // LDS images, dh = 64: UNPADDED rows of 128 bytes whose 16-byte chunks are XOR-swizzled by row bits, chosen (exhaustive search over linear
-  // maps, bank rule of MI355X_MICROARCH.md, LDS) so that every read of the loop is conflict-free: the row reads (ds_read_b128: 16 rows x one
-  // chunk per lane group) AND the transposed reads (ds_read_b64_tr_b16: four / eight rows x 64 / 32 bytes per 32 lanes) of the same image.
-  // The padded rows before (Q / dO 144 bytes, K 192 bytes, dS + 16 bytes) were 2-way on the transposed reads of Q^T / dO^T and K and on the
-  // dS row reads: SQ_LDS_BANK_CONFLICT = 37 % of SQ_LDS_IDX_ACTIVE (profiles/r04b_attn_bwd_lds.txt).  dh = 32 keeps padded rows.
-  static constexpr bool SWZ = DH == 64;
-  static constexpr int RSK = (DH == 64) ? 64 : 32;    // K image (bf16 pair) for dQ: transposed reads only
-  static constexpr int RSQ = SWZ ? DH : DH + 8;       // Q / dO blocks: row reads (scores, dP) and transposed reads (dK, dV)
-  static constexpr int RSS = SWZ ? LKP + 16 : LKP + 8;   // dS block [query][key]: row reads, 32 bytes mod 256 per row
-  // chunk ^= swizzle(row).  Q / dO: bit 0 <- row bit 1, bit 1 <- row bit 2, bit 2 <- row bits 1 ^ 3.   K: bit 1 <- row bit 1, bit 2 <- row bit 3
-  static __device__ __forceinline__ int qsw(int row) { return SWZ ? (((row >> 1) & 3) | ((((row >> 1) ^ (row >> 3)) & 1) << 2)) : 0; }
-  static __device__ __forceinline__ int ksw(int row) { return SWZ ? ((row & 2) | (((row >> 3) & 1) << 2)) : 0; }
+  // LDS images: UNPADDED rows (dh halves) whose 16-byte chunks are XOR-swizzled by row bits, chosen (exhaustive search over linear maps, bank
+  // rule of MI355X_MICROARCH.md, LDS) so that every read of the loop is conflict-free: the row reads (ds_read_b128: 16 rows x one chunk per
+  // lane group) AND the transposed reads (ds_read_b64_tr_b16: four / eight rows x 64 / 32 bytes per 32 lanes) of the same image.  The
+  // padded rows before (Q / dO + 16 bytes, K 192 / 64 bytes, dS + 16 bytes) were 2-way on the transposed reads of Q^T / dO^T and K and on
+  // the dS row reads: SQ_LDS_BANK_CONFLICT = 37 % of SQ_LDS_IDX_ACTIVE at dh = 64 (profiles/r04b_attn_bwd_lds.txt).
+  static constexpr int RSK = DH;                      // K image (bf16 pair) for dQ: transposed reads only
+  static constexpr int RSQ = DH;                      // Q / dO blocks: row reads (scores, dP) and transposed reads (dK, dV)
+  static constexpr int RSS = LKP + 16;                // dS block [query][key]: row reads, 32 bytes mod 256 per row
+  // chunk ^= swizzle(row).  dh = 64 -- Q / dO: bit 0 <- row bit 1, bit 1 <- row bit 2, bit 2 <- row bits 1 ^ 3;  K: bit 1 <- row bit 1,
+  // bit 2 <- row bit 3.   dh = 32 (four chunks per row) -- Q / dO: bits 0, 1 <- row bits 2, 3;  K: bit 1 <- row bit 3
+  static __device__ __forceinline__ int qsw(int row) { return DH == 64 ? (((row >> 1) & 3) | ((((row >> 1) ^ (row >> 3)) & 1) << 2)) : ((row >> 2) & 3); }
+  static __device__ __forceinline__ int ksw(int row) { return DH == 64 ? ((row & 2) | (((row >> 3) & 1) << 2)) : (((row >> 3) & 1) << 1); }
+  static constexpr int R8X = DH == 64 ? 32 : 16;      // what row + 8 (row bit 3) does to a Q / dO column offset
   // element offset (in halves) of column `col` (a multiple of 4) of a row
   static __device__ __forceinline__ int qoff(int row, int col) { return row * RSQ + ((((col >> 3) ^ qsw(row)) << 3) | (col & 7)); }
   static __device__ __forceinline__ int koff(int row, int col) { return row * RSK + ((((col >> 3) ^ ksw(row)) << 3) | (col & 7)); }
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       // together nobody else covers the LDS round trip; all KS steps up front spill at KT = 8, dh = 64)
       // k-step s = chunks 2s + lh of the row: the swizzle is an XOR, so step s is at off0 ^ 16s (row * RSQ has those bits clear when swizzled)
       const int off0 = Cfg::qoff(lr, 8 * lh);
-      auto offs = [&](int s) { return Cfg::SWZ ? (off0 ^ (16 * s)) : (off0 + 16 * s); };
+      auto offs = [&](int s) { return off0 ^ (16 * s); };
       bf16x8 fq[2], fo[2];
       fq[0] = lds_read_b128(Qf + off0); fq[1] = lds_read_b128(Qf + Q_PL + off0);
       fo[0] = lds_read_b128(Ob + off0); fo[1] = lds_read_b128(Ob + Q_PL + off0);
@@ -405,10 +406,9 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       // this lane's element (row 4*lh + qq, column 16*(gi & 1) + 4*pp) once; steps and the second row group (+ 8: swizzle bit 2 flips) are
       // constant row offsets and one XOR of the 32-column bit
       const int tb0 = Cfg::qoff(4 * lh + qq, 16 * (gi & 1) + 4 * pp);
-      const int tb1 = Cfg::SWZ ? (tb0 ^ 32) : (tb0 + 32);
       auto frag = [&](int s2, int n, bf16x8 (&f)[4]) {
-        const int o0 = 16 * s2 * RSQ + (n ? tb1 : tb0);
-        const int o1 = (16 * s2 + 8) * RSQ + (Cfg::SWZ ? (n ? tb0 : tb1) : (n ? tb1 : tb0));
+        const int o0 = 16 * s2 * RSQ + (tb0 ^ (32 * n));
+        const int o1 = (16 * s2 + 8) * RSQ + (tb0 ^ (32 * n) ^ Cfg::R8X);
         f[0] = join4(lds_read_tr16(Ob + o0), lds_read_tr16(Ob + o1));
         f[1] = join4(lds_read_tr16(Ob + Q_PL + o0), lds_read_tr16(Ob + Q_PL + o1));
         f[2] = join4(lds_read_tr16(Qb + o0), lds_read_tr16(Qb + o1));

@@ -249,6 +249,31 @@ def test_ln_bwd_all_bf16_four_rows_per_wave(dev, M, p):
         assert torch.equal((drd == 0).cpu() | (mask == 1), torch.ones(M, N, dtype=torch.bool))      # exactly the masked elements are zero
 
 
+@pytest.mark.parametrize('M,p,bf', [(1234, 0.2, False), (4099, 0.0, False), (3, 0.1, False), (17, 0.1, True), (65536, 0.1, True)])
+def test_ln_bwd_width_64_four_rows_per_wave(dev, M, p, bf):
+    """N = 64 (the reference's default width): the four-rows-per-wave kernel, ragged M included (M % 4 != 0, M < 16), fp32 and bf16 storage,
+    against the fp64 LayerNorm backward of the same (rounded) operands."""
+    ops = _ops()
+    N = 64
+    g = torch.Generator().manual_seed(M)
+    r = torch.randn(M, N, generator=g) * 2 + 0.5; dy = torch.randn(M, N, generator=g); gam = torch.randn(N, generator=g)
+    if bf:
+        r, dy = r.to(torch.bfloat16), dy.to(torch.bfloat16)
+    r64 = r.double().requires_grad_(True); g64 = gam.double().requires_grad_(True); b64 = torch.zeros(N, dtype=torch.float64, requires_grad=True)
+    (F.layer_norm(r64, (N,), g64, b64, 1e-5) * dy.double()).sum().backward()
+    mean = r.double().mean(1); rstd = 1.0 / torch.sqrt(r.double().var(1, unbiased=False) + 1e-5)
+    site, seed = 5, 1234
+    kw = dict(drop_dtype=torch.bfloat16, dr_dtype=torch.bfloat16) if bf else {}
+    dr, drd, dg, db = ops.ln_bwd(dy.to(dev), r.to(dev), mean.float().to(dev), rstd.float().to(dev), gam.to(dev), drop_p=p, drop_site=site, drop_seed=seed, **kw)
+    tol = 6e-3 if bf else 1e-5
+    assert rel_err(dr, r64.grad) < tol
+    assert rel_err(dg, g64.grad) < 2e-5 and rel_err(db, b64.grad) < 2e-5
+    if p > 0:
+        mask = keep_mask_t(seed, site, (M, N), p).double()
+        assert rel_err(drd, r64.grad * mask * keep_scale(p)) < tol
+        assert torch.equal((drd == 0).cpu() | (mask == 1), torch.ones(M, N, dtype=torch.bool))
+
+
 def test_colsum_and_adam(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(1)
