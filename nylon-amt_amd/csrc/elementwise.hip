@@ -399,6 +399,110 @@ __global__ __launch_bounds__(256) void ln_bwd256_bf16_kernel(const hftt_ln_bwd_d
   }
 }
 
+// N = 256, any mix of fp32 / bf16 storage (the x3 plans: fp32 dy and dr, bf16 saved sums): R rows per wave, the lane's columns taken as
+// groups of four at a stride of 4 * (64 / R) so that the lanes of a row cover CONTIGUOUS bytes with every access; PF: the next step's rows
+// are in flight while the current step is computed.  Measured at 262,144 rows in that storage mix (tools/bench_ln_bwd.py): the row-per-wave
+// kernel above (64-lane reduction with four v_readlane per sum) 5.1 TB/s, R = 4 4.2 .. 4.4 TB/s (16 elements per lane in four arrays:
+// registers cost it the occupancy that hides the latency), R = 2 5.3 TB/s with or without PF -- the form instantiated.
+template <int R, bool PF>
+__global__ __launch_bounds__(256) void ln_bwd256_rows_kernel(const hftt_ln_bwd_desc g) {
+  constexpr int N = 256, L = 64 / R, G = N / (4 * L), E = 4 * G;      // lanes per row, float4 groups and elements per lane
+  __shared__ float red[4 * R][2][N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / L, cl = lane % L;
+  const uint32_t thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep = hftt_keep_scale(g.drop_p);
+  const bool drop = g.dr_drop != nullptr && g.drop_p > 0.f;
+  const bool dy_bf = g.io_flags & HFTT_LNB_DY_BF16, dr_bf = g.io_flags & HFTT_LNB_DR_BF16, r_bf = g.io_flags & HFTT_LNB_R_BF16;
+  float gam[E], dg[E], db[E];
+#pragma unroll
+  for (int k = 0; k < G; k++) {
+    const float4 t = *reinterpret_cast<const float4*>(g.gamma + cl * 4 + 4 * L * k);
+    gam[4 * k] = t.x; gam[4 * k + 1] = t.y; gam[4 * k + 2] = t.z; gam[4 * k + 3] = t.w;
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) { dg[e] = 0.f; db[e] = 0.f; }
+  const long ngrp = ((long)g.M + R - 1) / R;
+  const long stride = (long)gridDim.x * 4;
+  long grp = (long)blockIdx.x * 4 + wave;
+  float4 yv[G], rv[G];
+  float mean, rstd;
+  auto load = [&](long gq) {
+    const long row = gq * R + sub;
+    const long rc = row < g.M ? row : (long)g.M - 1;       // clamped: loads stay unconditional
+    const long base = rc * N + cl * 4;
+#pragma unroll
+    for (int k = 0; k < G; k++) { yv[k] = hftt_load4(g.dy, dy_bf, base + 4 * L * k); rv[k] = hftt_load4(g.r, r_bf, base + 4 * L * k); }
+    mean = g.mean[rc]; rstd = g.rstd[rc];
+  };
+  if (PF && grp < ngrp) load(grp);
+  for (; grp < ngrp; grp += stride) {
+    if (!PF) load(grp);
+    float dy[E], xh[E];
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+      dy[4 * k] = yv[k].x; dy[4 * k + 1] = yv[k].y; dy[4 * k + 2] = yv[k].z; dy[4 * k + 3] = yv[k].w;
+      xh[4 * k] = rv[k].x; xh[4 * k + 1] = rv[k].y; xh[4 * k + 2] = rv[k].z; xh[4 * k + 3] = rv[k].w;
+    }
+    const float mu = mean, rs = rstd;
+    const long row = grp * R + sub;
+    if (PF) {
+      const long nxt = grp + stride;
+      load(nxt < ngrp ? nxt : ngrp - 1);                   // the next step's rows are in flight while this step is computed
+    }
+    const bool valid = row < g.M;
+    float gg[E], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (!valid) dy[e] = 0.f;
+      xh[e] = (xh[e] - mu) * rs;
+      gg[e] = dy[e] * gam[e];
+      s1 += gg[e];
+      s2 += gg[e] * xh[e];
+      dg[e] += dy[e] * xh[e];
+      db[e] += dy[e];
+    }
+    s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
+    if (L == 32) { s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16); }
+    s1 *= (1.0f / N); s2 *= (1.0f / N);
+    float o[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) o[e] = rs * (gg[e] - s1 - xh[e] * s2);
+    if (valid) {
+      const long base = row * N + cl * 4;
+#pragma unroll
+      for (int k = 0; k < G; k++) hftt_store4(g.dr, dr_bf, base + 4 * L * k, o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+      if (g.dr_drop != nullptr) {
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+          float d4[4] = {o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]};
+          if (drop) {
+            const uint32_t k4 = hftt_keep_quad(g.drop_seed, g.drop_site, (uint64_t)(base + 4 * L * k) >> 2, thr);      // one hash quad (hftt_keep)
+#pragma unroll
+            for (int f = 0; f < 4; f++) d4[f] = ((k4 >> f) & 1u) ? d4[f] * inv_keep : 0.f;
+          }
+          hftt_store4(g.dr_drop, g.drop_bf16 != 0, base + 4 * L * k, d4[0], d4[1], d4[2], d4[3]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < G; k++)
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      red[wave * R + sub][0][cl * 4 + 4 * L * k + f] = dg[4 * k + f];
+      red[wave * R + sub][1][cl * 4 + 4 * L * k + f] = db[4 * k + f];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    const int which = i / N, c = i % N;
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4 * R; q++) acc += red[q][which][c];                    // fixed order: reproducible
+    g.ws[(long)blockIdx.x * 2 * N + i] = acc;
+  }
+}
+
 // out[c] = beta*out[c] + sum_w ws[w][c]   (c over 2N entries: dgamma then dbeta)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int n_wg, int N, float* dgamma, float* dbeta, float beta) {
   __shared__ float red[16][17];
@@ -811,6 +915,8 @@ extern "C" int hftt_ln_bwd(const hftt_ln_bwd_desc* d, void* stream) {
   const bool fast = d->N == 256 && (d->io_flags & all_bf) == all_bf && (d->dr_drop == nullptr || d->drop_bf16) &&
                     ((((uintptr_t)d->dy | (uintptr_t)d->r | (uintptr_t)d->dr | (uintptr_t)d->dr_drop) & 15) == 0);
   if (fast) hipLaunchKernelGGL(ln_bwd256_bf16_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
+  else if (d->N == 256 && ((((uintptr_t)d->dy | (uintptr_t)d->r | (uintptr_t)d->dr | (uintptr_t)d->dr_drop | (uintptr_t)d->gamma) & 15) == 0))
+    hipLaunchKernelGGL((ln_bwd256_rows_kernel<2, true>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   else if (d->N == 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   else if (d->N == 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, *d);
   else if (((((uintptr_t)d->dy | (uintptr_t)d->r | (uintptr_t)d->dr | (uintptr_t)d->dr_drop | (uintptr_t)d->gamma) & 15) == 0))
