@@ -750,7 +750,12 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
         for (int q = 0; q < 16; q++) v[q] = gcur[q] > 0.f ? hacc[q] * g.gate_scale : 0.f;
       }
       XChunk hf[2];
-      {
+      if (XDBG(g, 1024)) {                           // (timing only: the raw accumulator bits as the operand -- no activation, dropout or split)
+        hf[0].a = u4v{__float_as_uint(hacc[0]), __float_as_uint(hacc[1]), __float_as_uint(hacc[2]), __float_as_uint(hacc[3])};
+        hf[0].b = u4v{__float_as_uint(hacc[4]), __float_as_uint(hacc[5]), __float_as_uint(hacc[6]), __float_as_uint(hacc[7])};
+        hf[1].a = u4v{__float_as_uint(hacc[8]), __float_as_uint(hacc[9]), __float_as_uint(hacc[10]), __float_as_uint(hacc[11])};
+        hf[1].b = u4v{__float_as_uint(hacc[12]), __float_as_uint(hacc[13]), __float_as_uint(hacc[14]), __float_as_uint(hacc[15])};
+      } else {
         bf16x8 hi, lo;
         x3_split8<E>(v, hi, lo);
         hf[0].a = __builtin_bit_cast(u4v, hi); hf[0].b = __builtin_bit_cast(u4v, lo);
