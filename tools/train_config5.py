@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--seed', type=int, default=77)
     ap.add_argument('--out', default='gpurun_out/config5_tiny.pkl')
     ap.add_argument('--score-only', default='', help='skip training: score this pickled model')
+    ap.add_argument('--init', default='', help='start from this pickled model (weights only: the optimizer state starts afresh) -- chains runs that are each bounded by the GPU call limit')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     config = SA.default_config()
@@ -70,6 +71,10 @@ def main():
         t0 = time.time()
         tmp = tempfile.mkdtemp()
         model = bench.build_model(cfg, args.seed, 0.1, 'cpu')
+        if args.init:
+            with open(args.init, 'rb') as fh:
+                model.load_state_dict(pickle.load(fh).state_dict())
+            log['init'] = args.init
         with open(os.path.join(tmp, 'init.pkl'), 'wb') as fh:
             pickle.dump(model, fh, protocol=4)
         fe = AMT(config, os.path.join(tmp, 'init.pkl'), batch_size=1)              # (front end only)
@@ -104,7 +109,9 @@ def main():
                     l = (acc / 250).tolist(); acc.zero_()
                     curve.append((step, round(l[0], 4)))
                     print('step %6d  loss %.4f  (%.0f s, %.0f clips/s)' % (step, l[0], time.time() - t0, step * args.batch / (time.time() - t0)), flush=True)
-                    if (args.steps and step >= args.steps) or (not args.steps and time.time() - t0 > budget):
+                    if l[0] != l[0]:
+                        log['diverged_at_step'] = step
+                    if l[0] != l[0] or (args.steps and step >= args.steps) or (not args.steps and time.time() - t0 > budget):
                         done = True
                         break
             epoch += 1
