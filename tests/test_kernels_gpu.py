@@ -206,10 +206,9 @@ def test_bf16_stream_attention_backward_with_nearly_identical_keys(dev, n, H, Lq
     assert cos(dq, q64.grad) > 0.995 and cos(dk, k64.grad) > 0.995 and cos(dv, v64.grad) > 0.995
 
 
-@pytest.mark.parametrize('N', [256, 128, 64])
-def test_ln_bwd(dev, N):
+@pytest.mark.parametrize('N,M', [(256, 1234), (256, 4099), (256, 3), (128, 1234), (64, 1234)])
+def test_ln_bwd(dev, N, M):
     ops = _ops()
-    M = 1234
     g = torch.Generator().manual_seed(N)
     r = torch.randn(M, N, generator=g) * 2 + 0.5; dy = torch.randn(M, N, generator=g); gam = torch.randn(N, generator=g)
     r64 = r.double().requires_grad_(True); g64 = gam.double().requires_grad_(True); b64 = torch.zeros(N, dtype=torch.float64, requires_grad=True)
