@@ -186,7 +186,7 @@ __device__ __forceinline__ int chunk_off(int ch) { return (ch >> 1) * 32 + (ch &
 // conversion work sits in program order BETWEEN the MFMAs (a wave alone on its SIMD issues in order).
 // pre: fragments 0 .. 3 of THIS slot on entry (requested by the previous slot, or by slot_head() at the head of a block), of the NEXT slot
 // (`next`, already vouched for by this slot's barrier: XPipe) on exit.
-struct XPre { bf16x8 f[4]; };
+struct XPre { bf16x8 f[4]; bool noread = false; };     // noread: timing experiments only (HFTT_X3_DEBUG bit 2048: fragments are not re-read)
 __device__ __forceinline__ void slot_head(const unsigned char* slot, XPre& pre) {
 #pragma unroll
   for (int i = 0; i < 4; i++) pre.f[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
@@ -201,11 +201,13 @@ __device__ __forceinline__ void x3_slot_tiles(const unsigned char* slot, const u
     constexpr int t = decltype(t_c)::value;
     acc[t] = X3<E>::mma(fr[2 * t + 1], xh, acc[t]);
     side(std::integral_constant<int, 3 * t>{});
-    if (2 * t + 4 < 16) fr[2 * t + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 4) * 1024);
+    if (pre.noread) { if (2 * t + 4 < 16) fr[2 * t + 4] = fr[2 * t]; }
+    else if (2 * t + 4 < 16) fr[2 * t + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 4) * 1024);
     else pre.f[2 * t + 4 - 16] = *reinterpret_cast<const bf16x8*>(next + (2 * t + 4 - 16) * 1024);
     if (E != X3_BF16H) acc[t] = X3<E>::mma(fr[2 * t], xl, acc[t]);      // (X3_BF16H: the strip is a gradient, hi half only)
     side(std::integral_constant<int, 3 * t + 1>{});
-    if (2 * t + 5 < 16) fr[2 * t + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 5) * 1024);
+    if (pre.noread) { if (2 * t + 5 < 16) fr[2 * t + 5] = fr[2 * t + 1]; }
+    else if (2 * t + 5 < 16) fr[2 * t + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * t + 5) * 1024);
     else pre.f[2 * t + 5 - 16] = *reinterpret_cast<const bf16x8*>(next + (2 * t + 5 - 16) * 1024);
     acc[t] = X3<E>::mma(fr[2 * t], xh, acc[t]);
     side(std::integral_constant<int, 3 * t + 2>{});
@@ -223,11 +225,13 @@ __device__ __forceinline__ void x3_slot_chunks(const unsigned char* slot, const 
     const bf16x8 xh = __builtin_bit_cast(bf16x8, x[OFF + q].a), xl = __builtin_bit_cast(bf16x8, x[OFF + q].b);
     acc = X3<E>::mma(fr[2 * q + 1], xh, acc);
     side(std::integral_constant<int, 3 * q>{});
-    if (2 * q + 4 < 16) fr[2 * q + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 4) * 1024);
+    if (pre.noread) { if (2 * q + 4 < 16) fr[2 * q + 4] = fr[2 * q]; }
+    else if (2 * q + 4 < 16) fr[2 * q + 4] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 4) * 1024);
     else pre.f[2 * q + 4 - 16] = *reinterpret_cast<const bf16x8*>(next + (2 * q + 4 - 16) * 1024);
     if (E != X3_BF16H) acc = X3<E>::mma(fr[2 * q], xl, acc);
     side(std::integral_constant<int, 3 * q + 1>{});
-    if (2 * q + 5 < 16) fr[2 * q + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 5) * 1024);
+    if (pre.noread) { if (2 * q + 5 < 16) fr[2 * q + 5] = fr[2 * q + 1]; }
+    else if (2 * q + 5 < 16) fr[2 * q + 5] = *reinterpret_cast<const bf16x8*>(slot + (2 * q + 5) * 1024);
     else pre.f[2 * q + 5 - 16] = *reinterpret_cast<const bf16x8*>(next + (2 * q + 5 - 16) * 1024);
     acc = X3<E>::mma(fr[2 * q], xh, acc);
     side(std::integral_constant<int, 3 * q + 2>{});
@@ -706,6 +710,7 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
     if (MODE == 1) { if (HH) load16h(gtb16 + tokc * g.ldg + 16 * hb, gnext); else load16f(gtb + tokc * g.ldg + 16 * hb, gnext); }
 
     XPre pre;
+    pre.noread = XDBG(g, 2048);
     slot_head(abase, pre);
     // (a run-time loop: every hidden tile uses ring buffers 0..3 in order, and the body is ~100 MFMAs -- unrolled 16 times the kernel was
     // 14,000 instructions, far beyond the instruction cache)
