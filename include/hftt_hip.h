@@ -48,7 +48,9 @@ int hftt_device_cus(void);
  *     key  = splitmix64 round over (drop_seed + 0x9E3779B97F4A7C15 * (drop_site + 1))
  *     word = 32-bit two-multiply mix of (idx >> 2) with key          (one word per FOUR consecutive elements)
  *     keep = byte (idx & 3) of word  <  round((1 - drop_p) * 256)
- * kept elements are scaled by 1 / (1 - drop_p).  The backward of a site regenerates the same decisions from the same three numbers
+ * with thr = round((1 - drop_p) * 256); kept elements are scaled by 256 / thr -- the reciprocal of the keep probability ACTUALLY applied
+ * (p = 0.1: thr = 230, scale 1.11304, not 1/0.9 = 1.11111), so E[dropout(x)] = x exactly (csrc/hftt_common.h: hftt_keep_scale); drop_p
+ * so small that thr = 256 drops nothing and scales by 1.  The backward of a site regenerates the same decisions from the same three numbers
  * (no mask tensor exists); tests/util.py::keep_mask is the numpy restatement the tests compare against.
  * --------------------------------------------------------------------------------------------- */
 
@@ -85,7 +87,7 @@ int hftt_prep_weights_x3(const float* params, uint16_t* whi, uint16_t* wlo, floa
  * epilogue, in this order:  v = acc + bias[col];  if act==1 v = max(v,0);  v *= out_scale;
  *   if add_table: v += add_table[(row % add_mod)*N + col]              (position embedding, :95)
  *   if gate:      v = gate[row*ldg+col] > 0 ? v*gate_scale : 0          (ReLU/dropout backward)
- *   if drop_p>0:  v = keep(seed,site,row*N+col) ? v/(1-p) : 0           (nn.Dropout, :95,236,242,372)
+ *   if drop_p>0:  v = keep(seed,site,row*N+col) ? v*256/thr : 0         (nn.Dropout, :95,236,242,372; thr: see Dropout above)
  *   if residual:  v += residual[(row % res_mod)*ldr + col]              (:236,242)
  *   if ln_gamma:  pre_ln_out = v;  v = LayerNorm(v)*gamma+beta (eps 1e-5, over N; needs N in {64,128,256})
  *                 mean/rstd written per row                              (nn.LayerNorm, :225,236)
@@ -268,7 +270,11 @@ int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream);
  * the group's 32 fp16 hi halves followed by its 32 fp16 lo halves (x = hi + lo to 2^-22), written ONCE by the projection that produced them
  * (hftt_strip_linear with HFTT_SL_C_F16PAIR, hftt_x3_to_planes) instead of being split by every kernel that reads them; pointers and
  * strides keep their fp32 meaning.  Both flags or neither.  The forward then stages K / V by LDS-DMA (csrc/x3_attn_pl.hip: persistent
- * workgroups, ceil(Lq / 32) <= 8 at Lk > 128 and <= 4 below); results are bit-identical to the fp32-operand form's. */
+ * workgroups, ceil(Lq / 32) <= 8 at Lk > 128 and <= 4 below).  The FORWARD's results (output, row statistics, attention map) are bit-identical
+ * to the fp32-operand form's.  The backward recomputes P bitwise as the forward did, but forms the bf16 (hi, lo) operands of its gradient
+ * products from the stored fp16 pair (hi + lo, exact in fp32) instead of from the fp32 value: dq / dk / dv agree with the fp32-operand
+ * backward to 4e-5 of each tensor's maximum (tests/test_x3_gpu.py::test_attention_on_planes_equals_attention_on_fp32_operands, 12 geometries
+ * x dropout on / off). */
 #define HFTT_ATTN_Q_F16PAIR 32u
 #define HFTT_ATTN_KV_F16PAIR 64u
 typedef struct {
@@ -361,7 +367,7 @@ int hftt_time_embed_fwd(const float* x, const float* pos, float* y, int32_t B, i
  * io_flags: HFTT_TE_X_BF16 (dy), HFTT_TE_Y_BF16 (dx), HFTT_TE_M_BF16 (dym) stored as bf16 */
 int hftt_time_embed_bwd(const float* dy, float* dx, float* dym, int32_t B, int32_t T, int32_t Nn, int32_t d,
                         float scale, float drop_p, uint32_t site, uint64_t seed, int32_t accumulate, uint32_t io_flags, void* stream);
-/* in-place dropout backward: g *= mask/(1-p) (same indexing as the forward epilogue: idx = row*N+col); n % 4 == 0; bf16 != 0: g is bf16 */
+/* in-place dropout backward: g *= mask*256/thr, thr = round((1-p)*256) (same indexing as the forward epilogue: idx = row*N+col); n % 4 == 0; bf16 != 0: g is bf16 */
 int hftt_dropout_bwd(float* g, int64_t n, float drop_p, uint32_t site, uint64_t seed, uint32_t bf16, void* stream);
 /* colsum: out[j] = beta*out[j] + sum_r x[r*ld + j], j < n (x fp32, or bf16 when x_bf16 != 0; out fp32) */
 int hftt_colsum(const float* x, int64_t rows, int64_t n, int64_t ld, float* out, float beta, float* ws, uint32_t x_bf16, void* stream);

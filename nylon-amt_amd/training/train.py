@@ -7,8 +7,10 @@ Two execution paths, same kernels underneath:
     -> backward plan -> fused Adam on the flat parameter buffer, no autograd graph, no per-step host sync;
   * compatibility path -- any other optimizer / criterion: the model's autograd.Function + torch criteria + ``optimizer.step()``
     exactly as training/train.py:89-160 does.
-The mir_eval metrics branch of ``valid`` (train.py:9-57,193-200: SURVEY section 2 #15, a metric artefact) is out of scope:
-``metrics=True`` raises.
+``valid(metrics=True)`` -- what an unchanged ``m_training.py`` calls at its last step by default (m_training.py:64,466-470) --
+scores every batch as train.py:193-200 does (``reshape_for_mir_eval`` :9-57 on onset_B / offset_B against the onset labels, a
+degenerate metric restated as it is) through ``evaluation.metrics`` (mir_eval is absent: parity unpinned at that library boundary),
+prints the reference's three lines and writes ``test_performance.json`` with the keys ``precision`` / ``recall`` / ``f1`` (:235-251).
 
 Data parallel (the reference is single-device): when torch.distributed is initialised with world > 1, every process runs these same
 functions on ITS shard of the clips (``hftt_hip.ddp.shard_indices`` / ``DeviceClipStore.loader(rank=, world=)``: r::world, equal counts);
@@ -16,6 +18,7 @@ functions on ITS shard of the clips (``hftt_hip.ddp.shard_indices`` / ``DeviceCl
 pair of scalars per epoch, so every rank returns the loss of the whole job: ``train`` -> global mean, ``valid`` -> (global sum, global
 number of batches).  Checkpoints are written by rank 0 only (``hftt_hip.ddp.is_main``).
 """
+import json
 import os
 import sys
 
@@ -29,6 +32,7 @@ if _PKG not in sys.path:
 from hftt_hip._capi import HfttError           # noqa: E402
 from hftt_hip.trainer import FusedAdam, TrainStep   # noqa: E402
 from hftt_hip import ddp                        # noqa: E402
+from evaluation.metrics import reshape_for_mir_eval, transcription_evaluate   # noqa: E402
 
 try:
     from tqdm import tqdm
@@ -130,9 +134,8 @@ def valid(model, iterator,
           weight_A, weight_B,
           device,
           metrics=False):
-    if metrics:
-        raise HfttError('valid(metrics=True): the mir_eval scoring branch of the reference (train.py:193-200) is out of scope')
     model.eval()
+    precision = recall = f1 = 0.0
     crits = (criterion_onset_A, criterion_offset_A, criterion_mpe_A, criterion_velocity_A,
              criterion_onset_B, criterion_offset_B, criterion_mpe_B, criterion_velocity_B)
     fast = _reference_criteria(crits)
@@ -145,6 +148,14 @@ def valid(model, iterator,
             label_mpe = label_mpe.to(device, non_blocking=True)
             label_velocity = label_velocity.to(device, non_blocking=True)
             out = model(input_spec)
+            if metrics:                                  # train.py:193-200 (one host copy of two [B, 128, 88] posteriors per batch)
+                est_int, est_pitch = reshape_for_mir_eval(onset_matrix=out[5].detach().cpu().numpy(), offset_matrix=out[6].detach().cpu().numpy())
+                ref = label_onset.detach().cpu().numpy()
+                ref_int, ref_pitch = reshape_for_mir_eval(onset_matrix=ref, offset_matrix=ref)
+                scores = transcription_evaluate(ref_int, ref_pitch, est_int, est_pitch)
+                precision += scores['Precision']
+                recall += scores['Recall']
+                f1 += scores['F-measure']
             if fast:
                 eng = model.hftt_engine()
                 loss9 = eng.loss(input_spec.shape[0], (label_onset.float().contiguous(), label_offset.float().contiguous(),
@@ -161,7 +172,21 @@ def valid(model, iterator,
             epoch_loss += (weight_A * loss_A + weight_B * loss_B).item()
     if fast:
         epoch_loss = float(epoch_loss.item())
-    if ddp.rank_world()[1] > 1:
+    world = ddp.rank_world()[1]
+    n_batches = len(iterator)
+    if world > 1:
         epoch_loss, n_batches = ddp.allreduce_sums(epoch_loss, len(iterator), device=device)
-        return epoch_loss, int(n_batches)
-    return epoch_loss, len(iterator)
+        n_batches = int(n_batches)
+    if metrics:                                          # train.py:235-251
+        if world > 1:                                    # every rank scored its shard: the job's mean over all batches
+            precision, recall, f1 = ddp.allreduce_sums(precision, recall, f1, device=device)
+        precision /= n_batches
+        recall /= n_batches
+        f1 /= n_batches
+        print("Precision:", precision)
+        print("Recall:", recall)
+        print("F1:", f1)
+        if ddp.is_main():
+            with open("test_performance.json", mode="w") as opened_json:
+                json.dump({"precision": precision, "recall": recall, "f1": f1}, opened_json)
+    return epoch_loss, n_batches

@@ -89,3 +89,66 @@ def test_decode_and_score_round_trip_on_rendered_rolls():
     for n in est:
         roll[int(round(n['onset'] / hop)):int(round(n['offset'] / hop)), n['pitch'] - 21] = True
     assert frame_metrics(mpe >= 0.5, roll)['f1'] == 1.0
+
+
+def test_reshape_for_mir_eval_known_answer():
+    """training/train.py:9-57 on a hand-made 2-clip matrix (hop 4410 / 44100 -> 0.1 s frames, so nothing is stretched)."""
+    from evaluation.metrics import reshape_for_mir_eval
+    on = np.zeros((2, 6, 3)); off = np.zeros((2, 6, 3))
+    on[0, [1, 4], 1] = (0.3, 1.0); off[0, [2, 3], 1] = (1.0, 0.2)       # onset 1 -> offset 2; onset 4 -> none after it -> 4 + 1
+    on[0, 0, 2] = 1.0                                                   # a pitch with onsets and no offset entry: skipped
+    off[0, 5, 0] = 1.0                                                  # ... and one with offsets only: nothing to emit
+    on[1, 3, 0] = 0.5; off[1, [3, 5], 0] = 1.0                          # an offset in the onset's own frame does not end it
+    iv, pit = reshape_for_mir_eval(on, off, hop_length=4410, sample_rate=44100, min_duration=0.032)
+    np.testing.assert_allclose(iv, [[0.1, 0.2], [0.4, 0.5], [0.3, 0.5]], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(pit, [440 * 2 ** (-68 / 12)] * 2 + [440 * 2 ** (-69 / 12)], rtol=1e-15)
+    # defaults (512 / 44100 = 11.6 ms frames): a one-frame note is stretched to min_duration; "none after" = onset + int(0.032 / 0.0116) = +2 frames
+    iv, pit = reshape_for_mir_eval(on, off)
+    tpf = 512 / 44100
+    np.testing.assert_allclose(iv, [[tpf, tpf + 0.032], [4 * tpf, 4 * tpf + 0.032], [3 * tpf, 3 * tpf + 0.032]], rtol=0, atol=1e-15)
+    on2 = np.zeros((1, 8, 1)); off2 = np.zeros((1, 8, 1)); on2[0, 0, 0] = 1; off2[0, 7, 0] = 1
+    iv, _ = reshape_for_mir_eval(on2, off2)
+    np.testing.assert_allclose(iv, [[0.0, 7 * tpf]], atol=1e-15)         # long enough: kept as it is
+    # nothing at all: the reference's placeholder note
+    iv, pit = reshape_for_mir_eval(np.zeros((2, 4, 3)), np.zeros((2, 4, 3)))
+    assert iv.tolist() == [[0, 0.032]] and pit.tolist() == [440.0]
+    # the labels scored against themselves as train.py:194 does (offset matrix := onset matrix): a ramp of 3 non-zero frames -> 3 notes
+    lab = np.zeros((1, 10, 2)); lab[0, 2:5, 1] = (0.5, 1.0, 0.5)
+    iv, pit = reshape_for_mir_eval(lab, lab)
+    assert len(iv) == 3 and np.allclose(iv[:, 1] - iv[:, 0], 0.032) and np.allclose(iv[:, 0], np.arange(2, 5) * tpf)
+    with pytest.raises(ValueError):
+        reshape_for_mir_eval(np.zeros((2, 4)), np.zeros((2, 4)))
+
+
+def test_transcription_evaluate_known_answers():
+    from evaluation.metrics import transcription_evaluate
+    hz = lambda m: 440.0 * 2 ** ((m - 69) / 12)
+    ref_i = np.array([[1.00, 1.50], [2.00, 2.40], [3.00, 4.00]]); ref_p = np.array([hz(60), hz(64), hz(67)])
+    est_i = np.array([[1.04, 1.90], [2.06, 2.40], [2.95, 4.15]]); est_p = np.array([hz(60), hz(64), hz(67) * 2 ** (40 / 1200)])
+    m = transcription_evaluate(ref_i, ref_p, est_i, est_p)
+    # with offsets (what train.py reads): only the third note (onset -50 ms on the edge, +40 cents, offset +0.15 <= 0.2 * 1.0)
+    assert m['Precision'] == pytest.approx(1 / 3) and m['Recall'] == pytest.approx(1 / 3) and m['F-measure'] == pytest.approx(1 / 3)
+    assert m['Precision_no_offset'] == pytest.approx(2 / 3) and m['F-measure_no_offset'] == pytest.approx(2 / 3)
+    est_p2 = est_p.copy(); est_p2[2] = hz(67) * 2 ** (60 / 1200)          # 60 cents off: a different pitch
+    assert transcription_evaluate(ref_i, ref_p, est_i, est_p2)['Precision'] == 0.0
+    z = transcription_evaluate(np.zeros((0, 2)), np.zeros(0), est_i, est_p)
+    assert z['Precision'] == z['Recall'] == z['F-measure'] == 0.0
+    # different counts: precision over the estimates, recall over the references; each estimate used once
+    m = transcription_evaluate(ref_i[:1], ref_p[:1], np.array([[1.0, 1.5], [1.01, 1.5], [1.02, 1.5], [9.0, 9.5]]), np.full(4, hz(60)))
+    assert m['Precision'] == 0.25 and m['Recall'] == 1.0 and m['F-measure'] == pytest.approx(0.4)
+    with pytest.raises(ValueError):
+        transcription_evaluate(ref_i, -ref_p, est_i, est_p)
+
+
+def test_valid_metrics_pipeline_on_the_degenerate_case():
+    """What the reference's default run scores: every cell of the estimate is a note of min_duration.  A reference ramp of three frames
+    at one pitch then finds three matches among B * T * P estimates: recall 1, precision 3 / (B * T * P)."""
+    from evaluation.metrics import reshape_for_mir_eval, transcription_evaluate
+    B, T, P = 2, 16, 5
+    est = np.full((B, T, P), 0.3)
+    lab = np.zeros((B, T, P)); lab[1, 6:9, 2] = (0.5, 1.0, 0.5)
+    ei, ep = reshape_for_mir_eval(est, est)
+    ri, rp = reshape_for_mir_eval(lab, lab)
+    assert len(ei) == B * T * P and len(ri) == 3
+    m = transcription_evaluate(ri, rp, ei, ep)
+    assert m['Recall'] == 1.0 and m['Precision'] == pytest.approx(3 / (B * T * P))

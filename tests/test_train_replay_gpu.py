@@ -55,7 +55,7 @@ class _Driver:
         self.optimizer = make_optimizer(model.parameters(), lr)                                          # :146
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer)                      # :147
         self.crits = [nn.BCELoss(), nn.BCELoss(), nn.BCELoss(), nn.CrossEntropyLoss(), nn.BCELoss(), nn.BCELoss(), nn.BCELoss(), nn.CrossEntropyLoss()]
-        self.dev, self.d_out = dev, d_out
+        self.dev, self.d_out, self.cfg = dev, d_out, cfg
         conf = _ds_config(cfg)
         tr = _write_store(d_out, cfg, [70, 45], 11, 'train')
         va = _write_store(d_out, cfg, [40], 12, 'valid')
@@ -82,6 +82,15 @@ class _Driver:
         self.best = min(self.best, lv)
         self.scheduler.step(lv)                                                                          # :437
         return lt, lv
+
+    def test(self, batch=4, n_slice=4):
+        """(7-3) `-valid_test` is True by default (m_training.py:64): the last thing an unchanged run does is valid(metrics=True) :466-470"""
+        from training import dataset, train
+        te = _write_store(self.d_out, self.cfg, [52], 13, 'test')
+        dataset_test = dataset.MyDataset(*te, _ds_config(self.cfg), n_slice)                              # :238-246
+        loader_test = torch.utils.data.DataLoader(dataset_test, batch_size=batch, shuffle=False)
+        loss, n = train.valid(self.model, loader_test, *self.crits, 1.0, 1.0, self.dev, metrics=True)      # :466-470
+        return loss / n, loader_test                                                                     # :471
 
     def resume(self, epoch):
         ck = torch.load(os.path.join(self.d_out, 'model_%03d_000.dat' % epoch), weights_only=False)      # :268
@@ -132,6 +141,54 @@ def test_m_training_replay_fused_adam_and_unchanged_driver(dev, tmp_path):
     with torch.no_grad():
         for a, b in zip(m2(x), df.model(x)):
             assert torch.equal(a, b)
+
+
+def test_m_training_last_step_valid_with_metrics(dev, tmp_path, monkeypatch, capsys):
+    """m_training.py (7-3), on by default: valid(metrics=True) prints the reference's three lines, writes test_performance.json with its
+    three keys (train.py:235-251) and returns the same (loss sum, batches) as metrics=False; fast (reference criteria) and compat path.
+    The scores are the reference's degenerate ones restated (every cell of a sigmoid output is an 'onset'): checked against the scorer
+    run on the same posteriors by hand."""
+    import json
+    from hftt_hip.trainer import FusedAdam
+    from training import train
+    from evaluation.metrics import reshape_for_mir_eval, transcription_evaluate
+    d = _Driver(dev, str(tmp_path / 'run'), MINI, lambda ps, lr: FusedAdam(ps, lr=lr), dropout=0.0)
+    os.makedirs(d.d_out, exist_ok=True)
+    d.epoch(0)
+    monkeypatch.chdir(tmp_path)                                   # the reference writes the JSON into the working directory
+    loss_test, loader = d.test()
+    out = capsys.readouterr().out
+    with open(tmp_path / 'test_performance.json') as f:
+        perf = json.load(f)
+    assert set(perf) == {'precision', 'recall', 'f1'}
+    for k, label in (('precision', 'Precision:'), ('recall', 'Recall:'), ('f1', 'F1:')):
+        assert '%s %s' % (label, perf[k]) in out, out
+    # by hand: same posteriors, same pooling per batch, mean over batches
+    d.model.eval()
+    acc = np.zeros(3)
+    with torch.no_grad():
+        for spec, on, _off, _mpe, _vel in loader:
+            o = d.model(spec.to(dev))
+            ei, ep = reshape_for_mir_eval(o[5].cpu().numpy(), o[6].cpu().numpy())
+            ri, rp = reshape_for_mir_eval(on.numpy(), on.numpy())
+            assert len(ei) == o[5].numel()                        # a sigmoid output is never zero: one 'note' per cell
+            sc = transcription_evaluate(ri, rp, ei, ep)
+            acc += [sc['Precision'], sc['Recall'], sc['F-measure']]
+    acc /= len(loader)
+    assert perf['precision'] == pytest.approx(acc[0], abs=1e-12) and perf['recall'] == pytest.approx(acc[1], abs=1e-12)
+    assert perf['f1'] == pytest.approx(acc[2], abs=1e-12)
+    assert 0.0 < perf['precision'] < 0.2 and perf['recall'] > 0.5         # README.md:6-19's shape: P ~ 0.01, R ~ 0.95
+    lv, n = train.valid(d.model, loader, *d.crits, 1.0, 1.0, dev, metrics=False)
+    assert n == len(loader) and lv / n == pytest.approx(loss_test, rel=1e-6)
+    # compatibility path (a criterion that is not the reference's) takes the same branch
+    crits = list(d.crits)
+    crits[0] = nn.BCELoss(reduction='mean', weight=None)
+    crits[3] = nn.CrossEntropyLoss(label_smoothing=1e-9)
+    os.remove(tmp_path / 'test_performance.json')
+    lc, nc = train.valid(d.model, loader, *crits, 1.0, 1.0, dev, metrics=True)
+    with open(tmp_path / 'test_performance.json') as f:
+        assert json.load(f) == perf
+    assert lc / nc == pytest.approx(loss_test, rel=1e-4)
 
 
 def test_resume_is_bit_identical_with_dropout_on(dev, tmp_path):
