@@ -337,8 +337,13 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
 // ---------------------------------------------------------------------------------------------------------------------
 // fused two-GEMM block, d = 256, p = 32 * PT: mode 0 = FFN forward + residual + LayerNorm, mode 1 = dX half of its backward
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MODE, int PT>
-__global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc g) {
+// WPC = workgroups per CU.  1: the form above (one wave per SIMD, 512 registers, the next block's activations prefetched into a second
+// register set).  2 (round 5): the same stream with HALF the registers -- no second activation set (a block's rows are requested at its
+// top; the latency is the partner workgroup's to cover), four fragment reads in flight instead of six -- so that two workgroups share a
+// CU, each with its own ring and barrier: one's middle / LayerNorm epilogue and slot waits issue under the other's MFMA run, which one wave
+// per SIMD cannot do for itself.  LDS: 2 x (64 KB ring + parameters) = 141 KB.
+template <int MODE, int PT, int WPC>
+__global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_desc g) {
   static_assert(PT % 4 == 0, "the gate prefetch ring and the slot buffers assume PT % 4 == 0");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -371,14 +376,16 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
   // epilogue.  xn: the next block's activations, one piece per hidden tile.  Results are stored from the epilogue directly: with 16
   // hidden-tile stores already spread over the block, a deferred set on top overflowed the register file (73-95 spills, and a spill
   // of a register with a load in flight is a wrong answer, not a slow one).
-  u4v xf[16], xn[16];
+  u4v xf[16], xn[WPC == 1 ? 16 : 1];
   u4v gt[4][2];                                     // mode 1: stored hidden (the gate) of tiles t .. t+2, ring of four
   {
     const long t0 = tok_of(blockIdx.x);
     const unsigned short* p0 = xb + t0 * g.ldx + 16 * h;
+    if (WPC == 1) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) pload16(xn[i], p0 + piece_off(i));
-    P.issued += 16;
+      for (int i = 0; i < 16; i++) pload16(xn[WPC == 1 ? i : 0], p0 + piece_off(i));
+      P.issued += 16;
+    }
     if (MODE == 1) {
 #pragma unroll
       for (int t = 0; t < 2; t++) {
@@ -411,8 +418,15 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
     int zero = 0;                                     // (keeps the LDS parameter reads inside the iteration: see strip_linear2_kernel)
     asm volatile("" : "+s"(zero));
     const float* prm_b = prm + zero;
+    if (WPC == 1) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) xf[i] = xn[i];
+      for (int i = 0; i < 16; i++) xf[i] = xn[WPC == 1 ? i : 0];
+    } else {                                          // requested here, consumed by the first slot's MFMAs (hipcc places the wait)
+      const unsigned short* xrow = xb + tokc * g.ldx + 16 * hb;
+#pragma unroll
+      for (int i = 0; i < 16; i++) pload16(xf[i], xrow + piece_off(i));
+      P.issued += 16;
+    }
 
     f32x16 yacc[8];
 #pragma unroll
@@ -443,12 +457,13 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
         const unsigned char* slot = abase + BA * SLOT_BYTES;
         const bool in_blk = (t + 2) < PT;             // mode 1: gate of tile t + 2 (of the next block past the end)
         const unsigned short* gp = (MODE == 1) ? g.gate + (in_blk ? tokc : tokn) * g.ldg + ((t + 2) % PT) * 32 + 16 * hb : nullptr;
-        slot_mfmas(slot, [&](int f, bf16x8 a) __attribute__((always_inline)) { hacc = mfma32(a, as_frag(xf[f]), hacc); });    // fragment f = 2 * pt + u
+        if (!S2DBG(g, 256))
+        slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int f, bf16x8 a) __attribute__((always_inline)) { hacc = mfma32(a, as_frag(xf[f]), hacc); });    // fragment f = 2 * pt + u
         static_for<4>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int q = decltype(q_c)::value;
           P.template fill_piece<BA, q>();
           if (q == 0) {
-            if (has_next) { pload16(xn[t], xrow_next + piece_off(t)); P.issued += 1; }      // one piece of the next block's activations per tile
+            if (WPC == 1 && has_next) { pload16(xn[WPC == 1 ? t : 0], xrow_next + piece_off(t)); P.issued += 1; }      // one piece of the next block's activations per tile
           } else if (q < 3) {
             if (MODE == 1 && (in_blk || has_next)) { pload16(gt[(t + 2) & 3][q - 1], gp + 8 * (q - 1)); P.issued += 1; }
           }
@@ -464,7 +479,10 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
       // ---- middle epilogue: the lane's 16 hidden features of tile t become the B operand of the second GEMM ----
       float v[16];
       const int hcol0 = t * 32 + 16 * hb;
-      if (MODE == 0) {
+      if (S2DBG(g, 128)) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = hacc[q];
+      } else if (MODE == 0) {
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = fmaxf(hacc[q], 0.f);
         if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 2), thr, inv_keep);
@@ -484,7 +502,8 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
         const unsigned char* slot = abase + BB * SLOT_BYTES;
         const bool st_h = g.h_out != nullptr && wave_ok;
         unsigned short* hp = g.h_out + tok * g.ldh + hcol0;
-        slot_mfmas(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { yacc[i & 7] = mfma32(a, as_frag(hf[i >> 3]), yacc[i & 7]); });
+        if (!S2DBG(g, 256))
+        slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { yacc[i & 7] = mfma32(a, as_frag(hf[i >> 3]), yacc[i & 7]); });
         static_for<4>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int q = decltype(q_c)::value;
           P.template fill_piece<BB, q>();
@@ -498,6 +517,15 @@ __global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc 
     // ---------------- final epilogue of the block ----------------
         const uint64_t rowq = ((uint64_t)tok * 256ull) >> 2;
     unsigned short* yrow = yb + tok * g.ldy + 16 * hb;
+    if (S2DBG(g, 64)) {                               // timing switch: no epilogue (the sum of the accumulators keeps them live)
+      float sacc = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < 8; ot++)
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) sacc += yacc[ot][q];
+      if (sacc == 12345.678f) yrow[0] = 1;
+      continue;
+    }
 #pragma unroll
     for (int ot = 0; ot < 8; ot++) {
       const int col0 = ot * 32 + 16 * hb;
@@ -563,23 +591,32 @@ int launch_linear2(const hftt_strip_desc& d, hipStream_t st) {
   HFTT_CHECK_LAUNCH("strip_linear2");
   return 0;
 }
-template <int MODE>
+template <int MODE, int WPC>
 int launch_mlp2(const hftt_ffn_desc& d, hipStream_t st) {
   const int lds = RING_BYTES + 4 * (d.p + 768);
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(strip_mlp2_kernel<MODE, 16>, lds, "strip_mlp2")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(strip_mlp2_kernel<MODE, 16, WPC>, lds, "strip_mlp2")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("strip_mlp2: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  hipLaunchKernelGGL((strip_mlp2_kernel<MODE, 16>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  const long grid = (long)WPC * cus;
+  hipLaunchKernelGGL((strip_mlp2_kernel<MODE, 16, WPC>), dim3((unsigned)(nblk < grid ? nblk : grid)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("strip_mlp2");
   return 0;
+}
+// HFTT_MLP2_WPC / HFTT_MLP2_WPC_BWD = 1 / 2: workgroups per CU of the fused block.  Default 1, by measurement (round 5, S_e, same box): two per CU
+// ran the inference form 3.5 % faster (194 -> 188 us) and both training forms 4-8 % slower (283 -> 307, 299 -> 313 us): DESIGN section 5
+int mlp2_wpc(int mode) {      // (read per launch: tests and the A/B tools switch it inside one process)
+  const char* e = getenv(mode == 0 ? "HFTT_MLP2_WPC" : "HFTT_MLP2_WPC_BWD");
+  const int v = e ? atoi(e) : 1;
+  return v == 2 ? 2 : 1;
 }
 
 }  // namespace
 
 // -1: this shape / storage is not covered by the pipelined form (the caller launches the general kernel); otherwise the launch status
-// HFTT_STRIP2_DEBUG (timing experiments, results garbage): 1 no ring fills, 2 no barriers, 16 no result stores, 32 no activation prefetch
+// HFTT_STRIP2_DEBUG (timing experiments, results garbage; -DHFTT_STRIP2_ABLATE builds only): 1 no ring fills, 2 no barriers, 16 no result stores,
+// 32 no activation prefetch (linear); fused block: 64 no final epilogue, 128 no middle epilogue, 256 no MFMAs
 static int strip2_debug() { const char* e = getenv("HFTT_STRIP2_DEBUG"); return e ? atoi(e) : 0; }
 
 int hftt_strip_linear2_try(const hftt_strip_desc& d0, hipStream_t st) {
@@ -611,5 +648,6 @@ int hftt_strip_mlp2_try(const hftt_ffn_desc& d0, hipStream_t st) {
   d.pad = strip2_debug();
   if (!v2_enabled() || d.p != 512 || d.M % 32 != 0) return -1;
   if (d.mode == 0 && d.residual != nullptr) return -1;
-  return d.mode == 0 ? launch_mlp2<0>(d, st) : launch_mlp2<1>(d, st);
+  if (mlp2_wpc(d.mode == 0 ? 0 : 1) == 2) return d.mode == 0 ? launch_mlp2<0, 2>(d, st) : launch_mlp2<1, 2>(d, st);
+  return d.mode == 0 ? launch_mlp2<0, 1>(d, st) : launch_mlp2<1, 1>(d, st);
 }

@@ -105,20 +105,20 @@ __device__ __forceinline__ bf16x8 as_frag(const u4v& u) { return __builtin_bit_c
 // The 16 weight fragments of a slot -> 16 MFMAs.  With ONE wave per SIMD nobody else covers an LDS round trip, and left alone hipcc
 // keeps only one or two ds_read_b128 in flight (~120 cycles per MFMA instead of 32).  The group barriers pin the shape: six reads
 // up front, then one read behind every MFMA, so each fragment is requested ~6 MFMAs (~190 cycles) before it is consumed.
-template <typename F>
+template <int AHEAD = 6, typename F>
 __device__ __forceinline__ void slot_mfmas(const unsigned char* slot, F&& mfma_i) {
   bf16x8 fr[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) fr[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
 #pragma unroll
   for (int i = 0; i < 16; i++) mfma_i(i, fr[i]);
-  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
-  for (int k = 0; k < 10; k++) {
+  for (int k = 0; k < 16 - AHEAD; k++) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
   }
-  __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
 }
 
 // The same, with the slot's memory work (`side(i)`, called behind MFMA i) in program order BETWEEN the MFMAs: a wave alone on its SIMD

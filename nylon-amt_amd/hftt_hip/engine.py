@@ -135,6 +135,10 @@ class HfttEngine:
         # >= 0.9999 at paper size, but the gradients move from 2e-4 to 3e-3 .. 6e-3 of the fp32 reference's (relative to the tensor's maximum) --
         # outside the 1e-3 the default mode keeps for gradients too, hence opt-in.
         self.g8 = self.x3 and os.environ.get('HFTT_X3_GRAD_HI', '0') == '1' and not self.strip_small
+        if self.g8 and not (lib().hftt_build_options() & 1):
+            raise HfttError('HFTT_X3_GRAD_HI=1 needs a library built with HFTT_BUILD_GRAD_HI=1 (python nylon-amt_amd/build.py writes '
+                            'libhftt_hip_g.so; hftt_hip/_capi.py loads it under the same switch): the default library does not carry the '
+                            'gradient-rounding kernels')
         self._prepared_frozen = False
         if getattr(self, '_bound', None) is not None:
             self._build_prep()

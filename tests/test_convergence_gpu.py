@@ -1,12 +1,17 @@
 """Training-quality parity (BASELINE.json metric: "... frame-F1 parity"): the same model trained from the same initial
-parameters on the same clips for 1,500 steps in the device's precision modes -- and, at the small size, by the CPU oracle running the reference's own step
+parameters on the same clips in the device's precision modes -- and by the CPU oracle running the reference's own step
 (training/train.py:89-160: forward, 6 x BCE + 2 x CE, backward, torch.optim.Adam) -- must follow the same loss trajectory and end at the
-same frame-level F1 (mpe >= 0.5, evaluation/m_mpe.py:101, 166-175) within the run-to-run spread of that thresholded number, with the same
-threshold-free ranking of the held-out frames (frame_auc).
+same frame-level F1 (mpe >= 0.5, evaluation/m_mpe.py:101, 166-175) with the same threshold-free ranking of the held-out frames (frame_auc).
 
-The task is synthetic but LEARNABLE (the labels are a deterministic function of the spectrogram): over the run the loss falls from 6.1 to
-~5.0 (its floor is the entropy of the velocity classes) and the held-out frame-F1 rises to ~0.65-0.7, so the thresholded decisions mean
-something: a mode whose gradients pointed the wrong way would show here."""
+The task is synthetic but LEARNABLE (the labels are a deterministic function of the spectrogram).  Round 5: the models start from the
+reference's initialisation with the three POSITION tables multiplied by POS_SCALE = 300.  Why: m_training.py:31-33 draws nn.Embedding
+tables xavier-uniform (|w| <= 0.11) and model_spec2midi.py:95,190 adds them to token embeddings x sqrt(hid_dim) whose entries are in the
+hundreds on log-mel input, so as initialised the model cannot tell one bin (or frame) from another and sits on the predict-the-prior
+plateau for thousands of steps -- in EVERY arithmetic, the fp32 CPU oracle included (measured there, mini size, 600 steps: held-out AUC
+0.61 / F1 0.55 unscaled, 0.99 / 0.95 scaled; rounds 3-4 of this test trained on that plateau and could only assert AUC > 0.55).  With the
+tables scaled the loss falls from 6.0 to below 2 within 600 steps and the held-out frame-F1 reaches 0.9+, so a mode whose gradients
+pointed the wrong way fails by a wide margin: floors on F1 and AUC far above chance, the oracle comparison at the mini size
+and at the PAPER'S WIDTH AND DEPTH (d 256, ff 512, 3+3 layers, 4 heads on short axes: VERDICT r04 item 2a)."""
 import math
 
 import numpy as np
@@ -18,10 +23,23 @@ from util import O, MINI
 
 pytestmark = pytest.mark.gpu
 
-# the paper's WIDTH (d = 256, ff = 512, 4 heads: the strip kernels of both modes) on short axes
+# the paper's WIDTH (d = 256, ff = 512, 4 heads: the strip kernels of both modes) on short axes; DEEP adds the paper's depth (3 + 3 layers:
+# DecoderLayer -- self(notes) + cross + FFN under one shared LayerNorm -- trained against the oracle at d = 256)
 WIDE = O.HfttConfig(n_margin=4, n_frame=16, n_bin=32, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512, enc_layer=1, dec_layer=1,
                     enc_head=4, dec_head=4, n_note=8, n_velocity=16)
-STEPS, EVERY = 1500, 150          # (the architecture learns slowly from scratch: ~1000 Adam steps before the thresholded decisions mean something)
+DEEP = O.HfttConfig(n_margin=4, n_frame=16, n_bin=32, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512, enc_layer=3, dec_layer=3,
+                    enc_head=4, dec_head=4, n_note=8, n_velocity=16)
+STEPS, EVERY = 600, 50          # (dropout-on legs: 2 x STEPS -- the masked model leaves the plateau about 300 steps later)
+POS_SCALE = 300.0
+
+
+def scaled_model(cfg, seed, dropout):
+    model = util.build_model(cfg, seed, dropout=dropout)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if 'pos_embedding' in name:
+                p.mul_(POS_SCALE)
+    return model
 
 
 def make_clips(cfg, n, seed):
@@ -69,9 +87,9 @@ def frame_auc(prob, ref):
     return float((ranks[y].sum() - n1 * (n1 + 1) / 2) / (n1 * n0))
 
 
-def train_device(cfg, precision, dropout, data, held, dev, B, lr):
+def train_device(cfg, precision, dropout, data, held, dev, B, lr, STEPS=STEPS):
     from hftt_hip.trainer import TrainStep
-    model = util.build_model(cfg, 2025, dropout=dropout).to(dev)
+    model = scaled_model(cfg, 2025, dropout).to(dev)
     model.hftt_precision = precision
     model.train()
     ts = TrainStep(model, lr=lr)
@@ -93,10 +111,7 @@ def train_device(cfg, precision, dropout, data, held, dev, B, lr):
                     out = model(held[0].to(dev))
                 f1s.append((frame_f1(out[7].cpu(), held[1][2]), frame_f1(out[2].cpu(), held[1][2]), frame_auc(out[7].cpu(), held[1][2])))
                 model.train()
-    # The thresholded decisions of ONE instant of a 1,500-step trajectory are noisy at this size: over three initialisations the final
-    # F1_B of one and the same mode moved between 0.55 and 0.70, and a last-bit change of the arithmetic (q / k / v handed over as fp16
-    # pairs instead of fp32: gradients equal to 4e-5) moved a seed's final value from 0.58 to 0.36 while its loss stayed within 2 %.
-    # The median over the last three checkpoints is what the comparisons below use.
+    # the median over the last three checkpoints is what the comparisons below use
     med = lambda v: sorted(v)[len(v) // 2]
     print('  %s held-out F1 (B, A) and ranking AUC (B) at the last checkpoints: %s' % (precision, [tuple(round(v, 3) for v in t) for t in f1s]), flush=True)
     return curve, med([t[0] for t in f1s]), med([t[1] for t in f1s]), model, med([t[2] for t in f1s])
@@ -105,7 +120,7 @@ def train_device(cfg, precision, dropout, data, held, dev, B, lr):
 def train_oracle(cfg, data, held, B, lr):
     """the reference's step on the CPU: oracle forward (dropout 0), train.py:141-153 loss, autograd, torch.optim.Adam(lr)"""
     torch.set_num_threads(min(8, torch.get_num_threads()))        # small tensors: more threads only add overhead
-    model = util.build_model(cfg, 2025, dropout=0.0)
+    model = scaled_model(cfg, 2025, 0.0)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     opt = torch.optim.Adam(list(sd.values()), lr=lr)
     spec, labels = data
@@ -129,50 +144,89 @@ def train_oracle(cfg, data, held, B, lr):
     return curve, med([t[0] for t in f1s]), med([t[1] for t in f1s]), None, med([t[2] for t in f1s])
 
 
+def first_below(curve, level):
+    """index of the first checkpoint whose mean loss is below `level` (len(curve) if none): WHEN the run left the plateau"""
+    for i, v in enumerate(curve):
+        if v < level:
+            return i
+    return len(curve)
+
+
 @pytest.mark.parametrize('dropout', [0.0, 0.1])
-@pytest.mark.parametrize('size', ['mini', 'wide'])
+@pytest.mark.parametrize('size', ['mini', 'wide', 'deep'])
 def test_modes_train_alike(dev, size, dropout):
-    cfg = MINI if size == 'mini' else WIDE
+    cfg = {'mini': MINI, 'wide': WIDE, 'deep': DEEP}[size]
     B = 4
     lr = 1e-3 if size == 'mini' else 3e-4          # (the 256-wide model diverges at 1e-3 in every mode, the oracle's fp32 included)
     data = make_clips(cfg, 64, seed=1)
     held = make_clips(cfg, 48, seed=2)
-    res = {m: train_device(cfg, m, dropout, data, held, dev, B, lr) for m in ('x3', 'bf16')}
-    if size == 'mini' and dropout == 0.0:
+    res = {m: train_device(cfg, m, dropout, data, held, dev, B, lr, STEPS if dropout == 0.0 else 2 * STEPS) for m in ('x3', 'bf16')}
+    if size in ('mini', 'deep') and dropout == 0.0:
         res['oracle'] = train_oracle(cfg, data, held, B, lr)
     rep = {m: {'loss': [round(v, 4) for v in r[0]], 'f1_B': round(r[1], 4), 'f1_A': round(r[2], 4), 'auc_B': round(r[4], 4)} for m, r in res.items()}
     print(size, 'dropout', dropout, rep)
+    for m, r in res.items():
+        assert all(math.isfinite(v) for v in r[0]), (m, r[0])
+        # every mode LEARNS the task: the loss leaves the plateau (6.0 -> below 3.5; the floor is the entropy of the velocity classes) and the
+        # held-out frame decisions are right -- floors far above chance (F1 of the all-on answer: 0.67, AUC 0.5)
+        assert r[0][-1] < 3.5 and r[0][-1] < 0.6 * r[0][0], (m, r[0])
+        assert r[1] > 0.85 and r[2] > 0.85, 'held-out frame-F1 (B, A) of %s: %s' % (m, r[1:3])
+        assert r[4] > 0.97, 'held-out ranking AUC of %s: %g' % (m, r[4])
     base = res['x3']
-    # the loss really falls (its floor is the entropy of the velocity classes, most of the 6.1 it starts from) and the decisions mean something
-    assert base[0][-1] < base[0][0] - 0.5, 'the task was not learned: %s' % (base[0],)
-    # "Meaningful" is judged on the RANKING of the held-out frame posteriors (frame_auc: 0.58 .. 0.65 in every mode, size and checkpoint
-    # measured, chance 0.5), not on the F1 at the fixed threshold 0.5: this early in training that F1 follows the calibration of the
-    # posterior and swings between 0.27 and 0.65 from one checkpoint to the next of ONE run while the ranking and the loss do not move.
-    assert base[4] > 0.55, 'the held-out frame posteriors of the trained model do not rank the frames: AUC %g' % base[4]
     for m, r in res.items():
         if m == 'x3':
             continue
-        assert all(math.isfinite(v) for v in r[0]), (m, r[0])
-        if m == 'oracle':
-            # x3 against the reference's own arithmetic: the same trajectory to a few per cent -- 1,500 Adam steps amplify last-bit differences
-            # (two runs of the SAME mode that differ in one rounding end 1 .. 3 % apart in loss and 0.05 .. 0.08 apart in F1 at this size) -- and
-            # the same frame-F1 within that run-to-run spread, the same ranking within 0.05.  Measured (round 4): loss within 3.1 % at every
-            # checkpoint (1.2 % up to step 1200), F1_B 0.537 vs 0.603, F1_A 0.594 vs 0.608, AUC 0.584 vs 0.603.
-            for a, b in zip(r[0], base[0]):
-                assert abs(a - b) <= 0.04 * b, (m, r[0], base[0])
-            assert abs(r[1] - base[1]) <= 0.12 and abs(r[2] - base[2]) <= 0.12, (m, r[1:3], base[1:3])
-            assert abs(r[4] - base[4]) <= 0.05, (m, r[4], base[4])
-        else:
-            # The single-pass bf16 mode is the throughput mode and claims no output parity, but it must TRAIN alike: measured within 2 % of the
-            # x3 trajectory up to step 1050, with and without dropout, and within 6.4 % after it (the two trajectories of the small model
-            # separate there: x3 ends BELOW the fp32 oracle, bf16 above it), with the same held-out ranking (AUC within 0.03).
-            # (Until round 3 it stalled near 5.6 .. 5.7 with dropout on, where x3
-            # reaches 5.2 .. 5.3: dQ = dS.K lost its signal under the common part of near-identical keys -- csrc/attn_bwd.hip now takes the
-            # mean key off the dQ operand -- and a first-layer row with scores of -4e9 underflowed the softmax to 1/0: tests/test_x3_gpu.py.)
-            assert r[0][-1] < r[0][0] - 0.3, (m, r[0])
-            for i, (a, b) in enumerate(zip(r[0], base[0])):
-                assert abs(a - b) <= (0.04 if i < 7 else 0.10) * b, (m, r[0], base[0])
-            assert abs(r[4] - base[4]) <= 0.06, (m, r[4], base[4])
+        # Same trajectory: on the plateau the curves agree to a per cent; the step at which a run LEAVES it is the sensitive quantity (the
+        # loss then falls by a third within 100 steps, so a shift of a few steps is a large difference at one checkpoint): it may move by one
+        # checkpoint (50 steps) against x3, and the end points -- loss, F1, ranking -- must agree.
+        lvl = 0.5 * (base[0][0] + base[0][-1])
+        ia, ib = first_below(r[0], lvl), first_below(base[0], lvl)
+        assert abs(ia - ib) <= (1 if m == 'oracle' else 2), (m, ia, ib, r[0], base[0])
+        for i in range(min(ia, ib) - 1):
+            assert abs(r[0][i] - base[0][i]) <= (0.015 if m == 'oracle' else 0.03) * base[0][i], (m, i, r[0], base[0])
+        assert abs(r[0][-1] - base[0][-1]) <= 0.25 * base[0][-1], (m, r[0][-1], base[0][-1])
+        assert abs(r[1] - base[1]) <= 0.06 and abs(r[2] - base[2]) <= 0.06, (m, r[1:3], base[1:3])
+        assert abs(r[4] - base[4]) <= 0.02, (m, r[4], base[4])
+
+
+def test_plane_and_fp32_operand_backward_agree_on_the_training_shapes(dev, monkeypatch):
+    """the f16-pair planes changed the x3 backward's operands (bf16 pairs rebuilt from hi + lo instead of split from the fp32
+    value).  On the training shapes of the wide model, after 100 steps of training (not at initialisation), every gradient tensor of the
+    plane plan agrees with the fp32-operand plan's to 2e-4 of the tensor's maximum (kernel-level: tests/test_x3_gpu.py, 4e-5)."""
+    from hftt_hip.trainer import TrainStep
+    cfg, B = WIDE, 4
+    spec, labels = make_clips(cfg, 64, seed=1)
+    model = scaled_model(cfg, 2025, 0.1).to(dev)
+    model.hftt_precision = 'x3'
+    model.train()
+    ts = TrainStep(model, lr=3e-4)
+    for s_ in range(100):
+        idx = [(s_ * B + i) % 64 for i in range(B)]
+        ts(spec[idx].to(dev), *[t[idx].to(dev).contiguous() for t in labels])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    grads = {}
+    idx = list(range(B))
+    for planes in ('1', '0'):
+        monkeypatch.setenv('HFTT_X3_PLANES', planes)
+        m2 = util.build_model(cfg, 1, dropout=0.1)
+        m2.load_state_dict(sd)
+        m2 = m2.to(dev)
+        m2.hftt_precision = 'x3'
+        m2.train()
+        t2 = TrainStep(m2, lr=3e-4)
+        assert t2.engine.planes_opt == (planes == '1')
+        t2.engine.step_counter = 1000                 # the same dropout masks in both plans
+        t2.forward_backward(spec[idx].to(dev), *[t[idx].to(dev).contiguous() for t in labels])
+        grads[planes] = {n: t2.engine.flat_grads[o:o + k].clone() for (n, _p, o, k) in t2.engine._bound}
+    worst = 0.0
+    for n, a in grads['1'].items():
+        b = grads['0'][n]
+        scale = float(b.abs().max())
+        if scale < 1e-9:
+            continue
+        worst = max(worst, float((a - b).abs().max()) / scale)
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (n, float((a - b).abs().max()), scale)
+    print('  plane vs fp32-operand plan, worst gradient difference / tensor maximum: %.2e' % worst)
 
 
 def test_paper_size_modes_train_alike(dev):

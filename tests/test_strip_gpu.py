@@ -249,8 +249,12 @@ def test_pipelined_linear_is_bit_identical(dev, monkeypatch, M):
     assert torch.equal(a[0], b[0])
 
 
-@pytest.mark.parametrize('M', [128, 4096, 38432])
-def test_pipelined_ffn_is_bit_identical(dev, monkeypatch, M):
+@pytest.mark.parametrize('wpc', ['1', '2'])
+@pytest.mark.parametrize('M', [128, 4096, 38432, 140032])
+def test_pipelined_ffn_is_bit_identical(dev, monkeypatch, M, wpc):
+    """both register plans of the pipelined fused block -- one workgroup per CU with the next block prefetched, two per CU at half the
+    registers (round 5; M = 140,032 = 1,094 blocks: a workgroup of either walks several) -- against the general form, bit for bit"""
+    monkeypatch.setenv('HFTT_MLP2_WPC', wpc); monkeypatch.setenv('HFTT_MLP2_WPC_BWD', wpc)
     ops = _ops()
     g = torch.Generator().manual_seed(M + 1)
     d, pf = 256, 512

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../nylon-amt_amd"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -DHFTT_X3_STRIP_ABLATE -x hip -c csrc/x3_strip.hip -o build/x3_strip_ablate.o
-OBJS=$(ls build/*.o | grep -v "x3_strip\|\.x\.o\|strip_gemm[345]\|_g8\|_ablate")
+OBJS=$(ls build/*.o | grep -v "x3_strip\|\.x\.o\|\.g\.o\|strip_gemm[345]\|_g8\|_ablate")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libhftt_xstrip.so $OBJS build/x3_strip_ablate.o
 cd ..
 for bits in ${ABLATE_BITS:-0 16 32 48 1 2}; do

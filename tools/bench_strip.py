@@ -33,7 +33,8 @@ def line(name, us, flops, nbytes):
 
 
 def main():
-    only_strip = len(sys.argv) > 1 and sys.argv[1] == 'strip'
+    only_strip = len(sys.argv) > 1 and sys.argv[1] in ('strip', 'ffn')
+    ffn_only = len(sys.argv) > 1 and sys.argv[1] == 'ffn'
     M = int(os.environ.get('M', 262144))
     d, p = 256, 512
     g = torch.Generator().manual_seed(1)
@@ -46,6 +47,14 @@ def main():
     gam = torch.ones(d, device=dev); bet = torch.zeros(d, device=dev)
     res = torch.randn(M, d, generator=g).to(dev); resb = res.to(BF)
 
+    if ffn_only:
+        wf = ops.ffn_pack(W1, W2)
+        fl = 4.0 * M * d * p
+        line('ffn  fused training (h + pre saved, p=0.1)', timeit(lambda: ops.ffn_res_ln_fwd(xb, wf, p, b1, b2, gam, bet, drop_p=0.1, site_h=4, site_o=5, seed=7)),
+             fl, M * d * 2 * 3 + M * p * 2)
+        line('ffn  fused inference (nothing saved)', timeit(lambda: ops.ffn_res_ln_fwd(xb, wf, p, b1, b2, gam, bet, save_hidden=False, save_pre=False)),
+             fl, M * d * 2 * 2)
+        return
     # ---- QKV projection ----
     wq_s = ops.strip_pack(Wq); wq_o = ops.prepare_weight(Wq, 1)
     fl = 2.0 * M * 3 * d * d
