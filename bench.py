@@ -264,13 +264,21 @@ def measure_pmc(args, timeout_s=170):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    kernels, total = {}, 0.0
+    # Per-step bytes = sum over kernel symbols of (bytes per launch) x (launches per step), with launches per step = launches // 3 over the
+    # child's 1 + 2 steps: a kernel launched fewer than three times (model initialisation, data synthesis, plan warm-up) belongs to no step
+    # and is left out, and so is the remainder of a symbol that also ran once outside the steps (the plain total / 3 counted them,
+    # proportionally more on the small configuration).  The one-off bytes are reported beside the figure.
+    kernels, total, one_off = {}, 0.0, 0.0
+    n_child_steps = 3
     for k in set(per['FETCH_SIZE']) | set(per['WRITE_SIZE']):
         f, w = per['FETCH_SIZE'].get(k, [0.0, 0]), per['WRITE_SIZE'].get(k, [0.0, 0])
         n = max(f[1], w[1], 1)
         kernels[k] = (f[0] + w[0]) / n
-        total += f[0] + w[0]
-    return {'kernels': kernels, 'bytes_per_step': total / 3.0, 'source': 'this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of the same command (1 + 2 steps)'}
+        per_step = n // n_child_steps
+        total += kernels[k] * per_step
+        one_off += kernels[k] * (n - per_step * n_child_steps)
+    return {'kernels': kernels, 'bytes_per_step': total, 'bytes_outside_the_steps': one_off, 'divisor': 'per kernel symbol: launches // %d' % n_child_steps,
+            'source': 'this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of the same command (1 + 2 steps); kernels launched per step only'}
 
 
 def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench', mfma_passes=1):
@@ -617,6 +625,8 @@ def main():
         step_bytes, step_src = pmc_step_bytes()
         if _LIVE_PMC is not None:
             step_bytes, step_src = _LIVE_PMC['bytes_per_step'], _LIVE_PMC['source']
+            result['hbm_bytes_outside_the_steps'] = _LIVE_PMC.get('bytes_outside_the_steps')
+            result['hbm_bytes_divisor'] = _LIVE_PMC.get('divisor')
         if step_bytes is not None:
             # whole-step HBM traffic (PMC sum over every kernel of a profiled run of this same command) over THIS run's step time
             result['hbm_bytes_per_step'] = step_bytes

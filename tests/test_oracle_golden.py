@@ -123,3 +123,28 @@ def test_transcript_windowing_identity_model():
         outs = O.transcript_stride(feat, n_off, fwd, cfg, min_value=-5.0)
         assert outs[0].shape[1] == 4 and outs[0].shape[0] % 4 == 0
         np.testing.assert_array_equal(outs[1][:n], feat + 1)
+
+
+def test_config5_paper_trained_golden():
+    """Round 5: the CPU oracle against the REFERENCE's outputs on TRAINED paper-size weights (tests/golden/config5_paper_golden.npz, made by
+    make_golden_r5.py from config5_paper_trained.npz: the paper-size model this repo's training step trained, two clips of config 5's minute).
+    The six posterior tensors in full, samples of the velocity logits and of the attention tensor: 2e-6 of the tensor's scale."""
+    import os, sys
+    sys.path.insert(0, os.path.join(util.ROOT, 'tools'))
+    from pack_checkpoint import unpack_state_dict
+    g = util.golden('config5_paper_golden')
+    sd = unpack_state_dict(np.load(os.path.join(util.GOLDEN, 'config5_paper_trained.npz')))
+    assert len(sd) == 165 and sum(v.numel() for v in sd.values()) == 5516574
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    with torch.no_grad():
+        out = O.model_forward(sd, torch.from_numpy(g['input']), O.PAPER)
+    for n, t in zip(util.OUT_NAMES, out):
+        if 'out.' + n in g.files:
+            assert util.max_err(t, torch.from_numpy(g['out.' + n])) < 2e-6, n
+        else:
+            f = t.reshape(-1)
+            ref = torch.from_numpy(g['out.' + n + '.sample'])
+            assert util.max_err(f[::int(g['out.' + n + '.stride'])], ref) < 2e-6 * max(1.0, float(g['out.' + n + '.stats'][1])), n
+    # the fixture's model means something: a trained transcriber is confident -- most posteriors sit near 0 or 1
+    mpe = torch.from_numpy(g['out.mpe_B'])
+    assert float(((mpe < 0.05) | (mpe > 0.95)).float().mean()) > 0.97 and 0.01 < float((mpe >= 0.5).float().mean()) < 0.2

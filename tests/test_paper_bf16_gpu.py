@@ -9,6 +9,7 @@ autocast row with 1.4x headroom for other seeds / inputs, and every test prints 
 import json
 import os
 import pickle
+import sys
 
 import numpy as np
 import pytest
@@ -299,3 +300,76 @@ def test_config5_with_trained_weights(dev, tmp_path):
         a, b = mpe['x3'][k], mpe['parity'][k]
         assert float(np.abs(a - b).max()) <= 1e-3 and int(((a >= 0.5) != (b >= 0.5)).sum()) == 0, k
     assert float((mpe['x3'][7] != mpe['parity'][7]).mean()) < 2e-3 and float((mpe['x3'][3] != mpe['parity'][3]).mean()) < 2e-3
+
+
+def _paper_trained_pkl(tmp_path):
+    """tests/golden/config5_paper_trained.npz (tools/pack_checkpoint.py) -> this repo's module -> a pickle as m_training.py:372-373 writes it"""
+    sys.path.insert(0, os.path.join(util.ROOT, 'tools'))
+    from pack_checkpoint import unpack_state_dict
+    sd = unpack_state_dict(np.load(os.path.join(util.GOLDEN, 'config5_paper_trained.npz')))
+    model = util.build_model(O.PAPER, 1)
+    model.load_state_dict(sd)
+    f = tmp_path / 'paper_trained.pkl'
+    with open(f, 'wb') as fh:
+        pickle.dump(model, fh, protocol=4)
+    return model, str(f)
+
+
+def test_config5_paper_size_trained_weights_against_the_reference(dev, tmp_path):
+    """BASELINE config 5 at PAPER size with weights that mean something.  tests/golden/config5_paper_trained.npz is the
+    paper-size model (d 256, ff 512, 3+3 layers, 4 heads) after 12,000 steps of THIS path's training step in the default x3 mode on the synthetic
+    plucked-string corpus (six minutes at 266 clips/s; recipe and log: profiles/r05_config5_paper_trained.json).
+    (1) Against the REFERENCE module's own CPU outputs on those weights (config5_paper_golden.npz, tests/golden/make_golden_r5.py: two of the
+        minute's 30 clips): every posterior and logit within north_star's 1e-3, no frame decision different, the velocity argmax equal wherever
+        the reference's top-two margin exceeds 2e-3, the attention map within 1e-3 -- the default mode against the reference, not against
+        another mode of this repo.
+    (2) The whole of config 5 from the HIP log-mel on: note-F1 (onset, 50 ms) and frame-F1 against the GENERATING notes of the unseen minute
+        (seed 1234), and x3 against the exact-fp32 mode on all 30 clips."""
+    from model.amt import AMT
+    from corpus import synth_audio as SA
+    from evaluation.metrics import note_metrics, frame_metrics
+    model, pkl = _paper_trained_pkl(tmp_path)
+    g = util.golden('config5_paper_golden')
+    # ---- (1) the reference's outputs ----
+    m = model.to(dev).eval()
+    m.hftt_precision = 'x3'
+    with torch.no_grad():
+        out = [t.float().cpu() for t in m(torch.from_numpy(g['input']).to(dev))]
+    rep = {}
+    for n, t in zip(util.OUT_NAMES, out):
+        if 'out.' + n in g.files:
+            ref = torch.from_numpy(g['out.' + n])
+            rep[n] = max_err(t, ref)
+            assert rep[n] <= 1e-3, (n, rep[n])
+            assert int(((t >= 0.5) != (ref >= 0.5)).sum()) == 0, n
+        else:
+            f = t.reshape(-1)
+            rep[n] = max_err(f[::int(g['out.' + n + '.stride'])], torch.from_numpy(g['out.' + n + '.sample']))
+            assert rep[n] <= 1e-3, (n, rep[n], float(g['out.' + n + '.stats'][1]))
+            if n != 'attention':
+                decided = torch.from_numpy(g['out.' + n + '.margin']) > 2e-3
+                same = t.argmax(-1) == torch.from_numpy(g['out.' + n + '.argmax']).long()
+                assert bool(same[decided].all()), n
+                rep[n + '.argmax_equal'] = float(same.float().mean())
+    print('config 5, paper size, trained weights, x3 vs the reference (2 clips):', json.dumps({k: float('%.3g' % v) for k, v in rep.items()}))
+    # ---- (2) the whole minute ----
+    notes = SA.pluck_notes(1234)
+    wave = SA.pluck_wave(notes)
+    res, outs = {}, {}
+    for mode in ('parity', 'x3', 'bf16'):
+        amt = AMT(SA.default_config(), pkl, batch_size=32)
+        amt.model.hftt_precision = mode
+        feat = amt.wave2feature(wave.unsqueeze(0), SA.SR)
+        o = amt.transcript(feat.numpy())
+        est = amt.mpe2note(a_onset=o[4], a_offset=o[5], a_mpe=o[6], a_velocity=o[7])
+        nm = note_metrics(notes, est)
+        fm = frame_metrics(SA.reference_roll(notes, feat.shape[0]), o[6], threshold=0.5)
+        outs[mode] = o
+        res[mode] = {'note_f1': round(nm['F-measure'], 4), 'note_P': round(nm['Precision'], 4), 'note_R': round(nm['Recall'], 4),
+                     'frame_f1': round(fm['f1'], 4), 'n_est': len(est), 'n_ref': len(notes)}
+    print('config 5, paper size, trained weights, against the generating notes:', json.dumps(res))
+    assert res['x3']['note_f1'] >= 0.90 and res['x3']['frame_f1'] >= 0.85, res
+    assert res['bf16']['note_f1'] >= 0.90 and abs(res['bf16']['frame_f1'] - res['parity']['frame_f1']) < 5e-3, res
+    for k in (0, 1, 2, 4, 5, 6):
+        a, b = outs['x3'][k], outs['parity'][k]
+        assert float(np.abs(a - b).max()) <= 1e-3 and int(((a >= 0.5) != (b >= 0.5)).sum()) == 0, k
