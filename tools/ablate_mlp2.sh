@@ -8,7 +8,7 @@ OBJS=$(ls build/*.o | grep -v "strip_gemm2\|\.x\.o\|\.g\.o\|strip_gemm[345]\|_g8
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libhftt_abl2.so $OBJS build/strip_gemm2_ablate.o
 cd ..
 for wpc in 1 2; do
-  for bits in ${ABLATE_BITS:-0 1 2 3 64 128 192 256 259 451}; do
+  for bits in ${ABLATE_BITS:-0 1 2 3 64 128 192 256 259 451 512}; do
     echo "### WPC=$wpc HFTT_STRIP2_DEBUG=$bits"
     HFTT_LIB_PATH=$PWD/nylon-amt_amd/lib/libhftt_abl2.so HFTT_MLP2_WPC=$wpc HFTT_STRIP2_DEBUG=$bits python tools/bench_strip.py ffn
   done
