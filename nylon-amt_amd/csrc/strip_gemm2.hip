@@ -736,9 +736,20 @@ int hftt_strip_mlp2_try(const hftt_ffn_desc& d0, hipStream_t st) {
   d.pad = strip2_debug();
   if (!v2_enabled() || d.p != 512 || d.M % 32 != 0) return -1;
   if (d.mode == 0 && d.residual != nullptr) return -1;
-  if (mlp2_wpc(d.mode == 0 ? 0 : 1) == 2) return d.mode == 0 ? launch_mlp2<0, 2, false>(d, st) : launch_mlp2<1, 2, false>(d, st);
-  // HFTT_MLP2_PATCH=0: the round-2 row-piece stores (A/B switch; default: whole lines through the LDS patches)
+  if (mlp2_wpc(d.mode == 0 ? 0 : 1) == 2) {
+#ifdef HFTT_STRIP_EXPERIMENTS
+    return d.mode == 0 ? launch_mlp2<0, 2, false>(d, st) : launch_mlp2<1, 2, false>(d, st);
+#else
+    hftt_set_error("strip_mlp2: the two-workgroups-per-CU plan (HFTT_MLP2_WPC=2) is a measured-and-rejected experiment (DESIGN section 5, round 5); "
+                   "it is only in HFTT_BUILD_EXPERIMENTS=1 builds");
+    return 1;
+#endif
+  }
+  // Whole-line stores through the LDS patches (STP), chosen per form by measurement (round 5, S_e, same box, row pieces -> patches): forward
+  // with the hidden and the pre-LayerNorm rows saved 288.0 -> 269.8 us (253.7 -> 231.7 without dropout); inference form 191.5 -> 195.1 and
+  // the backward 307.2 -> 313.5, so those keep the row pieces.  HFTT_MLP2_PATCH=0 / 1 forces either (A/B, tests).
   const char* e = getenv("HFTT_MLP2_PATCH");
-  if (e && e[0] == '0') return d.mode == 0 ? launch_mlp2<0, 1, false>(d, st) : launch_mlp2<1, 1, false>(d, st);
+  const bool stp = e ? (e[0] != '0') : (d.mode == 0 && (d.h_out != nullptr || d.pre_ln_out != nullptr));
+  if (!stp) return d.mode == 0 ? launch_mlp2<0, 1, false>(d, st) : launch_mlp2<1, 1, false>(d, st);
   return d.mode == 0 ? launch_mlp2<0, 1, true>(d, st) : launch_mlp2<1, 1, true>(d, st);
 }

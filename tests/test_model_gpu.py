@@ -537,7 +537,7 @@ def test_cpu_call_fails_loudly():
         model(torch.zeros(1, MINI.n_bin, MINI.n_frame + 2 * MINI.n_margin))
 
 
-def test_training_train_mirror_fast_and_compat_paths(dev):
+def test_training_train_mirror_fast_and_compat_paths(dev, tmp_path, monkeypatch):
     """training.train.train()/valid() (signature of training/train.py:63,168): torch.optim.Adam + nn criteria (what
     m_training.py passes) and the fused path give the same parameters after two steps (dropout 0)."""
     import torch.nn as nn
@@ -563,8 +563,11 @@ def test_training_train_mirror_fast_and_compat_paths(dev):
     # Adam's first steps move every element by ~lr regardless of gradient size: noise-level gradients may take opposite signs
     assert (res['compat'][2] - res['fast'][2]).abs().max().item() <= 4.1e-3
     assert (res['compat'][2] - res['fast'][2]).abs().mean().item() < 2e-5
-    with pytest.raises(Exception):
-        T.valid(model, batches, *crits, 1.0, 1.0, dev, True)
+    # metrics=True (the reference's default last step, m_training.py:466-470): same loss, plus the scores file in the working directory
+    # (round 5; the replay test checks the values)
+    monkeypatch.chdir(tmp_path)
+    lm, nm = T.valid(model, batches, *crits, 1.0, 1.0, dev, True)
+    assert nm == 2 and abs(lm - res['fast'][1]) < 1e-6 * abs(lm) and (tmp_path / 'test_performance.json').exists()
 
 
 def test_inference_wave_to_midi_end_to_end(dev, tmp_path):
