@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HFTT_ABI_VERSION 5
+#define HFTT_ABI_VERSION 6
 
 int hftt_abi_version(void);
 /* bit 0: the library carries the opt-in gradient-rounding forms (HFTT_SL_X3_GRAD_HI, HFTT_TN_DY_HI, HFTT_NT_A_HI: a gradient operand enters a
@@ -427,6 +427,22 @@ typedef struct {
   float* feat;
 } hftt_logmel_desc;
 int hftt_logmel(const hftt_logmel_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Resampling in front of the log-mel (model/amt.py:57-58: torchaudio.transforms.Resample(sr, 16000) with its defaults -- Hann-windowed sinc,
+ * lowpass_filter_width 6, rolloff 0.99; torchaudio is un-vendored and absent: published algorithm, parity unpinned).  With g = gcd(sr_in,
+ * sr_out), down = sr_in / g, up = sr_out / g, width = ceil(6 * down / (min(down, up) * 0.99)): the host builds the kernel table
+ * kernel[up, taps], taps = 2 * width + down (row p = the windowed sinc sampled for output phase p), and
+ *     out[f * up + p] = sum_t wave[f * down - width + t] * kernel[p, t]          (samples outside [0, n_in) are zeros)
+ * for the first n_out = ceil(n_in * up / down) outputs.  fp32 accumulate in tap order.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* wave; int64_t n_in;
+  const float* kernel;       /* [up, taps] */
+  int32_t up, down, width, taps;
+  float* out; int64_t n_out;
+} hftt_resample_desc;
+int hftt_resample(const hftt_resample_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,12 @@ class LogmelDesc(C.Structure):
                 ('feat', c_f32p)]
 
 
+class ResampleDesc(C.Structure):
+    _fields_ = [('wave', c_f32p), ('n_in', C.c_int64), ('kernel', c_f32p),
+                ('up', C.c_int32), ('down', C.c_int32), ('width', C.c_int32), ('taps', C.c_int32),
+                ('out', c_f32p), ('n_out', C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/hftt_hip.h declares
 SIGNATURES = {
     'hftt_abi_version': (C.c_int, []),
@@ -185,10 +191,11 @@ SIGNATURES = {
     'hftt_adam_step': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,
                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     'hftt_logmel': (C.c_int, [C.POINTER(LogmelDesc), C.c_void_p]),
+    'hftt_resample': (C.c_int, [C.POINTER(ResampleDesc), C.c_void_p]),
 }
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HfttError(RuntimeError):

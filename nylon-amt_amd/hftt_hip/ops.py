@@ -10,7 +10,7 @@ import math
 import numpy as np
 import torch
 
-from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
+from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, ResampleDesc, PrepEntry, StripDesc, StripPackEntry,
                     SL_C_BF16, SL_C_F16PAIR, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16,
                     ATTN_Q_F16PAIR, ATTN_KV_F16PAIR, check, lib)
 
@@ -466,3 +466,36 @@ class LogMel:
         d.feat = feat.data_ptr()
         check(lib().hftt_logmel(C.byref(d), _stream(self.device)), 'logmel')
         return feat
+
+
+def resample_kernel_table(sr_in, sr_out, lowpass_filter_width=6, rolloff=0.99):
+    """(kernel [up, taps] float64 tensor, up, down, width) of torchaudio.transforms.Resample's defaults (Hann-windowed sinc): the published
+    algorithm restated (torchaudio is absent: parity unpinned at that boundary)."""
+    g = math.gcd(int(sr_in), int(sr_out))
+    down, up = int(sr_in) // g, int(sr_out) // g
+    base = min(down, up) * rolloff
+    width = math.ceil(lowpass_filter_width * down / base)
+    idx = torch.arange(-width, width + down, dtype=torch.float64)[None, :] / down
+    t = (torch.arange(0, -up, -1, dtype=torch.float64)[:, None] / up + idx) * base
+    t = t.clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kern = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / down)
+    return kern, up, down, width
+
+
+def resample(wave_mono, sr_in, sr_out):
+    """wave [n] fp32 device tensor at sr_in -> [ceil(n * sr_out / sr_in)] at sr_out (hftt_resample: polyphase, fp32)."""
+    _need_cuda(wave_mono)
+    kern, up, down, width = resample_kernel_table(sr_in, sr_out)
+    wave = wave_mono.contiguous().float()
+    kd = kern.float().contiguous().to(wave.device)
+    n = wave.numel()
+    n_out = -(-n * up // down)
+    out = torch.empty(n_out, device=wave.device)
+    d = ResampleDesc()
+    d.wave, d.n_in, d.kernel = wave.data_ptr(), n, kd.data_ptr()
+    d.up, d.down, d.width, d.taps = up, down, width, kd.shape[1]
+    d.out, d.n_out = out.data_ptr(), n_out
+    check(lib().hftt_resample(C.byref(d), _stream(wave.device)), 'resample')
+    return out

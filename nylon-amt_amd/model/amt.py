@@ -74,7 +74,7 @@ class AMT():
         wave = wave.float()
         wave_mono = wave.mean(dim=0) if wave.dim() == 2 else wave        # torch.mean(wave, dim=0), amt.py:56
         if sr != fe['sr']:
-            wave_mono = _resample(wave_mono, sr, fe['sr'])                # Resample(sr, 16000), amt.py:57-58
+            wave_mono = ops.resample(wave_mono.to(self.device), sr, fe['sr'])      # Resample(sr, 16000), amt.py:57-58: hftt_resample (HIP)
         if self._logmel is None:
             if fe['fft_bins'] != fe['window_length']:
                 raise HfttError('window_length must equal fft_bins')
@@ -304,25 +304,3 @@ def _load_wav(path):
     else:
         x = data.astype(np.float32)
     return np.ascontiguousarray(x.T), int(sr)
-
-
-def _resample(wave, sr_in, sr_out):
-    """Band-limited (Hann-windowed sinc, width 6, rolloff 0.99) resampling: the published algorithm of
-    torchaudio.transforms.Resample's defaults.  Host-side preprocessing, parity unpinned (torchaudio absent)."""
-    import math
-    g = math.gcd(int(sr_in), int(sr_out))
-    orig, new = int(sr_in) // g, int(sr_out) // g
-    lowpass_filter_width, rolloff = 6, 0.99
-    base = min(orig, new) * rolloff
-    width = math.ceil(lowpass_filter_width * orig / base)
-    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, :] / orig
-    t = (torch.arange(0, -new, -1, dtype=torch.float64)[:, None] / new + idx) * base
-    t = t.clamp(-lowpass_filter_width, lowpass_filter_width)
-    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
-    t = t * math.pi
-    kern = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / orig)
-    x = torch.nn.functional.pad(wave.double()[None, None, :], (width, width + orig))
-    y = torch.nn.functional.conv1d(x, kern[:, None, :], stride=orig)      # [1, new, frames]
-    y = y.transpose(1, 2).reshape(-1)
-    target = int(math.ceil(new * wave.numel() / orig))
-    return y[:target].float()

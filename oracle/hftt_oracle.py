@@ -349,3 +349,25 @@ def logmel_dft(wave_mono_16k: torch.Tensor, n_fft=2048, hop=256, n_mels=256, log
     im = frames @ torch.sin(ang).T
     power = re * re + im * im
     return torch.log(power @ mel_filterbank(sr, n_fft, n_mels).double() + log_offset).float()
+
+
+def resample(wave: torch.Tensor, sr_in: int, sr_out: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> torch.Tensor:
+    """model/amt.py:57-58: torchaudio.transforms.Resample(sr, 16000) with its defaults, restated from the published algorithm (Hann-windowed
+    sinc interpolation, torchaudio.functional.resample: `_get_sinc_resample_kernel` + `_apply_sinc_resample_kernel`); float64 on the CPU.
+    torchaudio is un-vendored, unpinned and absent: PARITY UNPINNED at that boundary -- this restatement is what the HIP kernel
+    (hftt_resample) is held against, and it is itself checked on band-limited signals (tests/test_amt_host.py)."""
+    g = math.gcd(int(sr_in), int(sr_out))
+    orig, new = int(sr_in) // g, int(sr_out) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, :] / orig
+    t = (torch.arange(0, -new, -1, dtype=torch.float64)[:, None] / new + idx) * base
+    t = t.clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kern = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / orig)
+    x = torch.nn.functional.pad(wave.double()[None, None, :], (width, width + orig))
+    y = torch.nn.functional.conv1d(x, kern[:, None, :], stride=orig)      # [1, new, frames]
+    y = y.transpose(1, 2).reshape(-1)
+    target = int(math.ceil(new * wave.numel() / orig))
+    return y[:target].float()

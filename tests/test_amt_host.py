@@ -92,7 +92,8 @@ def test_mpe2note_matches_reference(tmp_path):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # WAV loader and resampler of wav2feature (reference: torchaudio.load + transforms.Resample, amt.py:55-58; torchaudio is
-# not in this image, so the resampler is a restatement of its published algorithm -- checked here against analytic
+# not in this image, so the resampler is a restatement of its published algorithm (oracle.hftt_oracle.resample; the product runs the HIP kernel
+# hftt_resample, held against that restatement in tests/test_small_kernels_gpu.py) -- checked here against analytic
 # signals and against scipy's polyphase resampler as an independent implementation).
 # ---------------------------------------------------------------------------------------------------------------------
 import math
@@ -101,7 +102,8 @@ import pytest
 
 @pytest.mark.parametrize('sr_in', [44100, 48000, 22050, 8000])
 def test_resample_reproduces_a_band_limited_signal(sr_in):
-    from model.amt import _resample
+    from util import O
+    _resample = O.resample
     sr_out, dur = 16000, 0.25
     n = int(sr_in * dur)
     f1, f2 = 440.0, 2500.0                                    # both below every Nyquist involved
@@ -122,7 +124,8 @@ def test_resample_reproduces_a_band_limited_signal(sr_in):
 
 
 def test_resample_removes_what_the_new_rate_cannot_carry():
-    from model.amt import _resample
+    from util import O
+    _resample = O.resample
     sr_in, sr_out = 44100, 16000
     t = torch.arange(sr_in // 4, dtype=torch.float64) / sr_in
     tone = torch.sin(2 * math.pi * 11000.0 * t).float()                            # above the new Nyquist (8 kHz)

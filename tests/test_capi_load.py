@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(_capi.SIGNATURES.keys()), declared ^ set(_capi.SIGNATURES.keys())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hftt_abi_version() == _capi.ABI_VERSION == 5
+    assert lib.hftt_abi_version() == _capi.ABI_VERSION == 6
     assert lib.hftt_last_error() is not None
     # pure host helpers can be called without a GPU
     assert lib.hftt_gemm_tn_ws_bytes(1000, 256, 256) > 0
@@ -69,7 +69,7 @@ def test_struct_layouts_match_the_c_compiler(lib, tmp_path):
     from hftt_hip import _capi
     structs = {'hftt_prep_entry': _capi.PrepEntry, 'hftt_gemm_nt_desc': _capi.GemmNtDesc, 'hftt_gemm_tn_desc': _capi.GemmTnDesc,
                'hftt_attn_desc': _capi.AttnDesc, 'hftt_fold_desc': _capi.FoldDesc, 'hftt_ln_bwd_desc': _capi.LnBwdDesc,
-               'hftt_loss_desc': _capi.LossDesc, 'hftt_logmel_desc': _capi.LogmelDesc,
+               'hftt_loss_desc': _capi.LossDesc, 'hftt_logmel_desc': _capi.LogmelDesc, 'hftt_resample_desc': _capi.ResampleDesc,
                'hftt_strip_pack_entry': _capi.StripPackEntry, 'hftt_strip_desc': _capi.StripDesc, 'hftt_ffn_desc': _capi.FfnDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HDR, 'int main(void) {']
     for cname, cls in structs.items():

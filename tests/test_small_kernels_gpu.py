@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 import util
-from util import keep_scale, rel_err, max_err, keep_mask_t
+from util import O, keep_scale, rel_err, max_err, keep_mask_t
 
 pytestmark = pytest.mark.gpu
 
@@ -207,3 +207,34 @@ def test_dropout_bwd_in_place(dev, half):
     assert abs(rate - 230 / 256) < 4 * math.sqrt(0.9 * 0.1 / (M * N))
     with pytest.raises(capi.HfttError):
         capi.check(L.hftt_dropout_bwd(buf.data_ptr(), M * N + 2, p, site, seed, 0, _st(dev)), 'dropout_bwd')
+
+
+@pytest.mark.parametrize('sr_in', [44100, 48000, 22050, 8000, 32000])
+def test_resample_kernel_against_the_float64_restatement(dev, sr_in):
+    """hftt_resample (model/amt.py:57-58: Resample(sr, 16000)) against oracle.resample on the same samples: output length = ceil(n * 16000 / sr),
+    every sample within 2e-6 of the float64 polyphase sum (fp32 accumulation over <= 475 taps of a unit-gain filter); odd lengths, the zero
+    padding at both borders included.  Then through AMT.wave2feature: a 44.1 kHz wave gives the features of its resampled self."""
+    from hftt_hip import ops
+    g = torch.Generator().manual_seed(sr_in)
+    for n in (sr_in // 3 + 7, 1001):
+        x = (torch.rand(n, generator=g) * 2 - 1).float()
+        y = ops.resample(x.to(dev), sr_in, 16000).cpu()
+        ref = O.resample(x, sr_in, 16000)
+        assert y.shape == ref.shape and y.numel() == -(-n * 16000 // sr_in)
+        assert max_err(y, ref) < 2e-6 * 4, (sr_in, n, max_err(y, ref))
+
+
+def test_wave2feature_resamples_on_the_device(dev, tmp_path):
+    import pickle
+    from model.amt import AMT
+    from corpus import synth_audio as SA
+    f = tmp_path / 'm.pkl'
+    with open(f, 'wb') as fh:
+        pickle.dump(util.build_model(O.MICRO, 1), fh, protocol=4)
+    amt = AMT(SA.default_config(), str(f))
+    t = torch.arange(44100, dtype=torch.float64) / 44100.0
+    wave = (0.3 * torch.sin(2 * math.pi * 440.0 * t) + 0.2 * torch.sin(2 * math.pi * 1234.5 * t)).float()
+    feat = amt.wave2feature(wave, 44100)
+    ref = O.logmel(O.resample(wave, 44100, 16000))
+    assert feat.shape == ref.shape == (1 + 16000 // 256, 256)
+    assert max_err(feat, ref) < 5e-3          # log of a power spectrum: the fp32 FFT's relative error (test_logmel's bound)
