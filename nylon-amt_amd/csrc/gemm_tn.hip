@@ -179,7 +179,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
     } else if (X3M) {
       unsigned short* base = sm16 + buf * Cfg::BUF_ELEMS + which * Cfg::Y_ELEMS;
       uint2 hi, lo;
+#ifdef HFTT_TN_NOSPLIT
+      // timing experiment (tools/ablate_tn.sh; results garbage): the loader of VERDICT r04 item 5a -- operands that arrive pre-split only have to be
+      // copied -- approximated from above: two byte permutes per four elements instead of the split's sixteen vector operations
+      hi.x = __builtin_amdgcn_perm(u.y, u.x, 0x07060302u); hi.y = __builtin_amdgcn_perm(u.w, u.z, 0x07060302u); lo = hi;
+#else
       x3_split4<EX>(f, hi, lo);
+#endif
       *reinterpret_cast<uint2*>(base + off) = hi;
       if (!(DYH && which == 0)) *reinterpret_cast<uint2*>(base + (which ? BMT * RSX : BMT * RSY) + off) = lo;
     } else {
