@@ -194,10 +194,23 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
   // xf: this step's activations.  xn: the next step's, in flight.  pend: results of the last finished pass waiting to be stored, two
   // pieces per slot; once a piece is on its way its registers receive the residual rows the NEXT epilogue needs (one set for both).
   u4v xf[16], xn[16], pend[16];
+  // STP: the strip rows arrive as whole-line pieces (xn[4 p + k]: tile pair p, rows (lane >> 3) + 8 k, chunk lane & 7) from a wave-uniform base
+  // (M % 32 == 0: a wave's 32 rows are all valid or all past the end -- then the last 32 rows are read again, harmlessly) and are turned into
+  // the lane's own row pieces through the result patch when a step starts (patch_put_lines / patch_get_rows)
+  auto wave_rows = [&](long blk) { const long r0 = blk * 128 + wave * 32; const long rc = r0 < (long)g.M ? r0 : (long)g.M - 32; return xb + rc * g.ldx; };
+  // whole-line loads where the launch is load-heavy (K >= 512: dX of the fused projections, same box 187-197 -> 176 us); at K = 256 the strip
+  // is loaded once per block and the LDS round trip costs more than it saves (QKV 174 -> 180 us).  HFTT_LINEAR2_LINES=0 / 1 forces either (A/B).
+  const bool lines = STP && ((g.pad & 0x30000) ? ((g.pad & 0x20000) != 0) : (KCH > 1));
   {
-    const unsigned short* p0 = xb + tok_of(blockIdx.x) * g.ldx + 16 * h;
+    if (lines) {
+      const unsigned short* b0 = wave_rows(blockIdx.x);
 #pragma unroll
-    for (int i = 0; i < 16; i++) pload16(xn[i], p0 + piece_off(i));
+      for (int i = 0; i < 16; i++) xn[i] = aload16s(b0, patch_off(lane, i & 3, g.ldx, i >> 2));
+    } else {
+      const unsigned short* p0 = xb + tok_of(blockIdx.x) * g.ldx + 16 * h;
+#pragma unroll
+      for (int i = 0; i < 16; i++) pload16(xn[i], p0 + piece_off(i));
+    }
     P.issued += 16;
   }
   P.fill<0>(); P.fill<1>(); P.fill<2>();
@@ -242,8 +255,16 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
       }
       for (int kc = 0; kc < KCH; kc++) {
         if (KCH > 1 || pass == 0) {                   // this step's activations: prefetched during the previous step (or the prologue)
+          if (lines) {
 #pragma unroll
-          for (int i = 0; i < 16; i++) xf[i] = xn[i];
+            for (int pr = 0; pr < 4; pr++) {
+              patch_put_lines(patchC, lane, xn[4 * pr], xn[4 * pr + 1], xn[4 * pr + 2], xn[4 * pr + 3]);
+              patch_get_rows(patchC, j, hb, xf[4 * pr], xf[4 * pr + 1], xf[4 * pr + 2], xf[4 * pr + 3]);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) xf[i] = xn[i];
+          }
         }
 #ifdef HFTT_STRIP_STAMPS
         if (bstamp && pass == 0 && kc == 0) bsb[37] = __builtin_amdgcn_s_memtime();
@@ -251,6 +272,7 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
         const bool last_step = (pass == passes - 1) && (kc == KCH - 1);
         const bool pf_x = (KCH > 1) ? true : last_step;      // (past the last block the address falls back to this block's rows: a harmless re-read)
         const unsigned short* pf_src = (KCH > 1 && !last_step) ? (xb + tokc * g.ldx + (kc + 1 == KCH ? 0 : kc + 1) * 256 + 16 * hb) : xrow_next;
+        const unsigned short* pf_base = (KCH > 1 && !last_step) ? (wave_rows(blk) + (kc + 1 == KCH ? 0 : kc + 1) * 256) : wave_rows(has_next ? nxt : blk);      // (STP: wave-uniform)
         const bool pf_res = (KCH == 1) || (kc == KCH - 1);
         const unsigned short* res_src = rb + (has_res ? rrow * g.ldr + pass * 256 + 16 * hb : 0);
         // -DHFTT_STRIP_STAMPS builds only (tools/stamp_linear2.sh), HFTT_STRIP2_DEBUG & 4, !LN: thread 0 of each workgroup's SECOND block stamps the shader clock around the phases of every
@@ -276,7 +298,16 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
                          [&](auto i_c) __attribute__((always_inline)) {
                            constexpr int i = decltype(i_c)::value;
                            if (i == 1) P.template fill_piece<BUF, 0>();
-                           if (i == 4) { if (pf_x && !S2DBG(g, 32)) { pload16(xn[2 * pt], pf_src + piece_off(2 * pt)); pload16(xn[2 * pt + 1], pf_src + piece_off(2 * pt + 1)); } }
+                           if (i == 4) {
+                             if (pf_x && !S2DBG(g, 32)) {
+                               if (lines) {
+                                 int ln = lane;
+                                 asm volatile("" : "+v"(ln));      // (offsets formed here, not hoisted)
+                                 xn[2 * pt] = aload16s(pf_base, patch_off(ln, (2 * pt) & 3, g.ldx, (2 * pt) >> 2));
+                                 xn[2 * pt + 1] = aload16s(pf_base, patch_off(ln, (2 * pt + 1) & 3, g.ldx, (2 * pt + 1) >> 2));
+                               } else { pload16(xn[2 * pt], pf_src + piece_off(2 * pt)); pload16(xn[2 * pt + 1], pf_src + piece_off(2 * pt + 1)); }
+                             }
+                           }
                            if (i == 7) {
                              if (pend_valid && !S2DBG(g, 16)) {
                                if (STP) {
@@ -433,8 +464,15 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
     const long t0 = tok_of(blockIdx.x);
     const unsigned short* p0 = xb + t0 * g.ldx + 16 * h;
     if (WPC == 1) {
+      if (STP) {                                      // whole-line pieces from a wave-uniform base (see strip_linear2_kernel)
+        const long r0 = (long)blockIdx.x * 128 + wave * 32;
+        const unsigned short* b0 = xb + (r0 < (long)g.M ? r0 : (long)g.M - 32) * g.ldx;
 #pragma unroll
-      for (int i = 0; i < 16; i++) pload16(xn[WPC == 1 ? i : 0], p0 + piece_off(i));
+        for (int i = 0; i < 16; i++) xn[WPC == 1 ? i : 0] = aload16s(b0, patch_off(lane, i & 3, g.ldx, i >> 2));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) pload16(xn[WPC == 1 ? i : 0], p0 + piece_off(i));
+      }
       P.issued += 16;
     }
     if (MODE == 1) {
@@ -469,7 +507,13 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
     int zero = 0;                                     // (keeps the LDS parameter reads inside the iteration: see strip_linear2_kernel)
     asm volatile("" : "+s"(zero));
     const float* prm_b = prm + zero;
-    if (WPC == 1) {
+    if (WPC == 1 && STP) {                            // line pieces -> the lane's own row pieces, through the output patch
+#pragma unroll
+      for (int pr = 0; pr < 4; pr++) {
+        patch_put_lines(patchY, lane, xn[WPC == 1 ? 4 * pr : 0], xn[WPC == 1 ? 4 * pr + 1 : 0], xn[WPC == 1 ? 4 * pr + 2 : 0], xn[WPC == 1 ? 4 * pr + 3 : 0]);
+        patch_get_rows(patchY, j, hb, xf[4 * pr], xf[4 * pr + 1], xf[4 * pr + 2], xf[4 * pr + 3]);
+      }
+    } else if (WPC == 1) {
 #pragma unroll
       for (int i = 0; i < 16; i++) xf[i] = xn[WPC == 1 ? i : 0];
     } else {                                          // requested here, consumed by the first slot's MFMAs (hipcc places the wait)
@@ -516,7 +560,15 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
           constexpr int q = decltype(q_c)::value;
           P.template fill_piece<BA, q>();
           if (q == 0) {
-            if (WPC == 1 && has_next) { pload16(xn[WPC == 1 ? t : 0], xrow_next + piece_off(t)); P.issued += 1; }      // one piece of the next block's activations per tile
+            if (WPC == 1 && has_next) {               // one piece of the next block's activations per tile
+              if (STP) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const long r0 = nxt * 128 + wave * 32;
+                xn[WPC == 1 ? t : 0] = aload16s(xb + (r0 < (long)g.M ? r0 : (long)g.M - 32) * g.ldx, patch_off(ln, t & 3, g.ldx, t >> 2));
+              } else pload16(xn[WPC == 1 ? t : 0], xrow_next + piece_off(t));
+              P.issued += 1;
+            }
           } else if (q < 3) {
             if (MODE == 1 && (in_blk || has_next)) { pload16(gt[(t + 2) & 3][q - 1], gp + 8 * (q - 1)); P.issued += 1; }
           }
@@ -710,6 +762,7 @@ static int strip2_debug() { const char* e = getenv("HFTT_STRIP2_DEBUG"); return 
 int hftt_strip_linear2_try(const hftt_strip_desc& d0, hipStream_t st) {
   hftt_strip_desc d = d0;
   d.pad = strip2_debug();
+  { const char* e = getenv("HFTT_LINEAR2_LINES"); if (e) d.pad |= (e[0] == '0' ? 0x10000 : 0x20000); }
   const uint32_t bf = HFTT_SL_X_BF16 | HFTT_SL_C_BF16;
   if (!v2_enabled() || (d.flags & bf) != bf || d.K % 256 != 0 || d.M % 32 != 0 || d.gate != nullptr) return -1;
   if (d.residual != nullptr && !(d.flags & HFTT_SL_RES_BF16)) return -1;

@@ -163,6 +163,24 @@ __device__ __forceinline__ unsigned patch_off(int lane, int k, int ld, int pr) {
 __device__ __forceinline__ void astore16s(const void* base, unsigned off, const u4v& v) {
   asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base));
 }
+// Whole-line LOADS, the mirror image: a wave's 32 rows x 128 bytes (a pair of tiles) arrive as four line pieces (piece k: row (lane >> 3) + 8 k,
+// chunk lane & 7 -- each load instruction reads 8 complete lines instead of touching 64 rows), go into the patch as they are and come back as
+// the lane's own two 16-byte halves of each tile (the MFMA B operand layout).
+__device__ __forceinline__ u4v aload16s(const void* base, unsigned off) {
+  return *reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned char*>(base) + off);
+}
+__device__ __forceinline__ void patch_put_lines(unsigned char* patch, int lane, const u4v& l0, const u4v& l1, const u4v& l2, const u4v& l3) {
+  unsigned char* w = patch + (lane >> 3) * PATCH_PITCH + (lane & 7) * 16;
+  *reinterpret_cast<u4v*>(w) = l0;
+  *reinterpret_cast<u4v*>(w + 8 * PATCH_PITCH) = l1;
+  *reinterpret_cast<u4v*>(w + 16 * PATCH_PITCH) = l2;
+  *reinterpret_cast<u4v*>(w + 24 * PATCH_PITCH) = l3;
+}
+// lane (j, h): halves (tile A: a0, a1; tile B: b0, b1) of its token's row
+__device__ __forceinline__ void patch_get_rows(const unsigned char* patch, int j, int h, u4v& a0, u4v& a1, u4v& b0, u4v& b1) {
+  const u4v* r = reinterpret_cast<const u4v*>(patch + j * PATCH_PITCH + h * 32);
+  a0 = r[0]; a1 = r[1]; b0 = r[4]; b1 = r[5];
+}
 // the four pieces of a finished pair at once
 __device__ __forceinline__ void patch_flush(const unsigned char* patch, int lane, const void* wave_base, int ld, int pr) {
 #pragma unroll
