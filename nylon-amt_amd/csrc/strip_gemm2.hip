@@ -441,12 +441,15 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
   unsigned char* patchP = patchY + PATCH_BYTES;
   unsigned char* patchH = patchY + 2 * PATCH_BYTES;
 
-  PipeDyn P;
-  P.w = g.w; P.S = 2 * PT; P.fill_left = S2DBG(g, 1) ? 0 : my_blocks * P.S; P.fill_pos = 0; P.nobar = S2DBG(g, 2); P.closing = false;
+  // Round 5: the constant-wait pipe of the linear kernel (always-fill ring, s_waitcnt vmcnt(8) at every slot boundary) instead of the counted
+  // waits of PipeDyn -- ~25 scalar instructions and a branch tree per slot, a quarter of the 530 cycles per slot the kernel's skeleton costs
+  // with every mechanism switched off (tools/ablate_mlp2.sh, bits 451).  It used to tip this kernel into scratch; the whole-line store path
+  // freed the registers (no 64-bit row pointers per lane).
+  Pipe P;
+  P.w = g.w; P.S = 2 * PT; P.nofill = S2DBG(g, 1); P.fill_pos = 0; P.nobar = S2DBG(g, 2);
   P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
   P.wave = wave; P.lane = lane; P.issued = 0;
-#pragma unroll
-  for (int i = 0; i < NSLOT; i++) P.fill_mark[i] = 0;
+  (void)my_blocks;
 
   auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
 
@@ -539,8 +542,9 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
       const bool stamp = MODE == 0 && S2DBG(g, 4) && (t == 4 || t == 5) && blk == (long)blockIdx.x + gridDim.x && tid == 0;
       unsigned long long* sb = reinterpret_cast<unsigned long long*>(const_cast<unsigned short*>(g.gate)) + (long)blockIdx.x * 16 + (t - 4) * 8;
       if (stamp) sb[0] = __builtin_amdgcn_s_memtime();
-      P.template begin_slot<BA>();
-      if (stamp) sb[1] = __builtin_amdgcn_s_memtime();
+      // The hidden tile's bias is read BEFORE the slot's wait + barrier (round 5).  Behind it, its four ds_read_b128 were the first DS reads of
+      // the slot's scheduling region and took four of the six places of slot_mfmas' read-ahead group: the first GEMM's fragments then ran ONE
+      // read ahead (ISA: `ds_read; s_waitcnt lgkmcnt(1); v_mfma` sixteen times), every MFMA waiting out most of an LDS round trip.
       f32x16 hacc;
       {
         float b[16];
@@ -548,13 +552,17 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
 #pragma unroll
         for (int q = 0; q < 16; q++) hacc[q] = b[q];
       }
+      P.template begin_slot<BA>();
+      asm volatile("" : "+v"(P.lane));                // (the ring's source pointers are formed per slot: with the stream position a constant of every
+                                                      //  unrolled slot hipcc hoisted all 32 of them -- 64 registers -- out of the block loop and spilled)
+      if (stamp) sb[1] = __builtin_amdgcn_s_memtime();
       {
         const unsigned char* slot = abase + BA * SLOT_BYTES;
         const bool in_blk = (t + 2) < PT;             // mode 1: gate of tile t + 2 (of the next block past the end)
         const unsigned short* gp = (MODE == 1) ? g.gate + (in_blk ? tokc : tokn) * g.ldg + ((t + 2) % PT) * 32 + 16 * hb : nullptr;
         if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(1);      // two workgroups per CU: the wave in its matrix phase wins the issue slot
         if (!S2DBG(g, 256))
-        slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int f, bf16x8 a) __attribute__((always_inline)) { hacc = mfma32(a, as_frag(xf[f]), hacc); });    // fragment f = 2 * pt + u
+        slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int f, bf16x8 a) __attribute__((always_inline)) { hacc = mfma32(a, as_frag(xf[f]), hacc); }, S2DBG(g, 1024));    // fragment f = 2 * pt + u
         if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(0);
         static_for<4>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int q = decltype(q_c)::value;
@@ -602,6 +610,7 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
       // ---- second GEMM, K-slice t; the hidden tile's two stores ride behind its first two MFMA groups ----
       if (stamp) sb[3] = __builtin_amdgcn_s_memtime();
       P.template begin_slot<BB>();
+      asm volatile("" : "+v"(P.lane));
       if (stamp) sb[4] = __builtin_amdgcn_s_memtime();
       {
         const unsigned char* slot = abase + BB * SLOT_BYTES;
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
         if (STP && st_h) patch_put(patchH, j, hb, t & 1, hf[0], hf[1]);
         if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(1);
         if (!S2DBG(g, 256))
-        slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { yacc[i & 7] = mfma32(a, as_frag(hf[i >> 3]), yacc[i & 7]); });
+        slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { yacc[i & 7] = mfma32(a, as_frag(hf[i >> 3]), yacc[i & 7]); }, S2DBG(g, 1024));
         if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(0);
         static_for<4>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int q = decltype(q_c)::value;
@@ -690,6 +699,7 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
               });
     }
   }
+  P.drain();
 }
 
 int n_cus() {

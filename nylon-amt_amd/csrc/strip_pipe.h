@@ -106,8 +106,14 @@ __device__ __forceinline__ bf16x8 as_frag(const u4v& u) { return __builtin_bit_c
 // keeps only one or two ds_read_b128 in flight (~120 cycles per MFMA instead of 32).  The group barriers pin the shape: six reads
 // up front, then one read behind every MFMA, so each fragment is requested ~6 MFMAs (~190 cycles) before it is consumed.
 template <int AHEAD = 6, typename F>
-__device__ __forceinline__ void slot_mfmas(const unsigned char* slot, F&& mfma_i) {
+__device__ __forceinline__ void slot_mfmas(const unsigned char* slot, F&& mfma_i, bool noread = false) {
   bf16x8 fr[16];
+  if (noread) {                                       // timing experiment (HFTT_STRIP2_DEBUG bit 1024): one fragment read feeds all sixteen MFMAs
+    const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(slot);
+#pragma unroll
+    for (int i = 0; i < 16; i++) mfma_i(i, f0);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 16; i++) fr[i] = *reinterpret_cast<const bf16x8*>(slot + i * 1024);
 #pragma unroll
