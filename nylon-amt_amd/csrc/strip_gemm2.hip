@@ -42,6 +42,14 @@
 #define S2PRIO(g) false
 #endif
 
+// Compile-time timing switches of the fused block (tools/ablate_mlp2_ct.sh builds one library per mask; results garbage): unlike the run-time
+// switches above they leave no branch in the slot bodies, so the schedule of what remains is the product's.
+//   1 no ring fills   2 no slot barrier   4 no next-block row prefetch   8 no fragment reads (one fragment feeds a slot's 16 MFMAs)
+//   16 no slot wait (s_waitcnt vmcnt)
+#ifndef HFTT_MLP2_CT
+#define HFTT_MLP2_CT 0
+#endif
+
 namespace {
 
 #include "strip_pipe.h"
@@ -135,12 +143,12 @@ struct Pipe {
   // top of slot BUF: its DMA has landed in every wave and the buffer consumed one slot ago is free
   template <int BUF>
   __device__ __forceinline__ void begin_slot() {
-    HFTT_WAITVM(8);
-    if (!nobar) __builtin_amdgcn_s_barrier();
+    if (!(HFTT_MLP2_CT & 16)) HFTT_WAITVM(8);
+    if (!(HFTT_MLP2_CT & 2) && !nobar) __builtin_amdgcn_s_barrier();
   }
   template <int BUF, int I>
   __device__ __forceinline__ void fill_piece() {      // BUF: the slot being consumed; the refill goes to (BUF + 3) % 4 (all four pieces at I == 0)
-    if (I == 0 && !nofill) glds16x4(src_of(fill_pos), ring + (unsigned)((BUF + FILL_AHEAD) & (NSLOT - 1)) * SLOT_BYTES + (unsigned)wave * 4096u);
+    if (I == 0 && !(HFTT_MLP2_CT & 1) && !nofill) glds16x4(src_of(fill_pos), ring + (unsigned)((BUF + FILL_AHEAD) & (NSLOT - 1)) * SLOT_BYTES + (unsigned)wave * 4096u);
   }
   template <int BUF>
   __device__ __forceinline__ void fill_close() { advance(); }
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
           constexpr int q = decltype(q_c)::value;
           P.template fill_piece<BA, q>();
           if (q == 0) {
-            if (WPC == 1 && has_next) {               // one piece of the next block's activations per tile
+            if (WPC == 1 && has_next && !(HFTT_MLP2_CT & 4)) {               // one piece of the next block's activations per tile
               if (STP) {
                 int ln = lane;
                 asm volatile("" : "+v"(ln));

@@ -108,6 +108,9 @@ __device__ __forceinline__ bf16x8 as_frag(const u4v& u) { return __builtin_bit_c
 template <int AHEAD = 6, typename F>
 __device__ __forceinline__ void slot_mfmas(const unsigned char* slot, F&& mfma_i, bool noread = false) {
   bf16x8 fr[16];
+#if defined(HFTT_MLP2_CT) && (HFTT_MLP2_CT & 8)
+  noread = true;
+#endif
   if (noread) {                                       // timing experiment (HFTT_STRIP2_DEBUG bit 1024): one fragment read feeds all sixteen MFMAs
     const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(slot);
 #pragma unroll
