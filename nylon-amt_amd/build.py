@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libhftt_hip.so')
-SOURCES = ['capi.cpp', 'gemm_nt.hip', 'strip_gemm.hip', 'strip_gemm2.hip', 'gemm_tn.hip', 'attn_fwd.hip', 'attn_fwd8.hip', 'attn_bwd.hip', 'x3_attn.hip', 'x3_attn_pl.hip', 'x3_strip.hip', 'elementwise.hip', 'logmel.hip']
+SOURCES = ['capi.cpp', 'gemm_nt.hip', 'strip_gemm.hip', 'strip_gemm2.hip', 'bs_strip.hip', 'gemm_tn.hip', 'attn_fwd.hip', 'attn_fwd8.hip', 'attn_bwd.hip', 'x3_attn.hip', 'x3_attn_pl.hip', 'x3_strip.hip', 'elementwise.hip', 'logmel.hip']
 HEADERS = [os.path.join(CSRC, 'hftt_common.h'), os.path.join(CSRC, 'hftt_host.h'), os.path.join(CSRC, 'strip_internal.h'), os.path.join(CSRC, 'strip_pipe.h'), os.path.join(CSRC, 'x3_common.h'), os.path.join(CSRC, 'x3_internal.h'), os.path.join(CSRC, 'x3_attn_bwd.h'), os.path.join(CSRC, 'x3s_strip.h'),
            os.path.join(HERE, '..', 'include', 'hftt_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']

@@ -639,6 +639,10 @@ extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
                  "strip_linear: LayerNorm needs N == ldc == 256 (or 64: the small-width family), beta, no ReLU");
     return hftt_x3_strip_linear(*d, reinterpret_cast<hipStream_t>(stream));
   }
+  {                                                   // the bf16 small-width family (bs_strip.hip): K, N <= 192, all-bf16 storage
+    const int rc = hftt_bs_strip_linear_try(*d, reinterpret_cast<hipStream_t>(stream));
+    if (rc >= 0) return rc;
+  }
   HFTT_REQUIRE(d->M > 0 && d->N >= 256 && d->N % 256 == 0 && d->N <= 2048, "strip_linear: N=%d must be a multiple of 256", d->N);
   HFTT_REQUIRE(d->K >= 128 && d->K % 128 == 0 && (d->K <= 256 || d->K % 256 == 0), "strip_linear: K=%d must be 128, 256 or a multiple of 256", d->K);
   HFTT_REQUIRE((long)d->M * d->N < (1L << 33), "strip_linear: M*N too large for the 32-bit dropout pair index");
@@ -699,6 +703,7 @@ extern "C" int hftt_ffn_res_ln_fwd(const hftt_ffn_desc* d, void* stream) {
     HFTT_REQUIRE(d->ln_gamma != nullptr && d->ln_beta != nullptr && d->ldy == d->d, "ffn_res_ln_fwd: needs gamma, beta and ldy == d");
     return hftt_x3_strip_mlp(*d, reinterpret_cast<hipStream_t>(stream));
   }
+  if (d != nullptr && d->mode == 0) { const int rc = hftt_bs_strip_mlp_try(*d, reinterpret_cast<hipStream_t>(stream)); if (rc >= 0) return rc; }
   if (int rc = check_ffn(d, 0, "ffn_res_ln_fwd")) return rc;
   HFTT_REQUIRE(d->ln_gamma != nullptr && d->ln_beta != nullptr && d->ldy == 256, "ffn_res_ln_fwd: needs gamma, beta and ldy == 256");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -713,6 +718,7 @@ extern "C" int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream) {
     HFTT_REQUIRE(d->gate != nullptr && d->h_out != nullptr, "ffn_bwd_dx: needs the stored hidden (gate) and the dh output");
     return hftt_x3_strip_mlp(*d, reinterpret_cast<hipStream_t>(stream));
   }
+  if (d != nullptr && d->mode == 1) { const int rc = hftt_bs_strip_mlp_try(*d, reinterpret_cast<hipStream_t>(stream)); if (rc >= 0) return rc; }
   if (int rc = check_ffn(d, 1, "ffn_bwd_dx")) return rc;
   HFTT_REQUIRE(d->gate != nullptr && d->ldg % 8 == 0 && ((uintptr_t)d->gate & 15) == 0, "ffn_bwd_dx: needs the stored hidden (bf16, 16-byte aligned rows)");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -120,7 +120,9 @@ class HfttEngine:
         self.strip = getattr(self, 'strip_opt', True) and self.d == 256 and ((self.sb and self.p % 64 == 0) or (self.npass == 2 and self.p == 512))
         # the reference's default width (training/m_training.py:56-61: d = 64, ff = 128) in the x3 mode: the same launch sequence on the
         # small-width strip family (csrc/x3s_strip.h: every weight matrix of a launch resident in LDS, compact packs)
-        self.strip_small = getattr(self, 'strip_opt', True) and self.npass == 2 and self.d == 64 and self.p == 128
+        # ... and, since round 5, in the bf16 mode (csrc/bs_strip.hip: the same launch sequence on the bf16 stream -- BASELINE config 2; the packs
+        # are the x3 family's compact ones with bf16 halves, of which the bf16 kernels read the hi fragments)
+        self.strip_small = getattr(self, 'strip_opt', True) and (self.npass == 2 or self.sb) and self.d == 64 and self.p == 128
         self.strip = self.strip or self.strip_small
         # bfs: the bf16 activation / gradient STREAM of the bf16 strip plans.  The x3 strip plans run the same launch sequence on fp32 tensors.
         self.bfs = self.strip and self.sb
@@ -463,6 +465,10 @@ class HfttEngine:
             if self.x3:
                 check(self.lib.hftt_x3_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, 2, stream), 'x3_strip_pack')
                 check(self.lib.hftt_x3_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table_t.data_ptr(), self.n_spack_t, 4, stream), 'x3_strip_pack')
+            elif self.strip_small:                   # bf16 mode, small widths: compact packs with bf16 halves for both directions
+                check(self.lib.hftt_x3_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, 4, stream), 'x3_strip_pack')
+                if self.n_spack_t:
+                    check(self.lib.hftt_x3_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table_t.data_ptr(), self.n_spack_t, 4, stream), 'x3_strip_pack')
             else:
                 check(self.lib.hftt_strip_pack(self.flat_params.data_ptr(), self.wstrip.data_ptr(), self.spack_table.data_ptr(), self.n_spack, stream), 'strip_pack')
         self._prepared_frozen = self.frozen_weights
@@ -587,6 +593,8 @@ class HfttEngine:
             else 'strip_linear_kernel<%s, %s, %s>' % (tf(x_bf), tf(c_bf), tf(ln is not None))
         if self.x3 and self.strip_small:
             kname = 'x3s_linear_kernel<%d, %d, %d, %s, %s>' % (4 if self._in_backward else 2, K // 32, N // 32, tf(ln is not None), tf(bool(residual)))
+        elif self.strip_small:
+            kname = 'bs_linear_kernel<%d, %d, %s, %s>' % (K // 32, N // 32, tf(ln is not None), tf(bool(residual)))
         elif self.x3:
             xe = (5 if self.g8 else 4) if self._in_backward else 2
             kname = 'x3_linear_kernel<%d, %s, %d, %d, %s>' % (xe, tf(ln is not None), passes, kch, tf(bool(residual)))
@@ -626,7 +634,7 @@ class HfttEngine:
         v2 = os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and p == 512 and M % 32 == 0 and not (mode == 0 and residual)
         xname = ('x3s_mlp_kernel<%%d, %s>' % ('true' if self.hh else 'false')) if self.strip_small else \
             ('x3_mlp_kernel<%%d, 16, %s, %s>' % ('true' if self.hh else 'false', 'true' if (mode == 1 and self.g8) else 'false'))
-        meta = {'kernel': (xname if self.x3 else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>')) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
+        meta = {'kernel': (xname if self.x3 else ('bs_mlp_kernel<%d>' if self.strip_small else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>'))) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
                 'shape': (M, d, p), 'saves': bool(h_out or pre_saved)}
         plan.append((self.lib.hftt_ffn_res_ln_fwd if mode == 0 else self.lib.hftt_ffn_bwd_dx, (C.byref(dsc),), 'ffn_fwd' if mode == 0 else 'ffn_bwd_dx', meta))
         return dsc

@@ -175,12 +175,13 @@ def x3s_pack(w: torch.Tensor, elem=2, transpose=False, nt=None, out=None, pair_o
     return out
 
 
-def x3s_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False):
-    """the fused block's two matrices at d = 64, p = 128: pairs 0 .. 15 the first GEMM's, 16 .. 31 the second's"""
+def x3s_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False, bf16=False):
+    """the fused block's two matrices at d = 64, p = 128: pairs 0 .. 15 the first GEMM's, 16 .. 31 the second's
+    (bf16: bf16 halves for the forward matrices too -- the pack of the bf16 small-width family, csrc/bs_strip.hip, which reads the hi fragments)"""
     out = torch.zeros(32 * 1024, dtype=torch.int16, device=w1.device)
     if not backward:
-        x3s_pack(w1, 2, False, 4, out, 0)        # fc_1.weight [p, d]
-        x3s_pack(w2, 2, False, 2, out, 16)       # fc_2.weight [d, p]
+        x3s_pack(w1, 4 if bf16 else 2, False, 4, out, 0)        # fc_1.weight [p, d]
+        x3s_pack(w2, 4 if bf16 else 2, False, 2, out, 16)       # fc_2.weight [d, p]
     else:
         x3s_pack(w2, 4, True, 4, out, 0)         # fc_2.weight^T [p, d]
         x3s_pack(w1, 4, True, 2, out, 16)        # fc_1.weight^T [d, p]

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import util
 from util import keep_scale, rel_err, max_err, keep_mask_t
@@ -326,3 +327,84 @@ def test_two_strip_linear_is_bit_identical(dev, monkeypatch, M):
             torch.cuda.synchronize()
             assert torch.equal(a, c), (N, K, sorted(kw))
     monkeypatch.setenv('HFTT_STRIP_V5', '0')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16 small-width family (csrc/bs_strip.hip, round 5): the reference's default model (d = 64, ff = 128) on the bf16 stream -- BASELINE config 2
+# ---------------------------------------------------------------------------------------------------------------------
+def _b(t):
+    return t.to(BF).double()
+
+
+@pytest.mark.parametrize('M,N,K', [(1120, 192, 64), (4096 + 96, 128, 64), (256, 64, 64), (1120, 64, 128), (90112, 64, 192), (262144, 192, 64)])
+def test_bf16_small_strip_linear(dev, M, N, K):
+    """K x N in {64x192, 64x128, 64x64, 128x64, 192x64}: plain, ReLU + scale + residual, dropout + broadcast residual (res_mod), transposed pack;
+    operands rounded to bf16 in the reference, fp32 accumulation: the error left is the bf16 rounding of the result (2^-9)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(BF); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(BF)
+    wp = ops.x3s_pack(W.to(dev), 4)
+    ref = _b(x) @ _b(W).T + b.double()
+    out = ops.strip_linear(x.to(dev), wp, N, b.to(dev))
+    assert out.dtype == BF and rel_err(out.float(), ref) < 6e-3
+    if N == 64:
+        out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), relu=True, out_scale=0.5, residual=res.to(dev))
+        assert rel_err(out.float(), torch.relu(ref) * 0.5 + _b(res)) < 6e-3
+        p, site, seed = 0.1, 3, 4242
+        mask = keep_mask_t(seed, site, (M, N), p).double()
+        out = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res[:7].contiguous().to(dev), res_mod=7)
+        assert rel_err(out.float(), ref * mask * keep_scale(p) + _b(res)[torch.arange(M) % 7]) < 6e-3
+    if K == 64:
+        dy = (torch.randn(M, N, generator=g) * 1e-5).to(BF)
+        wt = ops.x3s_pack(W.to(dev), 4, transpose=True)            # logical [K, N]: maps [M, N] -> [M, K]
+        out = ops.strip_linear(dy.to(dev), wt, K, None)
+        assert rel_err(out.float(), _b(dy) @ _b(W)) < 6e-3
+
+
+def test_bf16_small_strip_linear_layernorm(dev):
+    ops = _ops()
+    M, N, K = 1120, 64, 64
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(M, K, generator=g).to(BF); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    res = (torch.randn(M, N, generator=g) * 3.0).to(BF); gam = torch.randn(N, generator=g); bet = torch.randn(N, generator=g)
+    p, site, seed = 0.1, 11, 99
+    mask = keep_mask_t(seed, site, (M, N), p).double()
+    wp = ops.x3s_pack(W.to(dev), 4)
+    out, pre, mean, rstd = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res.to(dev), ln=(gam.to(dev), bet.to(dev)))
+    r = (_b(x) @ _b(W).T + b.double()) * mask * keep_scale(p) + _b(res)
+    assert pre.dtype == BF and rel_err(pre.float(), r) < 6e-3
+    assert rel_err(out.float(), F.layer_norm(r, (N,), gam.double(), bet.double(), 1e-5)) < 8e-3
+    assert rel_err(mean, r.mean(1)) < 1e-4
+    assert rel_err(rstd, 1.0 / torch.sqrt(r.var(1, unbiased=False) + 1e-5)) < 1e-4
+    out2 = ops.strip_linear(x.to(dev), wp, N, b.to(dev), drop_p=p, drop_site=site, drop_seed=seed, residual=res.to(dev), ln=(gam.to(dev), bet.to(dev)), save_pre=False)[0]
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize('M', [256, 4096 + 96, 90112])
+def test_bf16_small_fused_ffn_forward_and_dx(dev, M):
+    ops = _ops()
+    d, pf = 64, 128
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, d, generator=g).to(BF); W1 = torch.randn(pf, d, generator=g) / 8.0; W2 = torch.randn(d, pf, generator=g) / 11.0
+    b1 = torch.randn(pf, generator=g) * 0.3; b2 = torch.randn(d, generator=g) * 0.3; gam = torch.randn(d, generator=g); bet = torch.randn(d, generator=g)
+    p, sh, so, seed = 0.1, 21, 22, 777
+    wf = ops.x3s_ffn_pack(W1.to(dev), W2.to(dev), bf16=True)
+    y, hid, pre, mean, rstd = ops.ffn_res_ln_fwd(x.to(dev), wf, pf, b1.to(dev), b2.to(dev), gam.to(dev), bet.to(dev), drop_p=p, site_h=sh, site_o=so, seed=seed)
+    h = torch.relu(_b(x) @ _b(W1).T + b1.double()) * keep_mask_t(seed, sh, (M, pf), p).double() * keep_scale(p)
+    assert hid.dtype == BF and rel_err(hid.float(), h) < 6e-3
+    hq = hid.cpu().double()                                   # the second GEMM takes the hidden as it was rounded
+    o = (hq @ _b(W2).T + b2.double()) * keep_mask_t(seed, so, (M, d), p).double() * keep_scale(p)
+    r = _b(x) + o
+    assert rel_err(pre.float(), r) < 6e-3
+    assert rel_err(y.float(), F.layer_norm(r, (d,), gam.double(), bet.double(), 1e-5)) < 8e-3
+    assert rel_err(mean, r.mean(1)) < 1e-4
+    y2 = ops.ffn_res_ln_fwd(x.to(dev), wf, pf, b1.to(dev), b2.to(dev), gam.to(dev), bet.to(dev), drop_p=p, site_h=sh, site_o=so, seed=seed,
+                            save_hidden=False, save_pre=False)[0]
+    assert torch.equal(y2, y)
+    dy = (torch.randn(M, d, generator=g) * 1e-5).to(BF); res = (torch.randn(M, d, generator=g) * 1e-5).to(BF)
+    wb = ops.x3s_ffn_pack(W1.to(dev), W2.to(dev), backward=True)
+    dx, dh = ops.ffn_bwd_dx(dy.to(dev), wb, pf, hid, gate_scale=1.25, residual=res.to(dev))
+    dh_ref = torch.where(hq > 0, (_b(dy) @ _b(W2)) * 1.25, torch.zeros((), dtype=torch.float64))
+    assert dh.dtype == BF and rel_err(dh.float(), dh_ref) < 6e-3
+    assert rel_err(dx.float(), dh.cpu().double() @ _b(W1) + _b(res)) < 6e-3
