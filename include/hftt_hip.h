@@ -183,7 +183,11 @@ int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_p
  * the fused block at d == 64, p == 128 -- the reference's default model (training/m_training.py:56-61).  `w` is then an
  * hftt_x3_strip_pack stream of order 2 ("compact": the (hi, lo) pair of (k chunk c, output tile t) at pair index slot_offset + c * NT + t with
  * NT = slot_stride = N / 32, 2 KB per pair; fused block: first matrix at pairs 0 .. 15, second at 16 .. 31): the whole matrix sits in LDS for the
- * launch (csrc/x3s_strip.h). */
+ * launch (csrc/x3s_strip.h).
+ * The same shapes WITHOUT a split flag and with all-bf16 storage (HFTT_SL_X_BF16 | HFTT_SL_C_BF16, a bf16 residual, M % 32 == 0) run the bf16
+ * small-width family (csrc/bs_strip.hip, round 5: BASELINE config 2 -- the reference's default model in the bf16 mode): same compact pack, made
+ * with bf16 halves (hftt_x3_strip_pack element type 4), of which these kernels read the hi fragment; one MFMA pass; every tensor bf16, statistics
+ * fp32; results leave as whole 128-byte lines. */
 /* HFTT_SL_X3_F16 without LayerNorm, K == 256 (the output-tile-major kernel): C is written as f16-pair planes per 32-column group (see
  * HFTT_ATTN_Q_F16PAIR) -- the q / k / v projections of the attention layers (model_spec2midi.py:328-330) */
 #define HFTT_SL_C_F16PAIR 512u
