@@ -402,16 +402,18 @@ def test_dropout_on_outputs_and_gradients_with_the_device_masks_exported_to_the_
         assert cos > cos1 - 0.03 and cos > cos_wrong + 0.05 and cos_builds > 0.93, (cos, cos1, cos_wrong, cos_builds)
 
 
-def test_strip_kernels_match_the_round1_kernels_with_dropout_on(dev, monkeypatch):
-    """bf16 mode at the paper's width runs the strip kernels (bf16 activation + gradient streams, fused FFN); HFTT_STRIP=0 runs the
+@pytest.mark.parametrize('width', [256, 64])
+def test_strip_kernels_match_the_round1_kernels_with_dropout_on(dev, monkeypatch, width):
+    """(width 64, round 5: the same yardstick for the small-width bf16 family, csrc/bs_strip.hip -- the reference's default model, BASELINE config 2.)
+    bf16 mode at the paper's width runs the strip kernels (bf16 activation + gradient streams, fused FFN); HFTT_STRIP=0 runs the
     round-1 kernels (fp32 streams).  Every dropout site must regenerate the same masks in both builds, forward and backward, as the
     exact-fp32 parity mode does (same plan, same sites, same seed).  Yardstick: each bf16 build's deviation from the parity mode.  Two
     bf16 roundings of this model differ visibly by themselves (first-layer attention logits ~1e4), so the strip
     build must simply not be further from the parity mode than the round-1 build is -- with dropout off AND on (a site / index
     mismatch anywhere would be an O(1) change of the masked activations and of every gradient behind them)."""
     from hftt_hip.trainer import TrainStep
-    cfg = O.HfttConfig(n_margin=4, n_frame=16, n_bin=48, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512,
-                       enc_layer=2, dec_layer=2, enc_head=4, dec_head=4, n_note=12, n_velocity=16)
+    cfg = O.HfttConfig(n_margin=4, n_frame=16, n_bin=48, cnn_channel=4, cnn_kernel=5, hid_dim=width, pf_dim=2 * width,
+                       enc_layer=2, dec_layer=2, enc_head=width // 64 if width > 64 else 2, dec_head=width // 64 if width > 64 else 2, n_note=12, n_velocity=16)
     B = 2
     x = (O.synth_spec(B, cfg, salt=21) * 0.5).to(dev)
     ld = _to_dev(O.synth_labels(B, cfg, salt=22), dev)
@@ -429,6 +431,9 @@ def test_strip_kernels_match_the_round1_kernels_with_dropout_on(dev, monkeypatch
             torch.cuda.synchronize()
             eng = ts.engine
             assert eng.strip == (build == 'strip') and torch.isfinite(eng.flat_grads).all()
+            if build == 'strip' and width == 64:
+                assert eng.strip_small and any('bs_mlp_kernel' in (m or {}).get('kernel', '') for _, _, _, m in eng._ws[B]['fwd'])
+                assert any('bs_linear_kernel' in (m or {}).get('kernel', '') for _, _, _, m in eng._ws[B]['bwd'])
             grads = torch.cat([eng.flat_grads[o:o + n] for (name, _, o, n) in eng._bound
                                if not name.endswith('fc_k.bias') and not any(t in name for t in skip)]).double()
             res[build] = ([t.clone() for t in eng._ws[B]['outs']], loss[0].item(), grads)
