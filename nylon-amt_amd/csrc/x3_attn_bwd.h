@@ -9,6 +9,16 @@
 #endif
 #endif
 constexpr float XB_LOG2E = 1.4426950408889634f;
+#ifndef HFTT_XB_IL
+#define HFTT_XB_IL 1           // 0: the 256-key form without the interleaved dQ product (A/B builds: tools/stamp_x3_attn.sh)
+#endif
+// -DHFTT_X3_ATTN_STAMPS (tools/stamp_x3_attn.sh): lane 0 of every wave of workgroups 1024 .. 1087 stamps the shader clock around the phases of
+// query block 3 into g.probs (unused by the backward) as [workgroup][wave][16] int64
+#ifdef HFTT_X3_ATTN_STAMPS
+#define XSTAMP(k) do { if (stamp_on) stamp_p[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XSTAMP(k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward
@@ -65,8 +75,13 @@ struct XbCfg {
   static constexpr int K_PL = LKP * RSK;
   static constexpr int Q_PL = 32 * RSQ;
   static constexpr int S_PL = 32 * RSS;
-  // Q fp16 (hi, lo) | Q bf16 (hi, lo) | dO bf16 (hi, lo) | dS bf16 (hi, lo) | row statistics | K image (bf16 hi, lo)
-  static constexpr int ELEMS = 2 * K_PL + 6 * Q_PL + 2 * S_PL;
+  // IL (256 keys: one workgroup per CU whatever the size): the dQ product of query block qb - 1 is issued inside the softmax-backward vector
+  // phase of block qb (matrix pipe and LDS under vector work; it was a phase of its own behind barrier (h): 150 of 1007 us standalone), which
+  // needs the dS block double-buffered.  The smaller forms keep one buffer: 76 KB = two workgroups per CU at 128 keys.
+  static constexpr bool IL = KT == 8 && HFTT_XB_IL != 0;
+  static constexpr int NSB = IL ? 2 : 1;
+  // Q fp16 (hi, lo) | Q bf16 (hi, lo) | dO bf16 (hi, lo) | row statistics | dS bf16 (hi, lo) x NSB | K image (bf16 hi, lo)
+  static constexpr int ELEMS = 2 * K_PL + 6 * Q_PL + NSB * 2 * S_PL;
   static constexpr int LDS_LOOP = ELEMS * 2 + 96 * 4;
   static constexpr int RSE = DH + 4;                  // epilogue patch rows (floats)
   static constexpr int LDS_EPI = KT * 2 * 32 * RSE * 4;
@@ -92,13 +107,19 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   unsigned short* Qf = reinterpret_cast<unsigned short*>(smem);       // fp16 hi | lo   (scores)
   unsigned short* Qb = Qf + 2 * Q_PL;                                   // bf16 hi | lo   (dK)
   unsigned short* Ob = Qb + 2 * Q_PL;                                   // dO, bf16 hi | lo
-  unsigned short* Sb = Ob + 2 * Q_PL;                                   // dS, bf16 hi | lo
-  float* lse_s = reinterpret_cast<float*>(Sb + 2 * S_PL);
-  unsigned short* Kb = reinterpret_cast<unsigned short*>(lse_s + 96);  // bf16 hi | lo (dQ)
+  float* lse_s = reinterpret_cast<float*>(Ob + 2 * Q_PL);              // row statistics (in front of the dS images: immediate offsets)
+  unsigned short* Sb0 = reinterpret_cast<unsigned short*>(lse_s + 96);  // dS, bf16 hi | lo  (x 2 buffers when IL)
+  unsigned short* Kb = Sb0 + Cfg::NSB * 2 * S_PL;                       // bf16 hi | lo (dQ)
   float* delta_s = lse_s + 32;
   float* inv_s = lse_s + 64;
+  constexpr bool IL = Cfg::IL;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef HFTT_X3_ATTN_STAMPS
+  long long* stamp_p = reinterpret_cast<long long*>(g.probs) + ((long)((int)blockIdx.x - 1024) * KT + wave) * 16;
+  const bool stamp_wg = g.probs != nullptr && blockIdx.x >= 1024 && blockIdx.x < 1088 && lane == 0;
+  if (stamp_wg) stamp_p[10] = (long long)__builtin_amdgcn_s_memtime();
+#endif
 #ifdef HFTT_PRIO_SKEW
   // waves w and w + 4 share a SIMD and run the same phases between the same barriers: a static priority makes the first finish its matrix
   // phase while the second waits, after which one is in vector work while the other multiplies
@@ -116,77 +137,6 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
 
   const long kofs = (long)seq * g.k_seq_stride + head * DH;
   const long vofs = (long)seq * g.v_seq_stride + head * DH;
-  // ---- stage all of K (row-major, bf16 pair) for the dQ product ----
-  {
-    constexpr int KCNT = (LKP * F4R + NTHR - 1) / NTHR;
-    float4 kst[KCNT];
-#pragma unroll
-    for (int u = 0; u < KCNT; u++) {
-      const int i = tid + NTHR * u;
-      const int ic = i < LKP * F4R ? i : LKP * F4R - 1;
-      const int key = ic / F4R, c4 = ic % F4R;
-      const int kc = key < Lk ? key : Lk - 1;       // clamped address + select: loads stay unconditional
-      if (PL) {
-        uint2 ph_, pl_;
-        pl_load4(g.k + kofs + (long)kc * g.ldk, c4, ph_, pl_);
-        kst[u] = pl_vals4(ph_, pl_);
-      } else {
-        kst[u] = *reinterpret_cast<const float4*>(g.k + kofs + (long)kc * g.ldk + c4 * 4);
-      }
-      if (key >= Lk) kst[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < KCNT; u++) {
-      const int i = tid + NTHR * u;
-      if (i < LKP * F4R) {
-        const int key = i / F4R, c4 = i % F4R;
-        uint2 hi, lo;
-        x3_split4<EB>(kst[u], hi, lo);
-        *reinterpret_cast<uint2*>(Kb + Cfg::koff(key, c4 * 4)) = hi;
-        *reinterpret_cast<uint2*>(Kb + K_PL + Cfg::koff(key, c4 * 4)) = lo;
-      }
-    }
-  }
-  // ---- this wave's K rows (fp16 pair: the scores) and V rows (bf16 pair: dP) as B-operand fragments (B[k = dh][col = key]) ----
-  const int mykey = wave * 32 + lr0;
-  const int mykey_c = mykey < Lk ? mykey : Lk - 1;
-  bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];
-#pragma unroll
-  for (int s = 0; s < KS; s++) {
-    if (PL) {
-      bf16x8 th, tl;
-      pl_load8(g.k + kofs + (long)mykey_c * g.ldk, 16 * s + 8 * lh0, kfh[s], kfl[s]);
-      pl_load8(g.v + vofs + (long)mykey_c * g.ldv, 16 * s + 8 * lh0, th, tl);
-      float vv[8];
-      pl_vals8(th, tl, vv);
-      if (mykey >= Lk) {
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        kfh[s] = z; kfl[s] = z;
-#pragma unroll
-        for (int e = 0; e < 8; e++) vv[e] = 0.f;
-      }
-      x3_split8<EB>(vv, vfh[s], vfl[s]);
-      continue;
-    }
-    const float* kp = g.k + kofs + (long)mykey_c * g.ldk + 16 * s + 8 * lh0;
-    const float* vp = g.v + vofs + (long)mykey_c * g.ldv + 16 * s + 8 * lh0;
-    const float4 a0 = *reinterpret_cast<const float4*>(kp), a1 = *reinterpret_cast<const float4*>(kp + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(vp), b1 = *reinterpret_cast<const float4*>(vp + 4);
-    float kv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    float vv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    if (mykey >= Lk) {
-#pragma unroll
-      for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
-    }
-    x3_split8<EF>(kv, kfh[s], kfl[s]);
-    x3_split8<EB>(vv, vfh[s], vfl[s]);
-  }
-  f32x16 dKT[NT], dVT[NT];
-#pragma unroll
-  for (int n = 0; n < NT; n++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) { dKT[n][r] = 0.f; dVT[n][r] = 0.f; }
-
   const long qofs = (long)seq * g.q_seq_stride + head * DH;
   const long oofs = (long)seq * g.o_seq_stride + head * DH;
   const long dqofs = (long)seq * g.dq_seq_stride + head * DH;
@@ -227,9 +177,134 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       pl[u] = *reinterpret_cast<const float2*>(lbase + qc * 8u);
     }
   };
-  qload(0);
 
+  // ---- the item's first loads are ALL requested before anything is converted: the K rows of the image, this wave's K / V rows, the first
+  // query block (one memory round trip instead of three in a row: the prologue was 14 % of a (sequence, head) item, nothing overlaps it
+  // at one workgroup per CU) ----
+  constexpr int KCNT = (LKP * F4R + NTHR - 1) / NTHR;
+  float4 kst[KCNT];                                   // PL: the (hi, lo) words as loaded
+#pragma unroll
+  for (int u = 0; u < KCNT; u++) {
+    const int i = tid + NTHR * u;
+    const int ic = i < LKP * F4R ? i : LKP * F4R - 1;
+    const int key = ic / F4R, c4 = ic % F4R;
+    const int kc = key < Lk ? key : Lk - 1;           // clamped address + select: loads stay unconditional
+    if (PL) {
+      uint2 ph_, pl_;
+      pl_load4(g.k + kofs + (long)kc * g.ldk, c4, ph_, pl_);
+      kst[u] = make_float4(__uint_as_float(ph_.x), __uint_as_float(ph_.y), __uint_as_float(pl_.x), __uint_as_float(pl_.y));
+    } else {
+      kst[u] = *reinterpret_cast<const float4*>(g.k + kofs + (long)kc * g.ldk + c4 * 4);
+    }
+  }
+  // this wave's K rows (fp16 pair: the scores) and V rows (bf16 pair: dP) as B-operand fragments (B[k = dh][col = key])
+  const int mykey = wave * 32 + lr0;
+  const int mykey_c = mykey < Lk ? mykey : Lk - 1;
+  bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];         // PL: V's fp16 (hi, lo) as loaded until converted below
+  float4 kraw[PL ? 1 : KS][2], vraw[PL ? 1 : KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    if (PL) {
+      pl_load8(g.k + kofs + (long)mykey_c * g.ldk, 16 * s + 8 * lh0, kfh[s], kfl[s]);
+      pl_load8(g.v + vofs + (long)mykey_c * g.ldv, 16 * s + 8 * lh0, vfh[s], vfl[s]);
+    } else {
+      const float* kp = g.k + kofs + (long)mykey_c * g.ldk + 16 * s + 8 * lh0;
+      const float* vp = g.v + vofs + (long)mykey_c * g.ldv + 16 * s + 8 * lh0;
+      kraw[PL ? 0 : s][0] = *reinterpret_cast<const float4*>(kp); kraw[PL ? 0 : s][1] = *reinterpret_cast<const float4*>(kp + 4);
+      vraw[PL ? 0 : s][0] = *reinterpret_cast<const float4*>(vp); vraw[PL ? 0 : s][1] = *reinterpret_cast<const float4*>(vp + 4);
+    }
+  }
+  qload(0);
+  __builtin_amdgcn_sched_barrier(0);                  // (nothing below is moved in front of a load)
+  // ---- the K image (row-major, bf16 pair) for the dQ product ----
+#pragma unroll
+  for (int u = 0; u < KCNT; u++) {
+    const int i = tid + NTHR * u;
+    if (i < LKP * F4R) {
+      const int key = i / F4R, c4 = i % F4R;
+      float4 kv4 = kst[u];
+      if (PL) kv4 = pl_vals4(make_uint2(__float_as_uint(kst[u].x), __float_as_uint(kst[u].y)), make_uint2(__float_as_uint(kst[u].z), __float_as_uint(kst[u].w)));
+      if (key >= Lk) kv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint2 hi, lo;
+      x3_split4<EB>(kv4, hi, lo);
+      *reinterpret_cast<uint2*>(Kb + Cfg::koff(key, c4 * 4)) = hi;
+      *reinterpret_cast<uint2*>(Kb + K_PL + Cfg::koff(key, c4 * 4)) = lo;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    if (PL) {
+      float vv[8];
+      pl_vals8(vfh[s], vfl[s], vv);
+      if (mykey >= Lk) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        kfh[s] = z; kfl[s] = z;
+#pragma unroll
+        for (int e = 0; e < 8; e++) vv[e] = 0.f;
+      }
+      x3_split8<EB>(vv, vfh[s], vfl[s]);
+      continue;
+    }
+    const float4 a0 = kraw[PL ? 0 : s][0], a1 = kraw[PL ? 0 : s][1], b0 = vraw[PL ? 0 : s][0], b1 = vraw[PL ? 0 : s][1];
+    float kv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    float vv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    if (mykey >= Lk) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
+    }
+    x3_split8<EF>(kv, kfh[s], kfl[s]);
+    x3_split8<EB>(vv, vfh[s], vfl[s]);
+  }
+  f32x16 dKT[NT], dVT[NT];
+#pragma unroll
+  for (int n = 0; n < NT; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dKT[n][r] = 0.f; dVT[n][r] = 0.f; }
+
+  // ---- dQ block = dS . K with 16x16 tiles spread over the waves: tile t = wave + KT * (i / KT), key tile ks = i % KT of step i ----
+  constexpr int CT = DH / 16, NTILE = 2 * CT, TPW = (NTILE + KT - 1) / KT, TS = TPW * KT;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  f32x4 dq_acc = {0.f, 0.f, 0.f, 0.f};
+  // (gi, qq, pp: the caller's opaque copies of the lane indices, see the loop)
+  auto dq_step = [&](int i, const unsigned short* Sbuf, int gi, int qq, int pp) {
+    const int t = wave_s + KT * (i / KT), ks = i % KT;
+    if (TPW * KT == NTILE || t < NTILE) {                   // (wave-uniform)
+      const int qh2 = t / CT, ct = t % CT;
+      if (ks == 0) { dq_acc[0] = 0.f; dq_acc[1] = 0.f; dq_acc[2] = 0.f; dq_acc[3] = 0.f; }
+      const unsigned short* ps = Sbuf + (qh2 * 16 + (lane & 15)) * RSS + 8 * gi + ks * 32;
+      const unsigned short* pk = Kb + Cfg::koff(8 * gi + qq, ct * 16 + 4 * pp) + ks * 32 * RSK;   // (the swizzle does not depend on ks, nor on the + 4 rows below)
+      const bf16x8 ah = lds_read_b128(ps), al = lds_read_b128(ps + S_PL);
+      const bf16x8 bh = join4(lds_read_tr16(pk), lds_read_tr16(pk + 4 * RSK));
+      const bf16x8 bl = join4(lds_read_tr16(pk + K_PL), lds_read_tr16(pk + K_PL + 4 * RSK));
+      dq_acc = x3_mma16<EB>(ah, al, bh, bl, dq_acc);
+    }
+  };
+  // the finished tile of step i (its last key tile) -> dQ rows of query block qbp (nothing is stored for qbp < 0)
+  auto dq_store = [&](int i, int qbp, int gi) {
+    const int t = wave_s + KT * (i / KT);
+    if ((TPW * KT == NTILE || t < NTILE) && qbp >= 0 && !XABL(g, 32)) {
+      const int qh2 = t / CT, ct = t % CT;
+      const int q0 = qbp * 32 + qh2 * 16 + gi * 4;
+      unsigned char* dq0 = reinterpret_cast<unsigned char*>(g.dq + dqofs);
+      const unsigned lddq_b = (unsigned)g.lddq * 4u;
+      const unsigned dqo = __umul24((unsigned)q0, lddq_b) + (unsigned)(ct * 16 + (lane & 15)) * 4u;
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (q0 + r < Lq) *reinterpret_cast<float*>(dq0 + (dqo + (unsigned)r * lddq_b)) = dq_acc[r];
+    }
+  };
+
+#ifdef HFTT_X3_ATTN_STAMPS
+  if (stamp_wg) stamp_p[11] = (long long)__builtin_amdgcn_s_memtime();
+#endif
   for (int qb = 0; qb < nqb; qb++) {
+#ifdef HFTT_X3_ATTN_STAMPS
+    const bool stamp_on = stamp_wg && qb == 3;
+    if (stamp_wg && qb == 4) stamp_p[9] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    XSTAMP(0);
+    unsigned short* Sb = Sb0 + (IL ? (qb & 1) * (2 * S_PL) : 0);                  // this block's dS image
+    const unsigned short* Sprev = Sb0 + (IL ? ((qb & 1) ^ 1) * (2 * S_PL) : 0);   // the previous block's (IL)
     // lane-derived indices as values the optimiser cannot see through: every LDS / global address below is then formed where it is used.
     // Left visible, LICM hoists dozens of loop-invariant addresses out of this loop and keeps them live across it (spills at KT = 8, dh = 64).
     int lr = lr0, lh = lh0, gi = gi0, qq = qq0, pp = pp0;
@@ -281,8 +356,12 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         }
       }
     }
+    XSTAMP(1);
     __syncthreads();   // (b)
-    if (qb + 1 < nqb) qload(qb + 1);
+    XSTAMP(2);
+    // (IL: the prefetch registers would be live across the vector phase that now also holds the dQ fragments -- requested behind it instead,
+    // one matrix phase and a barrier ahead of their use)
+    if (!IL && qb + 1 < nqb) qload(qb + 1);
 
     // ---- (c) S tile and (d) dP tile: rows = queries (registers), column = this lane's key ----
     f32x16 sacc, pacc;
@@ -314,6 +393,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    XSTAMP(3);
     const bool key_ok = mykey < Lk;
     const bool pad_wave = (wave * 32 + 32) > Lk;         // (wave-uniform) this wave's key tile has padding columns
     // The 16 registers of a lane are 16 query rows: rows 8j + 4*lh + {0,1,2,3} for j = r >> 2 -> one 16-byte LDS read per statistic and j.
@@ -331,6 +411,12 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       const uint32_t qlo = (uint32_t)(row0 + sub) * quarter + (uint32_t)(mykey >> 2);
 #pragma unroll
       for (int j4 = 0; j4 < 4; j4++) {
+        // IL: a quarter of the previous block's dQ steps in front of every quarter of the vector work (block 0 multiplies whatever the LDS
+        // holds and stores nothing: no branch, so the steps stay inside this scheduling region)
+        if (IL && TPW == 1 && !XABL(g, 16) && !XABL(g, 64)) {
+#pragma unroll
+          for (int i = j4 * TS / 4; i < (j4 + 1) * TS / 4; i++) dq_step(i, Sprev, gi, qq, pp);
+        }
         const float4 m4 = *reinterpret_cast<const float4*>(lse_s + 8 * j4 + 4 * lh);
         const float4 i4 = *reinterpret_cast<const float4*>(inv_s + 8 * j4 + 4 * lh);
         const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 8 * j4 + 4 * lh);
@@ -358,7 +444,23 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
           sacc[r] = pd;
           pacc[r] = p * (dp - rs_d[e]);
         }
+        if (IL && TPW == 1) {
+          // issue order of this quarter: per dQ step its six fragment reads, vector work while they travel, then its three (dependent,
+          // 16-cycle) MFMAs with vector instructions between them; what is left of the quarter's vector work follows
+#pragma unroll
+          for (int i = 0; i < TS / 4; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          }
+        }
       }
+      XSTAMP(4);
       // padding columns (keys past Lk: zero K rows, so S = 0 and p != 0): both products carry the factor p, so they are cleared here, by the
       // one wave that has such columns, instead of by a select per score in every wave
       if (pad_wave) {
@@ -369,6 +471,10 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         }
       }
     }
+    // (both behind the vector phase and its padding branch: a branch in front of it would end the scheduling region the dQ steps are placed in)
+    if (IL) qload(qb + 1 < nqb ? qb + 1 : qb);              // (unconditional: the last block re-requests its own rows)
+    if (IL && TPW == 1 && !XABL(g, 16) && !XABL(g, 64)) dq_store(TS - 1, qb - 1, gi);
+    XSTAMP(5);
     // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS   (g) dS -> LDS ----
     // First ALL the vector work of the block (four bf16 splits; the dS copy for dQ from the same packed halves), then ONE matrix phase of 24
     // MFMAs whose transposed fragment reads run one step ahead.  (Interleaved per half tile, each group of eight reads was waited for in
@@ -402,6 +508,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      XSTAMP(6);
       // steps (s2, n): A operands dO^T and Q^T of rows 16*s2 .. by transposed reads, B operands the packed halves above
       // this lane's element (row 4*lh + qq, column 16*(gi & 1) + 4*pp) once; steps and the second row group (+ 8: swizzle bit 2 flips) are
       // constant row offsets and one XOR of the 32-column bit
@@ -427,36 +534,36 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    XSTAMP(7);
     __syncthreads();   // (h)
+    XSTAMP(8);
 
-    // ---- (i) dQ block = dS . K with 16x16 tiles spread over the waves ----
-    constexpr int CT = DH / 16;
-    for (int t = wave; t < 2 * CT && !XABL(g, 16); t += KT) {
-      const int qh2 = t / CT, ct = t % CT;
-      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-      const unsigned short* ps0 = Sb + (qh2 * 16 + (lane & 15)) * RSS + 8 * gi;
-      const unsigned short* pk0 = Kb + Cfg::koff(8 * gi + qq, ct * 16 + 4 * pp);   // (the swizzle does not depend on ks, nor on the + 4 rows below)
-#pragma unroll 2
-      for (int ks = 0; ks < KT; ks++) {
-        const unsigned short* ps = ps0 + ks * 32;
-        const bf16x8 ah = lds_read_b128(ps), al = lds_read_b128(ps + S_PL);
-        const unsigned short* pk = pk0 + ks * 32 * RSK;
-        const bf16x8 bh = join4(lds_read_tr16(pk), lds_read_tr16(pk + 4 * RSK));
-        const bf16x8 bl = join4(lds_read_tr16(pk + K_PL), lds_read_tr16(pk + K_PL + 4 * RSK));
-        a4 = x3_mma16<EB>(ah, al, bh, bl, a4);
-      }
-      const int q0 = qb * 32 + qh2 * 16 + gi * 4;
-      unsigned char* dq0 = reinterpret_cast<unsigned char*>(g.dq + dqofs);
-      const unsigned lddq_b = (unsigned)g.lddq * 4u;
-      const unsigned dqo = __umul24((unsigned)q0, lddq_b) + (unsigned)(ct * 16 + (lane & 15)) * 4u;
+    // ---- (i) dQ block = dS . K (the forms that do not interleave it: see (d)) ----
+    if (!(IL && TPW == 1) && !XABL(g, 16) && !XABL(g, 64)) {
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (q0 + r < Lq && !XABL(g, 32)) *reinterpret_cast<float*>(dq0 + (dqo + (unsigned)r * lddq_b)) = a4[r];
+      for (int tw = 0; tw < TPW; tw++) {
+#pragma unroll 2
+        for (int ks = 0; ks < KT; ks++) dq_step(tw * KT + ks, Sb, gi, qq, pp);
+        dq_store(tw * KT + KT - 1, qb, gi);
+      }
     }
     // no barrier needed here: the next iteration's staging touches only Qf / Qb / Ob / statistics, which no wave reads in (i);
-    // barrier (b) of the next iteration orders (i) before the next (g).
+    // barrier (b) of the next iteration orders (i) before the next (g).  IL: block qb's dS image is read during block qb + 1 (behind (h))
+    // and rewritten by block qb + 2 (behind the next (h)).
+  }
+#ifdef HFTT_X3_ATTN_STAMPS
+  if (stamp_wg) stamp_p[12] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  if (IL && TPW == 1 && !XABL(g, 16) && !XABL(g, 64)) {       // the last block's dQ (barrier (h) of the last iteration is behind us)
+    const unsigned short* Slast = Sb0 + ((nqb - 1) & 1) * (2 * S_PL);
+#pragma unroll 2
+    for (int ks = 0; ks < KT; ks++) dq_step(ks, Slast, gi0, qq0, pp0);
+    dq_store(TS - 1, nqb - 1, gi0);
   }
 
+#ifdef HFTT_X3_ATTN_STAMPS
+  if (stamp_wg) stamp_p[13] = (long long)__builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: dK, dV (this wave's 32 keys) leave through LDS as whole row segments (DH fp32 = 128 / 256 bytes per key row) ----
   constexpr int RSE = Cfg::RSE;
   const float rscale = sqrtf((float)DH);                       // dV was accumulated from probabilities scaled by 1/sqrt(dh) (8: exact at dh = 64)
@@ -485,6 +592,10 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       *reinterpret_cast<float4*>(dvp + (long)key * g.lddv + ch * 4) = *reinterpret_cast<const float4*>(ev + row * RSE + ch * 4);
     }
   }
+#ifdef HFTT_X3_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stamp_wg) stamp_p[14] = (long long)__builtin_amdgcn_s_memtime();
+#endif
 }
 
 template <int KT, int DH, bool PL, int DM>

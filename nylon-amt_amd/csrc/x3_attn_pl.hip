@@ -469,7 +469,14 @@ int hftt_x3p_attn_bwd(const hftt_attn_desc& d, hipStream_t st) {
   HFTT_REQUIRE((d.io_flags & both) == both && d.dh == 64, "attn_bwd: f16-pair planes need both flags and dh == 64");
   HFTT_REQUIRE(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.q_seq_stride % 4 == 0 && d.k_seq_stride % 4 == 0 && d.v_seq_stride % 4 == 0,
                "attn_bwd: f16-pair planes must be 16-byte aligned");
+#ifdef HFTT_X3_ATTN_ABLATE
+  hftt_attn_desc da = d;
+  da.pad = 0;
+  if (const char* e = getenv("HFTT_X3_ATTN_DEBUG")) da.pad = (uint32_t)atoi(e);      // (timing switches of csrc/x3_attn_bwd.h)
+  return dispatch_xb<64, true>(da, st);
+#else
   return dispatch_xb<64, true>(d, st);
+#endif
 }
 
 // -1: not this kernel's case (x3_attn.hip handles fp32 operands); otherwise the launch status.  Called by hftt_x3_attn_fwd.
