@@ -93,8 +93,13 @@ struct XbCfg {
 // bit); the bf16 pairs of the gradient products are formed from hi + lo
 // DM: the dropout form (0 none, 1 one hash per aligned key quad, 2 per element), chosen by the host (as in x3_attn_pl.hip: three forms
 // instantiated side by side inside the query-block loop cost registers and scratch)
+// PL kernels are PERSISTENT: a workgroup walks items (sequence, head) blockIdx.x, + gridDim.x, ... and requests the next item's K / V rows and
+// first query block from inside the current item's last query block (the registers those live in are free there), so the item prologue --
+// 13 % of an item at one workgroup per CU, with nothing to overlap it -- is reduced to its conversions.
+struct XbBases { const unsigned char *q, *dout, *o, *l; const float *k, *v; };
 template <int KT, int DH, bool PL, int DM>
 __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_desc g) {
+  constexpr bool PS = PL;
   static_assert(!PL || DH == 64, "f16-pair planes: dh == 64");
   using Cfg = XbCfg<KT, DH>;
   constexpr int EF = X3_F16, EB = X3_BF16;
@@ -115,11 +120,6 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   constexpr bool IL = Cfg::IL;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef HFTT_X3_ATTN_STAMPS
-  long long* stamp_p = reinterpret_cast<long long*>(g.probs) + ((long)((int)blockIdx.x - 1024) * KT + wave) * 16;
-  const bool stamp_wg = g.probs != nullptr && blockIdx.x >= 1024 && blockIdx.x < 1088 && lane == 0;
-  if (stamp_wg) stamp_p[10] = (long long)__builtin_amdgcn_s_memtime();
-#endif
 #ifdef HFTT_PRIO_SKEW
   // waves w and w + 4 share a SIMD and run the same phases between the same barriers: a static priority makes the first finish its matrix
   // phase while the second waits, after which one is in vector work while the other multiplies
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
 #endif
   const int lr0 = lane & 31, lh0 = lane >> 5;
   const int gi0 = lane >> 4, qq0 = (lane & 15) >> 2, pp0 = lane & 3;
-  const int seq = blockIdx.x / g.n_heads, head = blockIdx.x % g.n_heads;
+  int item = blockIdx.x;
+  const int n_items = g.n_seq * g.n_heads;
   const int Lq = g.Lq, Lk = g.Lk;
   const float scale = 1.0f / sqrtf((float)DH);
   const float c2 = scale * XB_LOG2E;
@@ -135,13 +136,8 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   const float inv_keep = hftt_keep_scale(g.drop_p);
   const float keep_inv = g.drop_p > 0.f ? (float)thr * (1.0f / 256.0f) : 1.0f;      // 1 / inv_keep, exactly
 
-  const long kofs = (long)seq * g.k_seq_stride + head * DH;
-  const long vofs = (long)seq * g.v_seq_stride + head * DH;
-  const long qofs = (long)seq * g.q_seq_stride + head * DH;
-  const long oofs = (long)seq * g.o_seq_stride + head * DH;
-  const long dqofs = (long)seq * g.dq_seq_stride + head * DH;
-  const long sh = (long)seq * g.n_heads + head;
   const int nqb = (Lq + 31) / 32;
+  long dqofs = 0, sh = 0;                             // (of the current item)
 
   // Q / dO / O rows (+ row statistics) of the NEXT query block are fetched into registers while the current block is processed
   constexpr int QCNT = (32 * F4R + NTHR - 1) / NTHR;
@@ -149,12 +145,20 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   float2 pl[QCNT];
   // (wave-uniform base pointers + 32-bit byte offsets per lane: one 24-bit multiply per row stride instead of 64-bit address arithmetic
   // per tensor; a sequence's rows span Lq * ld * 4 bytes, far below 2^32)
-  const unsigned char* qbase = reinterpret_cast<const unsigned char*>(g.q + qofs);
-  const unsigned char* dobase = reinterpret_cast<const unsigned char*>(g.dout + oofs);
-  const unsigned char* obase = reinterpret_cast<const unsigned char*>(g.out + oofs);
-  const unsigned char* lbase = reinterpret_cast<const unsigned char*>(g.lse + sh * Lq * 2);
+  auto bases = [&](int it) {
+    const int seq_ = it / g.n_heads, head_ = it % g.n_heads;
+    const long oofs_ = (long)seq_ * g.o_seq_stride + head_ * DH;
+    XbBases b;
+    b.q = reinterpret_cast<const unsigned char*>(g.q + (long)seq_ * g.q_seq_stride + head_ * DH);
+    b.dout = reinterpret_cast<const unsigned char*>(g.dout + oofs_);
+    b.o = reinterpret_cast<const unsigned char*>(g.out + oofs_);
+    b.l = reinterpret_cast<const unsigned char*>(g.lse + ((long)seq_ * g.n_heads + head_) * Lq * 2);
+    b.k = g.k + (long)seq_ * g.k_seq_stride + head_ * DH;
+    b.v = g.v + (long)seq_ * g.v_seq_stride + head_ * DH;
+    return b;
+  };
   const unsigned ldq_b = (unsigned)g.ldq * 4u, ldo_b = (unsigned)g.ldo * 4u;
-  auto qload = [&](int qb) {
+  auto qload = [&](const XbBases& b, int qb) {
     int tid_q = tid;
     asm volatile("" : "+v"(tid_q));                    // (row / column offsets are formed per call, not kept in registers across the loop)
 #pragma unroll
@@ -166,100 +170,73 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       const unsigned qc = (unsigned)(q < Lq ? q : Lq - 1);   // clamped address: loads stay unconditional (rows past Lq are zeroed at consumption)
       const unsigned rq = __umul24(qc, ldq_b), ro = __umul24(qc, ldo_b) + (unsigned)cs * 16u;
       if (PL) {                                    // (hi, lo) pairs of the four elements, carried in the same four registers
-        const unsigned char* p_ = qbase + (rq + (unsigned)((cs >> 3) * 128 + (cs & 7) * 8));     // (pl_load4's layout)
+        const unsigned char* p_ = b.q + (rq + (unsigned)((cs >> 3) * 128 + (cs & 7) * 8));     // (pl_load4's layout)
         const uint2 ph_ = *reinterpret_cast<const uint2*>(p_), pl_ = *reinterpret_cast<const uint2*>(p_ + 64);
         pq[u] = make_float4(__uint_as_float(ph_.x), __uint_as_float(ph_.y), __uint_as_float(pl_.x), __uint_as_float(pl_.y));
       } else {
-        pq[u] = *reinterpret_cast<const float4*>(qbase + (rq + (unsigned)cs * 16u));
+        pq[u] = *reinterpret_cast<const float4*>(b.q + (rq + (unsigned)cs * 16u));
       }
-      pdo[u] = *reinterpret_cast<const float4*>(dobase + ro);
-      po[u] = *reinterpret_cast<const float4*>(obase + ro);
-      pl[u] = *reinterpret_cast<const float2*>(lbase + qc * 8u);
+      pdo[u] = *reinterpret_cast<const float4*>(b.dout + ro);
+      po[u] = *reinterpret_cast<const float4*>(b.o + ro);
+      pl[u] = *reinterpret_cast<const float2*>(b.l + qc * 8u);
     }
   };
 
-  // ---- the item's first loads are ALL requested before anything is converted: the K rows of the image, this wave's K / V rows, the first
-  // query block (one memory round trip instead of three in a row: the prologue was 14 % of a (sequence, head) item, nothing overlaps it
-  // at one workgroup per CU) ----
-  constexpr int KCNT = (LKP * F4R + NTHR - 1) / NTHR;
-  float4 kst[KCNT];                                   // PL: the (hi, lo) words as loaded
-#pragma unroll
-  for (int u = 0; u < KCNT; u++) {
-    const int i = tid + NTHR * u;
-    const int ic = i < LKP * F4R ? i : LKP * F4R - 1;
-    const int key = ic / F4R, c4 = ic % F4R;
-    const int kc = key < Lk ? key : Lk - 1;           // clamped address + select: loads stay unconditional
-    if (PL) {
-      uint2 ph_, pl_;
-      pl_load4(g.k + kofs + (long)kc * g.ldk, c4, ph_, pl_);
-      kst[u] = make_float4(__uint_as_float(ph_.x), __uint_as_float(ph_.y), __uint_as_float(pl_.x), __uint_as_float(pl_.y));
-    } else {
-      kst[u] = *reinterpret_cast<const float4*>(g.k + kofs + (long)kc * g.ldk + c4 * 4);
-    }
-  }
-  // this wave's K rows (fp16 pair: the scores) and V rows (bf16 pair: dP) as B-operand fragments (B[k = dh][col = key])
+  // ---- this wave's K rows (fp16 pair: the scores) and V rows (bf16 pair: dP) as B-operand fragments (B[k = dh][col = key]).  The K image of
+  // the dQ product (row-major, bf16 pair) is written from the same registers: the eight waves' rows are the image (it was loaded a second
+  // time, 64 KB per item through the vector memory path) ----
   const int mykey = wave * 32 + lr0;
-  const int mykey_c = mykey < Lk ? mykey : Lk - 1;
-  bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];         // PL: V's fp16 (hi, lo) as loaded until converted below
+  const int mykey_c = mykey < Lk ? mykey : Lk - 1;  // clamped address + select: loads stay unconditional
+  bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];         // PL: V's fp16 (hi, lo) as loaded until frag_convert
   float4 kraw[PL ? 1 : KS][2], vraw[PL ? 1 : KS][2];
+  auto frag_load = [&](const XbBases& b) {
+    int mk = mykey_c, lhh = lh0;
+    asm volatile("" : "+v"(mk), "+v"(lhh));          // (addresses formed here, not hoisted out of the query-block loop and kept live across it)
 #pragma unroll
-  for (int s = 0; s < KS; s++) {
-    if (PL) {
-      pl_load8(g.k + kofs + (long)mykey_c * g.ldk, 16 * s + 8 * lh0, kfh[s], kfl[s]);
-      pl_load8(g.v + vofs + (long)mykey_c * g.ldv, 16 * s + 8 * lh0, vfh[s], vfl[s]);
-    } else {
-      const float* kp = g.k + kofs + (long)mykey_c * g.ldk + 16 * s + 8 * lh0;
-      const float* vp = g.v + vofs + (long)mykey_c * g.ldv + 16 * s + 8 * lh0;
-      kraw[PL ? 0 : s][0] = *reinterpret_cast<const float4*>(kp); kraw[PL ? 0 : s][1] = *reinterpret_cast<const float4*>(kp + 4);
-      vraw[PL ? 0 : s][0] = *reinterpret_cast<const float4*>(vp); vraw[PL ? 0 : s][1] = *reinterpret_cast<const float4*>(vp + 4);
+    for (int s = 0; s < KS; s++) {
+      if (PL) {
+        pl_load8(b.k + (long)mk * g.ldk, 16 * s + 8 * lhh, kfh[s], kfl[s]);
+        pl_load8(b.v + (long)mk * g.ldv, 16 * s + 8 * lhh, vfh[s], vfl[s]);
+      } else {
+        const float* kp = b.k + (long)mk * g.ldk + 16 * s + 8 * lhh;
+        const float* vp = b.v + (long)mk * g.ldv + 16 * s + 8 * lhh;
+        kraw[PL ? 0 : s][0] = *reinterpret_cast<const float4*>(kp); kraw[PL ? 0 : s][1] = *reinterpret_cast<const float4*>(kp + 4);
+        vraw[PL ? 0 : s][0] = *reinterpret_cast<const float4*>(vp); vraw[PL ? 0 : s][1] = *reinterpret_cast<const float4*>(vp + 4);
+      }
     }
-  }
-  qload(0);
-  __builtin_amdgcn_sched_barrier(0);                  // (nothing below is moved in front of a load)
-  // ---- the K image (row-major, bf16 pair) for the dQ product ----
+  };
+  auto frag_convert = [&]() {
 #pragma unroll
-  for (int u = 0; u < KCNT; u++) {
-    const int i = tid + NTHR * u;
-    if (i < LKP * F4R) {
-      const int key = i / F4R, c4 = i % F4R;
-      float4 kv4 = kst[u];
-      if (PL) kv4 = pl_vals4(make_uint2(__float_as_uint(kst[u].x), __float_as_uint(kst[u].y)), make_uint2(__float_as_uint(kst[u].z), __float_as_uint(kst[u].w)));
-      if (key >= Lk) kv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint2 hi, lo;
-      x3_split4<EB>(kv4, hi, lo);
-      *reinterpret_cast<uint2*>(Kb + Cfg::koff(key, c4 * 4)) = hi;
-      *reinterpret_cast<uint2*>(Kb + K_PL + Cfg::koff(key, c4 * 4)) = lo;
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < KS; s++) {
-    if (PL) {
-      float vv[8];
-      pl_vals8(vfh[s], vfl[s], vv);
+    for (int s = 0; s < KS; s++) {
+      float kv[8], vv[8];
+      if (PL) {
+        pl_vals8(kfh[s], kfl[s], kv);
+        pl_vals8(vfh[s], vfl[s], vv);
+      } else {
+        const float4 a0 = kraw[PL ? 0 : s][0], a1 = kraw[PL ? 0 : s][1], b0 = vraw[PL ? 0 : s][0], b1 = vraw[PL ? 0 : s][1];
+        kv[0] = a0.x; kv[1] = a0.y; kv[2] = a0.z; kv[3] = a0.w; kv[4] = a1.x; kv[5] = a1.y; kv[6] = a1.z; kv[7] = a1.w;
+        vv[0] = b0.x; vv[1] = b0.y; vv[2] = b0.z; vv[3] = b0.w; vv[4] = b1.x; vv[5] = b1.y; vv[6] = b1.z; vv[7] = b1.w;
+      }
       if (mykey >= Lk) {
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        kfh[s] = z; kfl[s] = z;
+        if (PL) { kfh[s] = z; kfl[s] = z; }
 #pragma unroll
-        for (int e = 0; e < 8; e++) vv[e] = 0.f;
+        for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
       }
+      if (!PL) x3_split8<EF>(kv, kfh[s], kfl[s]);
       x3_split8<EB>(vv, vfh[s], vfl[s]);
-      continue;
+      bf16x8 ih, il;                                  // the image row piece: elements 16 s + 8 lh .. + 8 of key `mykey`
+      x3_split8<EB>(kv, ih, il);
+      const int ko = Cfg::koff(mykey, 16 * s + 8 * lh0);
+      *reinterpret_cast<bf16x8*>(Kb + ko) = ih;
+      *reinterpret_cast<bf16x8*>(Kb + K_PL + ko) = il;
     }
-    const float4 a0 = kraw[PL ? 0 : s][0], a1 = kraw[PL ? 0 : s][1], b0 = vraw[PL ? 0 : s][0], b1 = vraw[PL ? 0 : s][1];
-    float kv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    float vv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    if (mykey >= Lk) {
-#pragma unroll
-      for (int e = 0; e < 8; e++) { kv[e] = 0.f; vv[e] = 0.f; }
-    }
-    x3_split8<EF>(kv, kfh[s], kfl[s]);
-    x3_split8<EB>(vv, vfh[s], vfl[s]);
-  }
+  };
+  XbBases cur = bases(item);
+  frag_load(cur);
+  qload(cur, 0);
+  __builtin_amdgcn_sched_barrier(0);                  // (nothing below is moved in front of a load)
   f32x16 dKT[NT], dVT[NT];
-#pragma unroll
-  for (int n = 0; n < NT; n++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) { dKT[n][r] = 0.f; dVT[n][r] = 0.f; }
 
   // ---- dQ block = dS . K with 16x16 tiles spread over the waves: tile t = wave + KT * (i / KT), key tile ks = i % KT of step i ----
   constexpr int CT = DH / 16, NTILE = 2 * CT, TPW = (NTILE + KT - 1) / KT, TS = TPW * KT;
@@ -294,10 +271,28 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     }
   };
 
+  for (;;) {                                          // items of this workgroup
+  const int seq = item / g.n_heads, head = item % g.n_heads;
+  dqofs = (long)seq * g.dq_seq_stride + head * DH;
+  sh = (long)seq * g.n_heads + head;
+  const int nxt = item + (int)gridDim.x;
+  const bool has_next = PS && nxt < n_items;
+  const XbBases nb = bases(has_next ? nxt : item);
+#ifdef HFTT_X3_ATTN_STAMPS
+  long long* stamp_p = reinterpret_cast<long long*>(g.probs) + ((long)(item - 1024) * KT + wave) * 16;
+  const bool stamp_wg = g.probs != nullptr && item >= 1024 && item < 1088 && lane == 0;
+  if (stamp_wg) stamp_p[10] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  frag_convert();
+#pragma unroll
+  for (int n = 0; n < NT; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dKT[n][r] = 0.f; dVT[n][r] = 0.f; }
 #ifdef HFTT_X3_ATTN_STAMPS
   if (stamp_wg) stamp_p[11] = (long long)__builtin_amdgcn_s_memtime();
 #endif
   for (int qb = 0; qb < nqb; qb++) {
+    const bool last_qb = qb + 1 == nqb;
 #ifdef HFTT_X3_ATTN_STAMPS
     const bool stamp_on = stamp_wg && qb == 3;
     if (stamp_wg && qb == 4) stamp_p[9] = (long long)__builtin_amdgcn_s_memtime();
@@ -361,7 +356,10 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     XSTAMP(2);
     // (IL: the prefetch registers would be live across the vector phase that now also holds the dQ fragments -- requested behind it instead,
     // one matrix phase and a barrier ahead of their use)
-    if (!IL && qb + 1 < nqb) qload(qb + 1);
+    if (!IL) {
+      if (!last_qb) qload(cur, qb + 1);
+      else if (has_next) qload(nb, 0);              // the next item's first query block
+    }
 
     // ---- (c) S tile and (d) dP tile: rows = queries (registers), column = this lane's key ----
     f32x16 sacc, pacc;
@@ -394,6 +392,8 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       }
     }
     XSTAMP(3);
+    // the next item's K / V rows: this item's fragments had their last use above
+    if (PS && last_qb && has_next) frag_load(nb);
     const bool key_ok = mykey < Lk;
     const bool pad_wave = (wave * 32 + 32) > Lk;         // (wave-uniform) this wave's key tile has padding columns
     // The 16 registers of a lane are 16 query rows: rows 8j + 4*lh + {0,1,2,3} for j = r >> 2 -> one 16-byte LDS read per statistic and j.
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       }
     }
     // (both behind the vector phase and its padding branch: a branch in front of it would end the scheduling region the dQ steps are placed in)
-    if (IL) qload(qb + 1 < nqb ? qb + 1 : qb);              // (unconditional: the last block re-requests its own rows)
+    if (IL) qload(last_qb ? nb : cur, last_qb ? 0 : qb + 1);   // (unconditional; in the last block the next item's first rows, or -- no next item -- this item's again)
     if (IL && TPW == 1 && !XABL(g, 16) && !XABL(g, 64)) dq_store(TS - 1, qb - 1, gi);
     XSTAMP(5);
     // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS   (g) dS -> LDS ----
@@ -556,9 +556,11 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
 #endif
   if (IL && TPW == 1 && !XABL(g, 16) && !XABL(g, 64)) {       // the last block's dQ (barrier (h) of the last iteration is behind us)
     const unsigned short* Slast = Sb0 + ((nqb - 1) & 1) * (2 * S_PL);
+    int gi = gi0, qq = qq0, pp = pp0;
+    asm volatile("" : "+v"(gi), "+v"(qq), "+v"(pp));           // (per item: see the loop)
 #pragma unroll 2
-    for (int ks = 0; ks < KT; ks++) dq_step(ks, Slast, gi0, qq0, pp0);
-    dq_store(TS - 1, nqb - 1, gi0);
+    for (int ks = 0; ks < KT; ks++) dq_step(ks, Slast, gi, qq, pp);
+    dq_store(TS - 1, nqb - 1, gi);
   }
 
 #ifdef HFTT_X3_ATTN_STAMPS
@@ -568,15 +570,17 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   constexpr int RSE = Cfg::RSE;
   const float rscale = sqrtf((float)DH);                       // dV was accumulated from probabilities scaled by 1/sqrt(dh) (8: exact at dh = 64)
   __syncthreads();                                             // every wave is done with the loop's LDS images
-  float* ek = reinterpret_cast<float*>(smem) + wave * (2 * 32 * RSE);
+  int lane_e = lane, lr_e = lr0, lh_e = lh0;
+  asm volatile("" : "+v"(lane_e), "+v"(lr_e), "+v"(lh_e));     // (the store addresses are formed per item, not kept -- spilled -- across the item loop)
+  float* ek = reinterpret_cast<float*>(smem) + wave_s * (2 * 32 * RSE);
   float* ev = ek + 32 * RSE;
 #pragma unroll
   for (int n = 0; n < NT; n++)
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      const int dh0 = n * 32 + 8 * c + 4 * lh0;
-      *reinterpret_cast<float4*>(ek + lr0 * RSE + dh0) = make_float4(dKT[n][4 * c], dKT[n][4 * c + 1], dKT[n][4 * c + 2], dKT[n][4 * c + 3]);
-      *reinterpret_cast<float4*>(ev + lr0 * RSE + dh0) = make_float4(dVT[n][4 * c] * rscale, dVT[n][4 * c + 1] * rscale, dVT[n][4 * c + 2] * rscale, dVT[n][4 * c + 3] * rscale);
+      const int dh0 = n * 32 + 8 * c + 4 * lh_e;
+      *reinterpret_cast<float4*>(ek + lr_e * RSE + dh0) = make_float4(dKT[n][4 * c], dKT[n][4 * c + 1], dKT[n][4 * c + 2], dKT[n][4 * c + 3]);
+      *reinterpret_cast<float4*>(ev + lr_e * RSE + dh0) = make_float4(dVT[n][4 * c] * rscale, dVT[n][4 * c + 1] * rscale, dVT[n][4 * c + 2] * rscale, dVT[n][4 * c + 3] * rscale);
     }
   __syncthreads();
   constexpr int CPR = DH / 4;                                  // 16-byte chunks per row
@@ -585,17 +589,21 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   float* dvp = g.dv + (long)seq * g.dv_seq_stride + head * DH;
 #pragma unroll
   for (int ps = 0; ps < 32 / RPP; ps++) {
-    const int row = ps * RPP + lane / CPR, ch = lane % CPR;
-    const int key = wave * 32 + row;
+    const int row = ps * RPP + lane_e / CPR, ch = lane_e % CPR;
+    const int key = wave_s * 32 + row;
     if (key < Lk) {
       *reinterpret_cast<float4*>(dkp + (long)key * g.lddk + ch * 4) = *reinterpret_cast<const float4*>(ek + row * RSE + ch * 4);
       *reinterpret_cast<float4*>(dvp + (long)key * g.lddv + ch * 4) = *reinterpret_cast<const float4*>(ev + row * RSE + ch * 4);
     }
   }
 #ifdef HFTT_X3_ATTN_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (stamp_wg) stamp_p[14] = (long long)__builtin_amdgcn_s_memtime();
+  if (stamp_wg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_p[14] = (long long)__builtin_amdgcn_s_memtime(); }
 #endif
+  if (!has_next) break;
+  item = nxt;
+  cur = nb;
+  __syncthreads();                                    // the patches above alias the images the next item writes
+  }
 }
 
 template <int KT, int DH, bool PL, int DM>
@@ -607,7 +615,22 @@ int launch_xb(const hftt_attn_desc& d, hipStream_t st) {
     if (e != hipSuccess) { hftt_set_error("x3_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 2; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((x3_attn_bwd_kernel<KT, DH, PL, DM>), dim3((unsigned)(d.n_seq * d.n_heads)), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, d);
+  long grid = (long)d.n_seq * d.n_heads;
+  if (PL) {                                           // persistent: as many workgroups as the device holds at once
+    static int resident = 0;
+    if (resident == 0) {
+      int dev = 0, per_cu = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(x3_attn_bwd_kernel<KT, DH, PL, DM>), Cfg::NTHR, Cfg::LDS_BYTES) != hipSuccess || per_cu < 1) {
+        hftt_set_error("x3_attn_bwd: device / occupancy query failed");
+        return 2;
+      }
+      resident = per_cu * prop.multiProcessorCount;
+    }
+    if (grid > resident) grid = resident;
+  }
+  hipLaunchKernelGGL((x3_attn_bwd_kernel<KT, DH, PL, DM>), dim3((unsigned)grid), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, d);
   HFTT_CHECK_LAUNCH("x3_attn_bwd");
   return 0;
 }
