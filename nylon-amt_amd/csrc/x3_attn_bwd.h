@@ -13,7 +13,7 @@ constexpr float XB_LOG2E = 1.4426950408889634f;
 #define HFTT_XB_IL 1           // 0: the 256-key form without the interleaved dQ product (A/B builds: tools/stamp_x3_attn.sh)
 #endif
 // -DHFTT_X3_ATTN_STAMPS (tools/stamp_x3_attn.sh): lane 0 of every wave of workgroups 1024 .. 1087 stamps the shader clock around the phases of
-// query block 3 into g.probs (unused by the backward) as [workgroup][wave][16] int64
+// query block 3 into g.probs (unused by the backward) as [item][wave][32] int64 (16, 17: the 100 MHz counter at the item's start and end)
 #ifdef HFTT_X3_ATTN_STAMPS
 #define XSTAMP(k) do { if (stamp_on) stamp_p[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -279,9 +279,9 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   const bool has_next = PS && nxt < n_items;
   const XbBases nb = bases(has_next ? nxt : item);
 #ifdef HFTT_X3_ATTN_STAMPS
-  long long* stamp_p = reinterpret_cast<long long*>(g.probs) + ((long)(item - 1024) * KT + wave) * 16;
+  long long* stamp_p = reinterpret_cast<long long*>(g.probs) + ((long)(item - 1024) * KT + wave) * 32;
   const bool stamp_wg = g.probs != nullptr && item >= 1024 && item < 1088 && lane == 0;
-  if (stamp_wg) stamp_p[10] = (long long)__builtin_amdgcn_s_memtime();
+  if (stamp_wg) { stamp_p[10] = (long long)__builtin_amdgcn_s_memtime(); stamp_p[16] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
   frag_convert();
 #pragma unroll
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     }
   }
 #ifdef HFTT_X3_ATTN_STAMPS
-  if (stamp_wg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_p[14] = (long long)__builtin_amdgcn_s_memtime(); }
+  if (stamp_wg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_p[14] = (long long)__builtin_amdgcn_s_memtime(); stamp_p[17] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
   if (!has_next) break;
   item = nxt;

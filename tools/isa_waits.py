@@ -11,7 +11,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ''
 names = re.findall(r'^(_Z\w+):\s*; @', src, flags=re.M)
 def demangle(n):
     try:
-        return subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', n], capture_output=True, text=True).stdout.strip()
+        return subprocess.run(['/usr/bin/c++filt', n], capture_output=True, text=True).stdout.strip()
     except Exception:
         return n
 for n in names:

@@ -15,7 +15,7 @@ qp, kvp = ops.to_planes(q), ops.to_planes(kv)
 kp, vp = kvp[..., :d], kvp[..., d:]
 out, lse = ops.attn_fwd(q, kv[..., :d], kv[..., d:], H, npass=2, drop_p=0.1, drop_site=1, drop_seed=3)
 dq = torch.empty_like(q); dkv = torch.empty_like(kv)
-stamps = torch.zeros(64 * 8 * 16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(64 * 8 * 32, dtype=torch.int64, device=dev)
 dsc = _attn_desc(qp, kp, vp, H, 2, 0.1, 1, 3, True)
 dsc.out, dsc.o_seq_stride, dsc.ldo = out.data_ptr(), out.stride(0), out.stride(1)
 dsc.lse, dsc.dout = lse.data_ptr(), do.data_ptr()
@@ -33,7 +33,7 @@ for _ in range(8): check(lib().hftt_attn_bwd(C.byref(dsc), _stream(dev)), 'attn_
 b.record(); torch.cuda.synchronize()
 us = a.elapsed_time(b) / 8 * 1e3
 print('launch %.1f us' % us)
-t = stamps.view(64, 8, 16).cpu().double()
+t = stamps.view(64, 8, 32).cpu().double()
 names = ['(a) staging: registers -> LDS', 'barrier (b)', '(c) S / dP: 24 MFMA', '(d) softmax backward (+ dQ steps when interleaved)', 'padding, prefetch, dQ store',
          '(e) splits + dS -> LDS', '(f) dV / dK: 24 MFMA', 'barrier (h)', '(i) dQ phase / loop end']
 for k, nm in enumerate(names):
@@ -44,5 +44,6 @@ for nm, a_, b_ in (('prologue: K image, K / V fragments, first prefetch', 10, 11
                    ('epilogue: dK / dV through LDS, stores drained', 13, 14), ('whole (sequence, head) item', 10, 14)):
     dl = (t[:, :, b_] - t[:, :, a_]).reshape(-1)
     print('%-52s mean %7.0f  p10 %7.0f  p90 %7.0f' % (nm, dl.mean(), dl.quantile(0.1), dl.quantile(0.9)))
+print('shader clock over the stamped items: %.2f GHz (s_memtime ticks per 100 MHz s_memrealtime tick)' % (((t[:, :, 14] - t[:, :, 10]) / (t[:, :, 17] - t[:, :, 16])).mean() * 0.1))
 wg = t[:, 0, 10].sort().values
 print('workgroups 1024 .. 1087 start over %.0f ticks; item ticks x 16 items / launch time = %.2f GHz' % (wg[-1] - wg[0], (t[:, :, 14] - t[:, :, 10]).mean() * 16 / (us * 1e3)))
