@@ -287,7 +287,7 @@ def test_to_planes_and_the_projection_epilogue_write_the_same_bytes(dev):
         assert torch.equal(pln.view(torch.int32), ops.to_planes(full).view(torch.int32)), (M, N)
 
 
-PLANE_GEOMS = [(5, 4, 256, 256), (37, 4, 256, 256), (5, 4, 88, 256), (300, 4, 88, 256), (5, 4, 88, 88), (6, 4, 128, 128), (700, 2, 128, 128), (3, 2, 48, 48),
+PLANE_GEOMS = [(5, 4, 256, 256), (37, 4, 256, 256), (80, 4, 256, 256), (5, 4, 88, 256), (300, 4, 88, 256), (5, 4, 88, 88), (6, 4, 128, 128), (700, 2, 128, 128), (3, 2, 48, 48),
                (3, 1, 16, 16), (3, 2, 12, 40), (2, 1, 100, 70), (2, 2, 200, 250)]
 
 
@@ -296,7 +296,8 @@ PLANE_GEOMS = [(5, 4, 256, 256), (37, 4, 256, 256), (5, 4, 88, 256), (300, 4, 88
 def test_attention_on_planes_equals_attention_on_fp32_operands(dev, n, H, Lq, Lk, drop):
     """The plane forms run the SAME arithmetic in the same order on the same halves: forward outputs, row statistics and the attention map are
     bit-identical to the fp32-operand kernels' (themselves held against fp64 above); the backward's bf16 pairs are formed from hi + lo instead
-    of the fp32 value (2^-23 apart: a bf16 pair's last bit, 2^-17, may round the other way), so its gradients agree to the pair's precision.  More (sequence, head) items than persistent workgroups, key padding,
+    of the fp32 value (2^-23 apart: a bf16 pair's last bit, 2^-17, may round the other way), so its gradients agree to the pair's precision.  More (sequence, head) items than persistent workgroups -- in the forward AND in the backward (320 / 1,200 / 1,400 items on 256 / 512
+    resident workgroups: second and third items per workgroup, unevenly) --, key padding,
     ragged query blocks, idle waves (88 queries on 4 waves), the shared query of layer zero."""
     ops = _ops()
     dh, d = 64, 64 * H
