@@ -152,3 +152,42 @@ def test_valid_metrics_pipeline_on_the_degenerate_case():
     assert len(ei) == B * T * P and len(ri) == 3
     m = transcription_evaluate(ri, rp, ei, ep)
     assert m['Recall'] == 1.0 and m['Precision'] == pytest.approx(3 / (B * T * P))
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_transcription_evaluate_against_a_brute_force_restatement_and_scipy_matching(seed):
+    """An independent route to the same numbers on dense random note sets (many candidates per note, so greedy matching and maximum matching
+    differ): the pairwise conditions written out as dense matrices (no sorting, no windows) and the matching size from
+    scipy.sparse.csgraph.maximum_bipartite_matching instead of the module's augmenting paths."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    from evaluation.metrics import transcription_evaluate
+    rng = np.random.default_rng(seed)
+    n_ref, n_est = 300, 330
+    ref_on = np.sort(rng.uniform(0, 20, n_ref)); ref_i = np.stack([ref_on, ref_on + rng.uniform(0.05, 1.0, n_ref)], 1)
+    ref_p = 440.0 * 2.0 ** (rng.integers(-6, 7, n_ref) / 12.0)                    # 13 pitches: collisions in time AND pitch
+    pick = rng.integers(0, n_ref, n_est)
+    est_on = ref_i[pick, 0] + rng.normal(0, 0.04, n_est)
+    est_i = np.stack([est_on, ref_i[pick, 1] + rng.normal(0, 0.08, n_est)], 1)
+    est_i[:, 1] = np.maximum(est_i[:, 1], est_i[:, 0] + 0.01)
+    est_p = ref_p[pick] * 2.0 ** (rng.normal(0, 0.25, n_est) / 12.0)              # some beyond 50 cents
+    got = transcription_evaluate(ref_i, ref_p, est_i, est_p)
+    d_on = np.around(np.abs(ref_i[:, None, 0] - est_i[None, :, 0]), 4)
+    d_off = np.around(np.abs(ref_i[:, None, 1] - est_i[None, :, 1]), 4)
+    cents = np.abs(1200.0 * np.log2(ref_p)[:, None] - 1200.0 * np.log2(est_p)[None, :])
+    tol = np.maximum(0.05, 0.2 * (ref_i[:, 1] - ref_i[:, 0]))[:, None]
+    for key, ok in (('_no_offset', (d_on <= 0.05) & (cents <= 50.0)), ('', (d_on <= 0.05) & (cents <= 50.0) & (d_off <= tol))):
+        match = maximum_bipartite_matching(csr_matrix(ok.astype(np.int8)), perm_type='column')
+        tp = int((match >= 0).sum())
+        assert 0 < tp < min(n_ref, n_est)
+        p, r = tp / n_est, tp / n_ref
+        assert got['Precision' + key] == pytest.approx(p, abs=1e-12) and got['Recall' + key] == pytest.approx(r, abs=1e-12)
+        assert got['F-measure' + key] == pytest.approx(2 * p * r / (p + r), abs=1e-12)
+        # and the matching really is larger than what a greedy first-fit finds on these sets (the test would be vacuous otherwise)
+        used, greedy = set(), 0
+        for i in range(n_ref):
+            for j in np.nonzero(ok[i])[0]:
+                if j not in used:
+                    used.add(j); greedy += 1
+                    break
+        assert greedy <= tp
