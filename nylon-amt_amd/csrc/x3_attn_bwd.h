@@ -98,7 +98,9 @@ struct XbCfg {
 // 13 % of an item at one workgroup per CU, with nothing to overlap it -- is reduced to its conversions.
 struct XbBases { const unsigned char *q, *dout, *o, *l; const float *k, *v; };
 template <int KT, int DH, bool PL, int DM>
-__global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_desc g) {
+// (second launch bound = waves per SIMD the registers must allow: the forms of <= 128 keys hold two or more workgroups per CU by their LDS, and
+// without the bound hipcc spreads them over 280 - 300 registers -- accumulation registers as spill space -- which halves their occupancy)
+__global__ __launch_bounds__(KT * 64, (KT == 3 || KT == 4) ? 2 : 1) void x3_attn_bwd_kernel(const hftt_attn_desc g) {
   constexpr bool PS = PL;
   static_assert(!PL || DH == 64, "f16-pair planes: dh == 64");
   using Cfg = XbCfg<KT, DH>;
@@ -118,6 +120,9 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   float* delta_s = lse_s + 32;
   float* inv_s = lse_s + 64;
   constexpr bool IL = Cfg::IL;
+  // the next block's rows are requested behind the vector phase (IL: they would be live across it together with the dQ fragments; 96
+  // keys: 3 sets of prefetch registers per lane do not fit the 256 registers of two workgroups per CU beside that phase)
+  constexpr bool LATE_Q = IL || KT == 3;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef HFTT_PRIO_SKEW
@@ -190,8 +195,10 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
   bf16x8 kfh[KS], kfl[KS], vfh[KS], vfl[KS];         // PL: V's fp16 (hi, lo) as loaded until frag_convert
   float4 kraw[PL ? 1 : KS][2], vraw[PL ? 1 : KS][2];
   auto frag_load = [&](const XbBases& b) {
-    int mk = mykey_c, lhh = lh0;
-    asm volatile("" : "+v"(mk), "+v"(lhh));          // (addresses formed here, not hoisted out of the query-block loop and kept live across it)
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));                      // (lane indices and addresses formed here from the thread index: nothing of them is kept live -- or spilled -- across the query-block loop)
+    const int mkey_ = (t_ >> 6) * 32 + (t_ & 31);
+    const int mk = mkey_ < Lk ? mkey_ : Lk - 1, lhh = (t_ >> 5) & 1;
 #pragma unroll
     for (int s = 0; s < KS; s++) {
       if (PL) {
@@ -206,6 +213,9 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     }
   };
   auto frag_convert = [&]() {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));                      // (as in frag_load)
+    const int mykey = (t_ >> 6) * 32 + (t_ & 31), lh0 = (t_ >> 5) & 1;
 #pragma unroll
     for (int s = 0; s < KS; s++) {
       float kv[8], vv[8];
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
     XSTAMP(2);
     // (IL: the prefetch registers would be live across the vector phase that now also holds the dQ fragments -- requested behind it instead,
     // one matrix phase and a barrier ahead of their use)
-    if (!IL) {
+    if (!LATE_Q) {
       if (!last_qb) qload(cur, qb + 1);
       else if (has_next) qload(nb, 0);              // the next item's first query block
     }
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(KT * 64) void x3_attn_bwd_kernel(const hftt_attn_de
       }
     }
     // (both behind the vector phase and its padding branch: a branch in front of it would end the scheduling region the dQ steps are placed in)
-    if (IL) qload(last_qb ? nb : cur, last_qb ? 0 : qb + 1);   // (unconditional; in the last block the next item's first rows, or -- no next item -- this item's again)
+    if (LATE_Q) qload(last_qb ? nb : cur, last_qb ? 0 : qb + 1);   // (unconditional; in the last block the next item's first rows, or -- no next item -- this item's again)
     if (IL && TPW == 1 && !XABL(g, 16) && !XABL(g, 64)) dq_store(TS - 1, qb - 1, gi);
     XSTAMP(5);
     // ---- (e) dV^T += dO^T . Pd   (f) dK^T += Q^T . dS   (g) dS -> LDS ----
