@@ -48,7 +48,12 @@ struct AbCfg {
 
 // HB: q, k, v, out, dout all stored as bf16 -> 16-byte loads straight into LDS / fragments (dq, dk, dv dtype by io_flags)
 template <int KT, int DH, int NPASS, bool HB>
-__global__ __launch_bounds__(KT * 64, (NPASS == 1 && (KT == 4 || (KT == 3 && HB))) ? 2 : 1) void attn_bwd_kernel(const hftt_attn_desc g) {   // (see x3_attn_bwd.h)
+#ifdef HFTT_ATTN_BWD_NOCAP      // (A/B build of tools/r05_step23.sh)
+#define HFTT_AB_WAVES(NPASS, KT, HB) 1
+#else
+#define HFTT_AB_WAVES(NPASS, KT, HB) (((NPASS) == 1 && ((KT) == 4 || ((KT) == 3 && (HB)))) ? 2 : 1)
+#endif
+__global__ __launch_bounds__(KT * 64, HFTT_AB_WAVES(NPASS, KT, HB)) void attn_bwd_kernel(const hftt_attn_desc g) {   // (see x3_attn_bwd.h)
   using Cfg = AbCfg<KT, DH, NPASS>;
   constexpr bool F32 = Cfg::F32;
   static_assert(!(F32 && HB), "bf16-stored tensors are a bf16-mode feature");

@@ -78,7 +78,7 @@ struct XbCfg {
   // IL (256 keys: one workgroup per CU whatever the size): the dQ product of query block qb - 1 is issued inside the softmax-backward vector
   // phase of block qb (matrix pipe and LDS under vector work; it was a phase of its own behind barrier (h): 150 of 1007 us standalone), which
   // needs the dS block double-buffered.  The smaller forms keep one buffer: 76 KB = two workgroups per CU at 128 keys.
-  static constexpr bool IL = KT == 8 && HFTT_XB_IL != 0;
+  static constexpr bool IL = KT == 8 && DH == 64 && HFTT_XB_IL != 0;   // (dh = 32: four dQ tiles for eight waves -- the interleaved form measured no gain there)
   static constexpr int NSB = IL ? 2 : 1;
   // Q fp16 (hi, lo) | Q bf16 (hi, lo) | dO bf16 (hi, lo) | row statistics | dS bf16 (hi, lo) x NSB | K image (bf16 hi, lo)
   static constexpr int ELEMS = 2 * K_PL + 6 * Q_PL + NSB * 2 * S_PL;
@@ -100,7 +100,7 @@ struct XbBases { const unsigned char *q, *dout, *o, *l; const float *k, *v; };
 template <int KT, int DH, bool PL, int DM>
 // (second launch bound = waves per SIMD the registers must allow: the forms of <= 128 keys hold two or more workgroups per CU by their LDS, and
 // without the bound hipcc spreads them over 280 - 300 registers -- accumulation registers as spill space -- which halves their occupancy)
-__global__ __launch_bounds__(KT * 64, (KT == 3 || KT == 4) ? 2 : 1) void x3_attn_bwd_kernel(const hftt_attn_desc g) {
+__global__ __launch_bounds__(KT * 64, (KT == 4 || (KT == 3 && (PL || DH == 32))) ? 2 : 1) void x3_attn_bwd_kernel(const hftt_attn_desc g) {
   constexpr bool PS = PL;
   static_assert(!PL || DH == 64, "f16-pair planes: dh == 64");
   using Cfg = XbCfg<KT, DH>;
