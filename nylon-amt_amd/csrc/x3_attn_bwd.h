@@ -9,6 +9,10 @@
 #endif
 #endif
 constexpr float XB_LOG2E = 1.4426950408889634f;
+#ifndef HFTT_XB_SG_A
+#define HFTT_XB_SG_A 10         // vector instructions between a dQ step's fragment reads and its first MFMA / between its MFMAs (tools/sweep_xb_sg.sh)
+#define HFTT_XB_SG_B 6
+#endif
 #ifndef HFTT_XB_IL
 #define HFTT_XB_IL 1           // 0: the 256-key form without the interleaved dQ product (A/B builds: tools/stamp_x3_attn.sh)
 #endif
@@ -460,13 +464,13 @@ __global__ __launch_bounds__(KT * 64, (KT == 4 || (KT == 3 && (PL || DH == 32)))
 #pragma unroll
           for (int i = 0; i < TS / 4; i++) {
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, HFTT_XB_SG_A, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, HFTT_XB_SG_B, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, HFTT_XB_SG_B, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, HFTT_XB_SG_B, 0);
           }
         }
       }
