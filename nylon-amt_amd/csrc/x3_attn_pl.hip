@@ -97,7 +97,7 @@ __device__ __forceinline__ void pl_dma_tensor(const unsigned char* base, long ld
 // DM: the dropout form (0 none, 1 one hash per aligned key quad, 2 per element -- Lk % 4 != 0 or more than 2^34 map elements), chosen by
 // the host: as a run-time test inside the tile loop the forms met in phi copies of whole score tiles and a branch per quad
 template <int KT, int NW, bool MAP, int DM>
-__global__ __launch_bounds__(NW * 64, (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kernel(const hftt_attn_desc g, const int n_items) {
+__global__ __launch_bounds__(NW * 64, (KT <= 3) ? 3 : (KT <= 4) ? 2 : 1) void x3p_attn_fwd_kernel(const hftt_attn_desc g, const int n_items) {
   using Cfg = PfCfg<KT>;
   constexpr int E = X3_F16, DH = 64, KS = 4, NT = 2;
   constexpr int IMG = Cfg::IMG, LKP = Cfg::LKP;
@@ -424,7 +424,7 @@ int launch_pf(const hftt_attn_desc& d, hipStream_t st) {
   }
   const int cus = pl_n_cus();
   if (cus <= 0) { hftt_set_error("x3p_attn_fwd: device query failed"); return 2; }
-  const int per_cu = Cfg::LDS_BYTES <= 80 * 1024 ? 2 : 1;
+  const int per_cu = Cfg::LDS_BYTES <= 53 * 1024 ? 3 : Cfg::LDS_BYTES <= 80 * 1024 ? 2 : 1;      // (<= 96 keys: 49 KB of images, three workgroups of four waves per CU; the launch bound keeps them at <= 170 registers)
   const long items = (long)d.n_seq * d.n_heads;
   const long grid = items < (long)per_cu * cus ? items : (long)per_cu * cus;
   hipLaunchKernelGGL((x3p_attn_fwd_kernel<KT, NW, MAP, DM>), dim3((unsigned)grid), dim3(NW * 64), Cfg::LDS_BYTES, st, d, (int)items);
