@@ -55,3 +55,16 @@ def test_attention_backward_on_planes_registers_and_occupancy():
         if kt == 8:             # eight waves = two per SIMD
             assert _get(v, 'VGPRs') + _get(v, 'AGPRs') <= 256, (name, v)
     assert seen == 15           # KT 1, 2, 3, 4, 8 x three dropout forms
+    # the forward on planes: its persistent grid is sized by LDS alone (launch_pf: three workgroups per CU at <= 96 keys, two at 128), so the
+    # registers must allow that many waves per SIMD without scratch
+    fwd = 0
+    for name, v in res.items():
+        m = re.match(r'x3p_attn_fwd_kernel<(\d+), (\d+), (true|false), (\d)>', name)
+        if not m:
+            continue
+        fwd += 1
+        kt, nw = int(m.group(1)), int(m.group(2))
+        assert _get(v, 'ScratchSize') == 0, (name, v)
+        need = 3 if kt <= 3 else (2 if kt <= 4 or nw == 8 else 1)
+        assert _get(v, 'Occupancy') >= need, (name, v)
+    assert fwd >= 24
