@@ -101,9 +101,10 @@ struct XbCfg {
 // first query block from inside the current item's last query block (the registers those live in are free there), so the item prologue --
 // 13 % of an item at one workgroup per CU, with nothing to overlap it -- is reduced to its conversions.
 struct XbBases { const unsigned char *q, *dout, *o, *l; const float *k, *v; };
+// Second launch bound = waves per SIMD the registers must allow: the forms of 96 / 128 keys hold two workgroups per CU by their LDS, and
+// without the bound hipcc spreads them over 280 - 300 registers -- accumulation registers as spill space -- which halves their occupancy
+// (tests/test_kernel_resources.py reads the compiler's resource remarks for exactly this).
 template <int KT, int DH, bool PL, int DM>
-// (second launch bound = waves per SIMD the registers must allow: the forms of <= 128 keys hold two or more workgroups per CU by their LDS, and
-// without the bound hipcc spreads them over 280 - 300 registers -- accumulation registers as spill space -- which halves their occupancy)
 __global__ __launch_bounds__(KT * 64, (KT == 4 || (KT == 3 && (PL || DH == 32))) ? 2 : 1) void x3_attn_bwd_kernel(const hftt_attn_desc g) {
   constexpr bool PS = PL;
   static_assert(!PL || DH == 64, "f16-pair planes: dh == 64");
