@@ -35,7 +35,7 @@ import collections   # noqa: E402
 import torch   # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-MEASURED_BF16_MFMA_LOOP_TFLOPS = 1646.0     # (see roofline_object)
+MEASURED_BF16_MFMA_LOOP_TFLOPS = 1940.0     # (see roofline_object)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_CLIP = 249.44    # SURVEY.md section 8(d), paper size, forward; training = 3x
@@ -304,7 +304,7 @@ def roofline_object(key, v, steps, peak_tf, total_ms, kind='bench', mfma_passes=
     roof.update({'mfma_passes': mfma_passes, 'frac_of_bf16_mfma_peak': tf / PEAK_BF16_TFLOPS, 'matrix_pipe_tflops': mfma_passes * tf,
                  'matrix_pipe_frac_of_bf16_peak': mfma_passes * tf / PEAK_BF16_TFLOPS,
                  # context, not the contract's peak: what a bare back-to-back v_mfma_f32_32x32x16_bf16 loop delivers on this chip (32.0 cycles per
-                 # instruction on all 1024 SIMDs at the 1.57 GHz the power management grants it: tools/probes/mfma_fp8_rate.hip, profiles/r05_fp8_cross_terms.txt)
+                 # instruction on all 1024 SIMDs at the 1.85 GHz the power management grants it on varied operands, steady state: tools/probes/mfma_chain.hip, profiles/r05_fp8_cross_terms.txt)
                  'matrix_pipe_frac_of_measured_mfma_loop': mfma_passes * tf / MEASURED_BF16_MFMA_LOOP_TFLOPS})
     roof.update({'traffic': traffic, 'traffic_source': src, 'mfma_busy': pmc_busy(key, kind), 'kernel': key,
                  'launches_per_step': v['launches'] / steps, 'avg_launch_ms': v['ms'] / v['launches'],

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 1) void probe_x3(unsigned long long* out, int 
 template <bool MIX>
 void run_x3(const char* name) {
   unsigned long long* d; hipMalloc(&d, 8 * (1 + 256 * 4 * 2));
-  const int iters = 1000;
+  const int iters = 5000;
   for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL((probe_x3<MIX>), dim3(256), dim3(256), 0, 0, d, iters, 3);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(1 + 256 * 4 * 2);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void probe(unsigned long long* out, int ite
 template <bool FP8>
 void run(const char* name, double macs) {
   unsigned long long* d; hipMalloc(&d, 8 * (1 + 256 * 4 * 2));
-  const int iters = 4000;
+  const int iters = 20000;
   for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL((probe<FP8>), dim3(256), dim3(256), 0, 0, d, iters, 3);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(1 + 256 * 4 * 2);
@@ -96,9 +96,13 @@ void run(const char* name, double macs) {
   hipFree(d);
 }
 int main() {
-  run<false>("v_mfma_f32_32x32x16_bf16", 32.0 * 32 * 16);
-  run<true>("v_mfma_scale_f32_32x32x64_f8f6f4", 32.0 * 32 * 64);
-  run_x3<false>("x3 product, three bf16 passes (12 instr.)");
-  run_x3<true>("x3 product, bf16 hi.hi + fp8 cross (4 + 2 instr.)");
+  // several rounds: the clock a loop is granted also depends on what ran in the seconds before it (the first kernels of a process run slower)
+  for (int round = 0; round < 4; round++) {
+    printf("-- round %d\n", round);
+    run<false>("v_mfma_f32_32x32x16_bf16", 32.0 * 32 * 16);
+    run<true>("v_mfma_scale_f32_32x32x64_f8f6f4", 32.0 * 32 * 64);
+    run_x3<false>("x3 product, three bf16 passes (12 instr.)");
+    run_x3<true>("x3 product, bf16 hi.hi + fp8 cross (4 + 2 instr.)");
+  }
   return 0;
 }
