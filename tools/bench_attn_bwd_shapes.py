@@ -16,7 +16,7 @@ kp, vp = kvp[..., :d], kvp[..., d:]
 out, lse = ops.attn_fwd(q, kv[..., :d], kv[..., d:], H, npass=2, drop_p=0.1, drop_site=1, drop_seed=3)      # (fp32 operands: any Lq / Lk; bit-identical outputs)
 dq = torch.empty_like(q); dkv = torch.empty_like(kv)
 def t(fn, reps=8):
-    for _ in range(2): fn()
+    for _ in range(int(os.environ.get('WARM', 2))): fn()      # (WARM=300: steady-state clocks -- the first kernels of a process are clocked lower)
     torch.cuda.synchronize()
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record()
