@@ -392,6 +392,11 @@ int hftt_bs_strip_linear_try(const hftt_strip_desc& d, hipStream_t st) {
 
 int hftt_bs_strip_mlp_try(const hftt_ffn_desc& d, hipStream_t st) {
   if (d.d != 64 || d.p != 128) return -1;
+  // the family computes on the bf16 stream only: the same storage requirement as check_ffn (strip_gemm.hip) -- a d = 64 descriptor without
+  // the all-bf16 flags is an error here, not a reinterpretation of fp32 buffers
+  const uint32_t all = HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16;
+  if ((d.flags & all) != all) { hftt_set_error("bs_strip_mlp: the fused block is all-bf16 (flags X_BF16 | C_BF16 | RES_BF16), got flags 0x%x", d.flags); return 1; }
+  if ((long)d.M * d.p >= (1L << 33)) { hftt_set_error("bs_strip_mlp: M*p too large for the 32-bit dropout pair index"); return 1; }
   if (d.M <= 0 || d.M % 32 != 0 || d.x == nullptr || d.w == nullptr || d.y == nullptr) { hftt_set_error("bs_strip_mlp: M=%d must be a positive multiple of 32, x / w / y non-null", d.M); return 1; }
   if ((((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.w | (uintptr_t)d.residual | (uintptr_t)d.pre_ln_out | (uintptr_t)d.h_out | (uintptr_t)d.gate) & 15) != 0 ||
       d.ldx % 8 != 0 || d.ldy % 8 != 0 || (d.h_out != nullptr && d.ldh % 8 != 0) || (d.gate != nullptr && d.ldg % 8 != 0) || (d.residual != nullptr && d.ldr % 8 != 0)) {

@@ -61,6 +61,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.hftt_ffn_res_ln_fwd(C.byref(fd), None) != 0
     assert b'd == 256' in lib.hftt_last_error()
     assert lib.hftt_ffn_bwd_dx(C.byref(fd), None) != 0          # mode 0 descriptor handed to the mode 1 entry point
+    # the small-width family (d = 64, ff = 128) keeps the all-bf16 storage requirement of the fused block: an fp32 descriptor of that shape
+    # is rejected before any launch, for both entry points (it used to be reinterpreted as bf16)
+    for mode, fn in ((0, lib.hftt_ffn_res_ln_fwd), (1, lib.hftt_ffn_bwd_dx)):
+        fs = _capi.FfnDesc()
+        fs.M, fs.d, fs.p, fs.mode, fs.flags = 128, 64, 128, mode, 0
+        fs.x = fs.w = fs.y = 0x1000
+        assert fn(C.byref(fs), None) != 0
+        assert b'all-bf16' in lib.hftt_last_error(), lib.hftt_last_error()
     with pytest.raises(_capi.HfttError):
         _capi.check(1, 'x')
 

@@ -320,23 +320,41 @@ def test_dropout_training_mode(dev):
     assert all(max_err(p, q) == 0.0 for p, q in zip(a, b))
 
 
-@pytest.mark.parametrize('precision', ['parity', 'parity256', 'bf16'])
-def test_dropout_on_outputs_and_gradients_with_the_device_masks_exported_to_the_oracle(dev, monkeypatch, precision):
+# d = 256 / ff = 512 (the paper's width): the strip plans.  x3_256: 32 keys per attention (plane forms at two workgroups per CU);
+# x3_256_long: 256 bins -- the 256-key plane kernels bench.py's step is made of (x3p_attn_fwd_kernel<8, 8, ...>, the persistent staggered
+# x3_attn_bwd_kernel<8, 64, true, 1> = the roofline kernel, and the cross-attention forms with 40 notes = two query blocks per item)
+_WIDE = dict(n_margin=4, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512, enc_layer=1, dec_layer=2, enc_head=4, dec_head=4, n_velocity=16)
+DROPOUT_CASES = {
+    'parity': ('parity', MINI), 'parity256': ('parity', O.HfttConfig(n_frame=16, n_bin=32, n_note=8, **_WIDE)),
+    'bf16': ('bf16', O.HfttConfig(n_frame=16, n_bin=32, n_note=8, **_WIDE)),
+    # the BENCHMARKED mode: its own launch sequence and site wiring -- block plans (MINI: ff = 96), the small-width strip
+    # family (the reference's default width, ff = 128), the strip + plane plans at the paper's width
+    'x3': ('x3', MINI),
+    'x3_small': ('x3', O.HfttConfig(n_margin=4, n_frame=16, n_bin=48, cnn_channel=4, cnn_kernel=5, hid_dim=64, pf_dim=128, enc_layer=2, dec_layer=2,
+                                    enc_head=2, dec_head=2, n_note=12, n_velocity=16)),
+    'x3_256': ('x3', O.HfttConfig(n_frame=16, n_bin=32, n_note=8, **_WIDE)),
+    'x3_256_long': ('x3', O.HfttConfig(n_frame=8, n_bin=256, n_note=40, **_WIDE)),
+}
+
+
+def _kernels(plan):
+    return [(m or {}).get('kernel', '') for _, _, _, m in plan]
+
+
+@pytest.mark.parametrize('case', list(DROPOUT_CASES))
+def test_dropout_on_outputs_and_gradients_with_the_device_masks_exported_to_the_oracle(dev, monkeypatch, case):
     """The benchmarked training path runs ~40 hash-mask sites, each regenerated in the backward.  Here the oracle is given the SAME masks (its
-    dropout calls, in reference order, are answered from the numpy emulation of the device generator with the engine's seed and site
-    numbers), so every output and every gradient can be compared exactly as in the dropout-free test: a site / seed / index mismatch
-    between a forward and a backward launch, or between two kernels of one site, shows up as a gradient error."""
+    dropout calls, in reference order -- model_spec2midi.py:95,236,242,348,372 --, are answered from the numpy emulation of the device generator
+    with the engine's seed and site numbers), so every output and every gradient can be compared exactly as in the dropout-free test: a site /
+    seed / index mismatch between a forward and a backward launch, or between two kernels of one site, shows up as a gradient error.  The
+    control -- the oracle's masks taken from sites shifted by one -- must be far off, or the comparison proves nothing."""
     from hftt_hip.trainer import TrainStep
-    cfg, B, p = MINI, 2, 0.1
-    wide = precision != 'parity'
-    precision = 'bf16' if precision == 'bf16' else 'parity'
-    if wide:                                # d = 256 (the strip kernels in bf16 mode): one encoder layer of the paper's width
-        cfg = O.HfttConfig(n_margin=4, n_frame=16, n_bin=32, cnn_channel=4, cnn_kernel=5, hid_dim=256, pf_dim=512, enc_layer=1, dec_layer=2,
-                           enc_head=4, dec_head=4, n_note=8, n_velocity=16)
+    precision, cfg = DROPOUT_CASES[case]
+    B, p = 2, 0.1
     model = util.build_model(cfg, 31, dropout=p)
     util.perturb(model, 32)
     sd = util.sd_cpu(model)
-    x = O.synth_spec(B, cfg, salt=13) * (0.5 if precision == 'parity' else 0.05)       # (bf16: small logits, so that rounding is not the story)
+    x = O.synth_spec(B, cfg, salt=13) * (0.05 if precision == 'bf16' else 0.5)       # (bf16: small logits, so that rounding is not the story)
     labels = O.synth_labels(B, cfg, salt=14)
     model = model.to(dev)
     model.hftt_precision = precision
@@ -344,31 +362,63 @@ def test_dropout_on_outputs_and_gradients_with_the_device_masks_exported_to_the_
     ts = TrainStep(model)
     loss = ts.forward_backward(x.to(dev), *_to_dev(labels, dev))
     eng = ts.engine
-    assert eng.strip == (precision == 'bf16' and os.environ.get('HFTT_STRIP', '1') != '0')
+    strip_on = os.environ.get('HFTT_STRIP', '1') != '0'
     ws = eng._ws[B]
+    if precision != 'x3':
+        assert eng.strip == (precision == 'bf16' and strip_on)
+    elif strip_on:                          # which launch sequence did the x3 case really run?
+        fk, bk = _kernels(ws['fwd']), _kernels(ws['bwd'])
+        if case == 'x3':
+            assert not eng.strip and any(k.startswith('gemm_nt_kernel') for k in fk)
+        elif case == 'x3_small':
+            assert eng.strip_small and ws['strip'] and any('x3s_mlp_kernel<0' in k for k in fk) and any('x3s_mlp_kernel<1' in k for k in bk)
+        else:
+            assert eng.strip and ws['strip'] and not eng.strip_small
+            assert any(k.startswith('x3_mlp_kernel<0, 16') for k in fk) and any(k.startswith('x3_mlp_kernel<1, 16') for k in bk)
+            assert any(k.startswith('x3p_attn_fwd_kernel') for k in fk)
+            if case == 'x3_256_long':       # the kernels of bench.py's step, dropout form 1 (one hash per key quad)
+                assert 'x3_attn_bwd_kernel<8, 64, true, 1>' in bk and 'x3p_attn_fwd_kernel<8, 8, false, 1>' in fk
+                assert 'x3p_attn_fwd_kernel<8, 4, true, 1>' in fk, fk      # cross attention of the last decoder layer (writes the attention map)
+            else:
+                assert 'x3_attn_bwd_kernel<1, 64, true, 1>' in bk, bk
     seed, n_sites = ws['seed'], eng._site
-    site = iter(range(1, n_sites + 1))
 
-    def drop(t, pp, training):
-        if not (training and pp > 0.0):
-            return t
-        m = util.keep_mask_t(seed, next(site), tuple(t.shape), pp).to(t.dtype)
-        return t * m * keep_scale(pp)
-    monkeypatch.setattr(O, '_drop', drop)
-    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref_out = O.model_forward(sdg, x, cfg, p=p, training=True)
-    ref_loss = O.spec2midi_loss(ref_out, *labels)
-    ref_loss.backward()
-    assert next(site, None) is None, 'the oracle made fewer dropout calls than the engine has sites'
+    def oracle_with_sites(order):
+        site = iter(order)
+
+        def drop(t, pp, training):
+            if not (training and pp > 0.0):
+                return t
+            m = util.keep_mask_t(seed, next(site), tuple(t.shape), pp).to(t.dtype)
+            return t * m * keep_scale(pp)
+        monkeypatch.setattr(O, '_drop', drop)
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out = O.model_forward(sdg, x, cfg, p=p, training=True)
+        l = O.spec2midi_loss(out, *labels)
+        l.backward()
+        assert next(site, None) is None, 'the oracle made fewer dropout calls than the engine has sites'
+        return sdg, out, l
+    sdg, ref_out, ref_loss = oracle_with_sites(range(1, n_sites + 1))
     outs = ws['outs']
-    tol_out, tol_loss, tol_g = (TOL_OUT, 1e-3, 3e-2) if precision == 'parity' else (0.3, 5e-2, None)      # bf16 vs an fp32 oracle at random init: DESIGN.md section 2
+    tol_out, tol_loss, tol_g = (0.3, 5e-2, None) if precision == 'bf16' else (TOL_OUT, 1e-3, 3e-2)      # bf16 vs an fp32 oracle at random init: DESIGN.md section 2
     worst = max(max_err(outs[k], ref_out[k]) for k in (0, 1, 2, 5, 6, 7))
     assert worst < tol_out, worst
     assert abs(loss[0].item() - ref_loss.item()) < tol_loss * max(1.0, abs(ref_loss.item()))
-    if precision == 'parity':
+    if precision == 'x3':
+        assert max(max_err(outs[k], ref_out[k]) for k in (3, 8)) < TOL_OUT and max_err(outs[4], ref_out[4]) < TOL_OUT      # velocity logits, attention map
+    if precision != 'bf16':
         rep = {}
         _grad_check(eng, None, {k: v.grad for k, v in sdg.items()}, tol_g, rep)
-        print('dropout-on parity gradients: worst relative error %.2e' % rep['worst_grad_rel'])
+        # control: masks from the WRONG sites (shifted by one) -- the same check must fail, by a wide margin
+        sdw, _, _ = oracle_with_sites(list(range(2, n_sites + 1)) + [1])
+        wrong = 0.0
+        for (name, _, o, n) in eng._bound:
+            ref = sdw[name].grad
+            if ref.abs().max().item() >= 1e-7:
+                wrong = max(wrong, (eng.flat_grads[o:o + n].view(eng.pshape[name]).cpu().double() - ref.double()).abs().max().item() / ref.abs().max().item())
+        print('dropout-on %s gradients (%d sites): worst relative error %.2e, posteriors %.2e; with shifted sites %.2e'
+              % (case, n_sites, rep['worst_grad_rel'], worst, wrong))
+        assert wrong > max(10 * rep['worst_grad_rel'], 10 * tol_g), (wrong, rep)
     else:                                   # bf16: the whole-gradient direction (a wrong mask anywhere turns it)
         g = torch.cat([eng.flat_grads[o:o + n] for (name, _, o, n) in eng._bound if not name.endswith('fc_k.bias')]).double().cpu()
         r = torch.cat([sdg[name].grad.reshape(-1) for (name, _, o, n) in eng._bound if not name.endswith('fc_k.bias')]).double()

@@ -437,15 +437,17 @@ def test_two_process_inference_scatter_equals_one_engine(dev, tmp_path):
             assert np.array_equal(r['s%d' % k], one_s[k]), (rank, 's', k)
 
 
-def test_one_rank_rccl_rehearsal_of_the_bench_ddp_branch(dev):
+@pytest.mark.parametrize('config', ['tiny', 'paper'])
+def test_one_rank_rccl_rehearsal_of_the_bench_ddp_branch(dev, config):
     """bench.py's N > 1 branch -- init_process_group('nccl') = RCCL, parameter broadcast, the three bucket all-reduces on the side stream,
     the barriers, the all-gathered device list in the JSON line -- with a ONE-rank group on the one GPU of this box (the multi-GPU node
-    only exists at the driver's round end)."""
+    only exists at the driver's round end).  'paper' is BASELINE config 4's own size: three buckets of the 22 MB flat
+    gradient against the persistent one-workgroup-per-CU kernels of the paper-size backward."""
     import json
     import subprocess
     import sys
-    env = dict(os.environ, HFTT_BENCH_FORCE_DDP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(39500 + (os.getpid() % 2000)))
-    r = subprocess.run([sys.executable, os.path.join(util.ROOT, 'bench.py'), '--config', 'tiny', '--steps', '3', '--warmup', '1',
+    env = dict(os.environ, HFTT_BENCH_FORCE_DDP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(39500 + (os.getpid() % 2000) + (7 if config == 'paper' else 0)))
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, 'bench.py'), '--config', config, '--steps', '3', '--warmup', '1',
                         '--no-cpu-baseline', '--no-extras', '--no-profile'], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
@@ -455,21 +457,31 @@ def test_one_rank_rccl_rehearsal_of_the_bench_ddp_branch(dev):
     # the three gradient buckets in release order (time decoder + heads B, frequency decoder + heads A, encoder): the all-reduces of the
     # first two were enqueued on the side stream while the backward still had the encoder to go, and finished before its last kernel
     assert len(col['buckets']) == 3 and col['buckets'][0]['range'][0] > col['buckets'][1]['range'][0] > col['buckets'][2]['range'][0] == 0
+    print('one-rank RCCL rehearsal, %s: %.1f clips/s, %.2f ms/step, buckets %s' % (config, line['value'], line['ms_per_step'], json.dumps(col['buckets'])))
+    out = os.path.join(util.ROOT, 'gpurun_out')
+    if os.path.isdir(out):                              # (the record DESIGN.md section 7 quotes)
+        json.dump({'config': config, 'clips_per_s': line['value'], 'ms_per_step': line['ms_per_step'], 'collective': col},
+                  open(os.path.join(out, 'r06_rccl_rehearsal_%s.json' % config), 'w'), indent=1)
     assert col['buckets'][0]['ms_before_backward_end'] > 0.0 and col['buckets'][1]['ms_before_backward_end'] > 0.0, col['buckets']
     assert col['early_buckets_hidden'] is True
+    if config == 'paper':
+        flat = col['buckets'][0]['range'][1]
+        assert flat >= 5516574 and line['config']['global_batch'] == 8       # the 22 MB flat gradient of the paper-size model (165 tensors + alignment)
 
 
-def test_two_rank_bench_on_one_gpu(dev):
+@pytest.mark.parametrize('config', ['tiny', 'paper'])
+def test_two_rank_bench_on_one_gpu(dev, config):
     """bench.py under torch.distributed.run with TWO ranks sharing this box's GPU (HFTT_BENCH_SHARE_GPU=1: gloo collectives, both ranks on
     cuda:0): the launch contract of the driver's N > 1 runs -- RANK / LOCAL_RANK / WORLD_SIZE from the environment, the barrier + max-over-
-    ranks timing, one JSON line from rank 0 with the all-gathered device list -- fails here for a reason instead of on the 8-GPU node."""
+    ranks timing, one JSON line from rank 0 with the all-gathered device list -- fails here for a reason instead of on the 8-GPU node.
+    'paper': BASELINE config 4 at its own size, 2 x batch 8 (two ~17 GB workspaces on the one 288 GB device)."""
     import json
     import subprocess
     import sys
     env = dict(os.environ, HFTT_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    port = str(41000 + (os.getpid() % 2000))
+    port = str(41000 + (os.getpid() % 2000) + (7 if config == 'paper' else 0))
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', port,
-                        os.path.join(util.ROOT, 'bench.py'), '--gpus', '2', '--config', 'tiny', '--steps', '3', '--warmup', '1',
+                        os.path.join(util.ROOT, 'bench.py'), '--gpus', '2', '--config', config, '--steps', '3', '--warmup', '1',
                         '--no-cpu-baseline', '--no-extras', '--no-profile'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -478,3 +490,5 @@ def test_two_rank_bench_on_one_gpu(dev):
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
     assert line['config']['global_batch'] == 16 and line['config']['parallelism'] == 'dp2'
     assert line['collective']['ranks'] == 2 and sorted(d['rank'] for d in line['collective']['devices']) == [0, 1]
+    assert len(line['collective']['buckets']) == 3 and ('%s-size' % config) in line['config']['workload']
+    print('two ranks on one GPU, %s: %.1f clips/s (both ranks share the device; gloo moves the buckets through the host)' % (config, line['value']))
