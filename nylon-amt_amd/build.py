@@ -18,22 +18,13 @@ SOURCES = ['capi.cpp', 'gemm_nt.hip', 'strip_gemm.hip', 'strip_gemm2.hip', 'bs_s
 HEADERS = [os.path.join(CSRC, 'hftt_common.h'), os.path.join(CSRC, 'hftt_host.h'), os.path.join(CSRC, 'strip_internal.h'), os.path.join(CSRC, 'strip_pipe.h'), os.path.join(CSRC, 'x3_common.h'), os.path.join(CSRC, 'x3_internal.h'), os.path.join(CSRC, 'x3_attn_bwd.h'), os.path.join(CSRC, 'x3s_strip.h'),
            os.path.join(HERE, '..', 'include', 'hftt_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
-# HFTT_BUILD_EXPERIMENTS=1: also build csrc/experiments/ (three alternative schedules of the bf16 strip tiling, each measured slower than
-# the shipped one: DESIGN.md section 4) and let HFTT_STRIP_V3 / V4 / V5 select them; the default library does not carry them
-# -- into a library of its own (libhftt_hip_x.so, which hftt_hip/_capi.py loads under the same switch), so switching the flag off again can
-# never leave the experiments build behind under the product library's name
-if os.environ.get('HFTT_BUILD_EXPERIMENTS') == '1':
-    SOURCES += ['experiments/strip_gemm3.hip', 'experiments/strip_gemm4.hip', 'experiments/strip_gemm5.hip']
-    FLAGS += ['-DHFTT_STRIP_EXPERIMENTS']
-    LIB = os.path.join(LIBDIR, 'libhftt_hip_x.so')
-
 
 # HFTT_BUILD_GRAD_HI=1: also build the opt-in gradient-rounding forms (a gradient operand as its bf16 rounding, two MFMA
 # passes; outside the 1e-3 gradient tolerance of the default mode).  They double the x3_linear* instantiations, so the default library leaves
 # them out (hftt_build_options() bit 0 says which build is loaded).
 if os.environ.get('HFTT_BUILD_GRAD_HI') == '1':
     FLAGS += ['-DHFTT_GRAD_HI_BUILD']
-    LIB = os.path.join(LIBDIR, 'libhftt_hip_g.so' if LIB.endswith('libhftt_hip.so') else 'libhftt_hip_xg.so')
+    LIB = os.path.join(LIBDIR, 'libhftt_hip_g.so')
 
 
 def _hipcc():
@@ -51,7 +42,7 @@ def _stale(target, deps):
 
 
 def _compile(src):
-    obj = os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + (('.x' if 'HFTT_STRIP_EXPERIMENTS' in ' '.join(FLAGS) else '') + ('.g' if 'HFTT_GRAD_HI_BUILD' in ' '.join(FLAGS) else '') + '.o'))
+    obj = os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + (('.g' if 'HFTT_GRAD_HI_BUILD' in ' '.join(FLAGS) else '') + '.o'))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
         cmd = [_hipcc()] + FLAGS + ['-x', 'hip', '-c', path, '-o', obj]

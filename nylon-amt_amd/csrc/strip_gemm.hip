@@ -666,14 +666,6 @@ extern "C" int hftt_strip_linear(const hftt_strip_desc* d, void* stream) {
   }
   {                                                   // the persistent software-pipelined form where it applies (strip_gemm2.hip)
     int rc;
-#ifdef HFTT_STRIP_EXPERIMENTS                         // csrc/experiments/: three measured-slower forms of the same tiling, opt-in builds only
-    rc = hftt_strip_linear5_try(*d, st);
-    if (rc >= 0) return rc;
-    rc = hftt_strip_linear4_try(*d, st);
-    if (rc >= 0) return rc;
-    rc = hftt_strip_linear3_try(*d, st);
-    if (rc >= 0) return rc;
-#endif
     rc = hftt_strip_linear2_try(*d, st);
     if (rc >= 0) return rc;
   }

@@ -422,15 +422,13 @@ __global__ __launch_bounds__(256, 1) void strip_linear2_kernel(const hftt_strip_
 // ---------------------------------------------------------------------------------------------------------------------
 // fused two-GEMM block, d = 256, p = 32 * PT: mode 0 = FFN forward + residual + LayerNorm, mode 1 = dX half of its backward
 // ---------------------------------------------------------------------------------------------------------------------
-// WPC = workgroups per CU.  1: the form above (one wave per SIMD, 512 registers, the next block's activations prefetched into a second
-// register set).  2 (round 5): the same stream with HALF the registers -- no second activation set (a block's rows are requested at its
-// top; the latency is the partner workgroup's to cover), four fragment reads in flight instead of six -- so that two workgroups share a
-// CU, each with its own ring and barrier: one's middle / LayerNorm epilogue and slot waits issue under the other's MFMA run, which one wave
-// per SIMD cannot do for itself.  LDS: 2 x (64 KB ring + parameters) = 141 KB.
+// One workgroup per CU: one wave per SIMD, 512 registers, the next block's activations prefetched into a second register set.  (A plan at half
+// the registers and two workgroups per CU was built and measured in round 5 -- +3.5 % on the inference form, -4 .. -8 % on the training
+// forms, compiler-limited -- and removed in round 6: docs/HISTORY.md.)
 // STP (round 5): results leave as whole 128-byte lines through wave-private LDS patches (strip_pipe.h: patch_put / patch_flush) instead of
 // 16-byte row pieces -- the stored hidden (pairs of tiles, four pieces behind the odd tile's second GEMM), the pre-LayerNorm rows and the output.
-template <int MODE, int PT, int WPC, bool STP>
-__global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_desc g) {
+template <int MODE, int PT, bool STP>
+__global__ __launch_bounds__(256, 1) void strip_mlp2_kernel(const hftt_ffn_desc g) {
   static_assert(PT % 4 == 0, "the gate prefetch ring and the slot buffers assume PT % 4 == 0");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -469,23 +467,21 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
   // epilogue.  xn: the next block's activations, one piece per hidden tile.  Results are stored from the epilogue directly: with 16
   // hidden-tile stores already spread over the block, a deferred set on top overflowed the register file (73-95 spills, and a spill
   // of a register with a load in flight is a wrong answer, not a slow one).
-  u4v xf[16], xn[WPC == 1 ? 16 : 1];
+  u4v xf[16], xn[16];
   u4v gt[4][2];                                     // mode 1: stored hidden (the gate) of tiles t .. t+2, ring of four
   {
     const long t0 = tok_of(blockIdx.x);
     const unsigned short* p0 = xb + t0 * g.ldx + 16 * h;
-    if (WPC == 1) {
-      if (STP) {                                      // whole-line pieces from a wave-uniform base (see strip_linear2_kernel)
-        const long r0 = (long)blockIdx.x * 128 + wave * 32;
-        const unsigned short* b0 = xb + (r0 < (long)g.M ? r0 : (long)g.M - 32) * g.ldx;
+    if (STP) {                                      // whole-line pieces from a wave-uniform base (see strip_linear2_kernel)
+      const long r0 = (long)blockIdx.x * 128 + wave * 32;
+      const unsigned short* b0 = xb + (r0 < (long)g.M ? r0 : (long)g.M - 32) * g.ldx;
 #pragma unroll
-        for (int i = 0; i < 16; i++) xn[WPC == 1 ? i : 0] = aload16s(b0, patch_off(lane, i & 3, g.ldx, i >> 2));
-      } else {
+      for (int i = 0; i < 16; i++) xn[i] = aload16s(b0, patch_off(lane, i & 3, g.ldx, i >> 2));
+    } else {
 #pragma unroll
-        for (int i = 0; i < 16; i++) pload16(xn[WPC == 1 ? i : 0], p0 + piece_off(i));
-      }
-      P.issued += 16;
+      for (int i = 0; i < 16; i++) pload16(xn[i], p0 + piece_off(i));
     }
+    P.issued += 16;
     if (MODE == 1) {
 #pragma unroll
       for (int t = 0; t < 2; t++) {
@@ -518,20 +514,15 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
     int zero = 0;                                     // (keeps the LDS parameter reads inside the iteration: see strip_linear2_kernel)
     asm volatile("" : "+s"(zero));
     const float* prm_b = prm + zero;
-    if (WPC == 1 && STP) {                            // line pieces -> the lane's own row pieces, through the output patch
+    if (STP) {                            // line pieces -> the lane's own row pieces, through the output patch
 #pragma unroll
       for (int pr = 0; pr < 4; pr++) {
-        patch_put_lines(patchY, lane, xn[WPC == 1 ? 4 * pr : 0], xn[WPC == 1 ? 4 * pr + 1 : 0], xn[WPC == 1 ? 4 * pr + 2 : 0], xn[WPC == 1 ? 4 * pr + 3 : 0]);
+        patch_put_lines(patchY, lane, xn[4 * pr], xn[4 * pr + 1], xn[4 * pr + 2], xn[4 * pr + 3]);
         patch_get_rows(patchY, j, hb, xf[4 * pr], xf[4 * pr + 1], xf[4 * pr + 2], xf[4 * pr + 3]);
       }
-    } else if (WPC == 1) {
+    } else {
 #pragma unroll
-      for (int i = 0; i < 16; i++) xf[i] = xn[WPC == 1 ? i : 0];
-    } else {                                          // requested here, consumed by the first slot's MFMAs (hipcc places the wait)
-      const unsigned short* xrow = xb + tokc * g.ldx + 16 * hb;
-#pragma unroll
-      for (int i = 0; i < 16; i++) pload16(xf[i], xrow + piece_off(i));
-      P.issued += 16;
+      for (int i = 0; i < 16; i++) xf[i] = xn[i];
     }
 
     f32x16 yacc[8];
@@ -568,21 +559,19 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
         const unsigned char* slot = abase + BA * SLOT_BYTES;
         const bool in_blk = (t + 2) < PT;             // mode 1: gate of tile t + 2 (of the next block past the end)
         const unsigned short* gp = (MODE == 1) ? g.gate + (in_blk ? tokc : tokn) * g.ldg + ((t + 2) % PT) * 32 + 16 * hb : nullptr;
-        if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(1);      // two workgroups per CU: the wave in its matrix phase wins the issue slot
         if (!S2DBG(g, 256))
-        slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int f, bf16x8 a) __attribute__((always_inline)) { hacc = mfma32(a, as_frag(xf[f]), hacc); }, S2DBG(g, 1024));    // fragment f = 2 * pt + u
-        if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(0);
+        slot_mfmas<6>(slot, [&](int f, bf16x8 a) __attribute__((always_inline)) { hacc = mfma32(a, as_frag(xf[f]), hacc); }, S2DBG(g, 1024));    // fragment f = 2 * pt + u
         static_for<4>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int q = decltype(q_c)::value;
           P.template fill_piece<BA, q>();
           if (q == 0) {
-            if (WPC == 1 && has_next && !(HFTT_MLP2_CT & 4)) {               // one piece of the next block's activations per tile
+            if (has_next && !(HFTT_MLP2_CT & 4)) {               // one piece of the next block's activations per tile
               if (STP) {
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
                 const long r0 = nxt * 128 + wave * 32;
-                xn[WPC == 1 ? t : 0] = aload16s(xb + (r0 < (long)g.M ? r0 : (long)g.M - 32) * g.ldx, patch_off(ln, t & 3, g.ldx, t >> 2));
-              } else pload16(xn[WPC == 1 ? t : 0], xrow_next + piece_off(t));
+                xn[t] = aload16s(xb + (r0 < (long)g.M ? r0 : (long)g.M - 32) * g.ldx, patch_off(ln, t & 3, g.ldx, t >> 2));
+              } else pload16(xn[t], xrow_next + piece_off(t));
               P.issued += 1;
             }
           } else if (q < 3) {
@@ -626,10 +615,8 @@ __global__ __launch_bounds__(256, WPC) void strip_mlp2_kernel(const hftt_ffn_des
         unsigned short* hp = g.h_out + tok * g.ldh + hcol0;
         const unsigned short* hwave = g.h_out + (blk * 128 + wave * 32) * g.ldh;       // (wave-uniform)
         if (STP && st_h) patch_put(patchH, j, hb, t & 1, hf[0], hf[1]);
-        if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(1);
         if (!S2DBG(g, 256))
-        slot_mfmas<WPC == 1 ? 6 : 4>(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { yacc[i & 7] = mfma32(a, as_frag(hf[i >> 3]), yacc[i & 7]); }, S2DBG(g, 1024));
-        if (WPC == 2 && S2PRIO(g)) __builtin_amdgcn_s_setprio(0);
+        slot_mfmas<6>(slot, [&](int i, bf16x8 a) __attribute__((always_inline)) { yacc[i & 7] = mfma32(a, as_frag(hf[i >> 3]), yacc[i & 7]); }, S2DBG(g, 1024));
         static_for<4>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int q = decltype(q_c)::value;
           P.template fill_piece<BB, q>();
@@ -749,27 +736,19 @@ int launch_linear2(const hftt_strip_desc& d, hipStream_t st) {
   if (e && e[0] == '0') return launch_linear2_stp<LN, PASSES, KCH, HR, false>(d, st);
   return launch_linear2_stp<LN, PASSES, KCH, HR, true>(d, st);
 }
-template <int MODE, int WPC, bool STP>
+template <int MODE, bool STP>
 int launch_mlp2(const hftt_ffn_desc& d, hipStream_t st) {
   const int lds = RING_BYTES + 4 * (d.p + 768) + (STP ? 4 * 3 * PATCH_BYTES : 0);
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(strip_mlp2_kernel<MODE, 16, WPC, STP>, lds, "strip_mlp2")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(strip_mlp2_kernel<MODE, 16, STP>, lds, "strip_mlp2")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("strip_mlp2: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  const long grid = (long)WPC * cus;
-  hipLaunchKernelGGL((strip_mlp2_kernel<MODE, 16, WPC, STP>), dim3((unsigned)(nblk < grid ? nblk : grid)), dim3(256), lds, st, d);
+  const long grid = cus;
+  hipLaunchKernelGGL((strip_mlp2_kernel<MODE, 16, STP>), dim3((unsigned)(nblk < grid ? nblk : grid)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("strip_mlp2");
   return 0;
 }
-// HFTT_MLP2_WPC / HFTT_MLP2_WPC_BWD = 1 / 2: workgroups per CU of the fused block.  Default 1, by measurement (round 5, S_e, same box): two per CU
-// ran the inference form 3.5 % faster (194 -> 188 us) and both training forms 4-8 % slower (283 -> 307, 299 -> 313 us): DESIGN section 5
-int mlp2_wpc(int mode) {      // (read per launch: tests and the A/B tools switch it inside one process)
-  const char* e = getenv(mode == 0 ? "HFTT_MLP2_WPC" : "HFTT_MLP2_WPC_BWD");
-  const int v = e ? atoi(e) : 1;
-  return v == 2 ? 2 : 1;
-}
-
 }  // namespace
 
 // -1: this shape / storage is not covered by the pipelined form (the caller launches the general kernel); otherwise the launch status
@@ -807,20 +786,11 @@ int hftt_strip_mlp2_try(const hftt_ffn_desc& d0, hipStream_t st) {
   d.pad = strip2_debug();
   if (!v2_enabled() || d.p != 512 || d.M % 32 != 0) return -1;
   if (d.mode == 0 && d.residual != nullptr) return -1;
-  if (mlp2_wpc(d.mode == 0 ? 0 : 1) == 2) {
-#ifdef HFTT_STRIP_EXPERIMENTS
-    return d.mode == 0 ? launch_mlp2<0, 2, false>(d, st) : launch_mlp2<1, 2, false>(d, st);
-#else
-    hftt_set_error("strip_mlp2: the two-workgroups-per-CU plan (HFTT_MLP2_WPC=2) is a measured-and-rejected experiment (DESIGN section 5, round 5); "
-                   "it is only in HFTT_BUILD_EXPERIMENTS=1 builds");
-    return 1;
-#endif
-  }
   // Whole-line stores through the LDS patches (STP), chosen per form by measurement (round 5, S_e, same box, row pieces -> patches): forward
   // with the hidden and the pre-LayerNorm rows saved 288.0 -> 269.8 us (253.7 -> 231.7 without dropout); inference form 191.5 -> 195.1 and
   // the backward 307.2 -> 313.5, so those keep the row pieces.  HFTT_MLP2_PATCH=0 / 1 forces either (A/B, tests).
   const char* e = getenv("HFTT_MLP2_PATCH");
   const bool stp = e ? (e[0] != '0') : (d.mode == 0 && (d.h_out != nullptr || d.pre_ln_out != nullptr));
-  if (!stp) return d.mode == 0 ? launch_mlp2<0, 1, false>(d, st) : launch_mlp2<1, 1, false>(d, st);
-  return d.mode == 0 ? launch_mlp2<0, 1, true>(d, st) : launch_mlp2<1, 1, true>(d, st);
+  if (!stp) return d.mode == 0 ? launch_mlp2<0, false>(d, st) : launch_mlp2<1, false>(d, st);
+  return d.mode == 0 ? launch_mlp2<0, true>(d, st) : launch_mlp2<1, true>(d, st);
 }

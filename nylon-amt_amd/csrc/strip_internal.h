@@ -4,9 +4,6 @@
 #include <hip/hip_runtime.h>
 #include "../../include/hftt_hip.h"
 int hftt_strip_linear2_try(const hftt_strip_desc& d, hipStream_t st);
-int hftt_strip_linear3_try(const hftt_strip_desc& d, hipStream_t st);      // strip_gemm3.hip: activations through LDS, split memory roles
-int hftt_strip_linear4_try(const hftt_strip_desc& d, hipStream_t st);      // strip_gemm4.hip: compute waves + mover waves
-int hftt_strip_linear5_try(const hftt_strip_desc& d, hipStream_t st);      // strip_gemm5.hip: two strips per wave, 128-column passes
 int hftt_strip_mlp2_try(const hftt_ffn_desc& d, hipStream_t st);
 // bs_strip.hip: the bf16 small-width family (K, N <= 192; fused block d = 64, p = 128): -1 = not one of its shapes / storages
 int hftt_bs_strip_linear_try(const hftt_strip_desc& d, hipStream_t st);

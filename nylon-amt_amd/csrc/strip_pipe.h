@@ -1,4 +1,4 @@
-// Helpers shared by the pipelined strip kernels (strip_gemm2.hip, strip_gemm3.hip): ring constants, static_for, LDS-DMA and store asm,
+// Helpers shared by the pipelined strip kernels (strip_gemm2.hip, bs_strip.hip): ring constants, static_for, LDS-DMA and store asm,
 // bf16 packing, the 16-element dropout, the slot's MFMA loops, the LayerNorm row pass.  Included inside an anonymous namespace.
 #pragma once
 constexpr int SLOT_BYTES = 16384;

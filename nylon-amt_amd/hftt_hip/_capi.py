@@ -9,9 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_NAME = 'libhftt_hip_x' if os.environ.get('HFTT_BUILD_EXPERIMENTS') == '1' else 'libhftt_hip'
-if os.environ.get('HFTT_BUILD_GRAD_HI') == '1':
-    _LIB_NAME += '_g' if _LIB_NAME == 'libhftt_hip' else 'g'
+_LIB_NAME = 'libhftt_hip_g' if os.environ.get('HFTT_BUILD_GRAD_HI') == '1' else 'libhftt_hip'
 LIB_PATH = os.environ.get('HFTT_LIB_PATH') or os.path.join(_HERE, '..', 'lib', _LIB_NAME + '.so')      # HFTT_LIB_PATH: dev builds (tools/ablate_strip.sh)
 
 c_f32p = C.c_void_p   # device pointers travel as plain integers

@@ -589,7 +589,8 @@ class HfttEngine:
         passes, kch = N // 256, K // 256
         v2 = (os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and x_bf and c_bf and K % 256 == 0 and M % 32 == 0 and not gate and (not residual or res_bf)
               and ((ln is not None and kch <= 3) or (ln is None and (kch, passes) in ((1, 1), (1, 2), (1, 3), (2, 1), (3, 1)))))
-        kname = ('strip_linear2_kernel<%s, %d, %d, %s>' % (tf(ln is not None), 1 if ln is not None else passes, kch, tf(bool(residual)))) if v2 \
+        kname = ('strip_linear2_kernel<%s, %d, %d, %s, %s>' % (tf(ln is not None), 1 if ln is not None else passes, kch, tf(bool(residual)),
+                                                                tf(os.environ.get('HFTT_LINEAR2_PATCH', '1')[:1] != '0'))) if v2 \
             else 'strip_linear_kernel<%s, %s, %s>' % (tf(x_bf), tf(c_bf), tf(ln is not None))
         if self.x3 and self.strip_small:
             kname = 'x3s_linear_kernel<%d, %d, %d, %s, %s>' % (4 if self._in_backward else 2, K // 32, N // 32, tf(ln is not None), tf(bool(residual)))
@@ -634,7 +635,12 @@ class HfttEngine:
         v2 = os.environ.get('HFTT_STRIP_V2', '1')[:1] != '0' and p == 512 and M % 32 == 0 and not (mode == 0 and residual)
         xname = ('x3s_mlp_kernel<%%d, %s>' % ('true' if self.hh else 'false')) if self.strip_small else \
             ('x3_mlp_kernel<%%d, 16, %s, %s>' % ('true' if self.hh else 'false', 'true' if (mode == 1 and self.g8) else 'false'))
-        meta = {'kernel': (xname if self.x3 else ('bs_mlp_kernel<%d>' if self.strip_small else ('strip_mlp2_kernel<%d, 16>' if v2 else 'strip_mlp_kernel<%d>'))) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
+        # (kernel symbols as rocprofv3 prints them -- tests/test_kernel_names_gpu.py holds every plan-meta name against a kernel trace.  The bf16 fused
+        # block takes its whole-line store path, the last template argument, for the training forward only: strip_gemm2.hip hftt_strip_mlp2_try)
+        stp = os.environ.get('HFTT_MLP2_PATCH')
+        stp = (stp[:1] != '0') if stp else (mode == 0 and bool(h_out or pre_saved))
+        bname = 'bs_mlp_kernel<%d>' if self.strip_small else (('strip_mlp2_kernel<%%d, 16, %s>' % ('true' if stp else 'false')) if v2 else 'strip_mlp_kernel<%d>')
+        meta = {'kernel': (xname if self.x3 else bname) % mode, 'flops': 4.0 * M * d * p, 'bytes': nbytes,
                 'shape': (M, d, p), 'saves': bool(h_out or pre_saved)}
         plan.append((self.lib.hftt_ffn_res_ln_fwd if mode == 0 else self.lib.hftt_ffn_bwd_dx, (C.byref(dsc),), 'ffn_fwd' if mode == 0 else 'ffn_bwd_dx', meta))
         return dsc

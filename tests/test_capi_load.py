@@ -95,3 +95,11 @@ def test_struct_layouts_match_the_c_compiler(lib, tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for f in cls._fields_:
             assert int(got['%s.%s' % (cname, f[0])]) == getattr(cls, f[0]).offset, (cname, f[0])
+
+
+def test_integration_stub_asserts_the_library_abi_version(lib):
+    """INTEGRATION.md's ctypes stub is what a maintainer pastes: its ABI assertion must be the loaded library's version (it said 4 at ABI 6)"""
+    txt = open(os.path.join(util.ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r'hftt_abi_version\(\)\s*==\s*(\d+)', txt)
+    assert m, 'the stub lost its ABI assertion'
+    assert int(m.group(1)) == lib.hftt_abi_version()

@@ -254,8 +254,7 @@ def test_pipelined_linear_is_bit_identical(dev, monkeypatch, M):
 @pytest.mark.parametrize('M', [128, 4096, 38432, 140032])
 def test_pipelined_ffn_is_bit_identical(dev, monkeypatch, M, patch):
     """the pipelined fused block (M = 140,032 = 1,094 blocks: a workgroup walks several) against the general form, bit for bit -- with its results
-    leaving as whole 128-byte lines through the wave-private LDS patches (round 5, the default) and as the round-2 row pieces (HFTT_MLP2_PATCH=0).
-    (The opt-in two-workgroups-per-CU register plan, HFTT_MLP2_WPC=2, is held by the fp64 tests only: DESIGN section 5, round 5.)"""
+    leaving as whole 128-byte lines through the wave-private LDS patches (round 5, the default) and as the round-2 row pieces (HFTT_MLP2_PATCH=0)."""
     monkeypatch.setenv('HFTT_MLP2_PATCH', patch)
     ops = _ops()
     g = torch.Generator().manual_seed(M + 1)
@@ -276,57 +275,6 @@ def test_pipelined_ffn_is_bit_identical(dev, monkeypatch, M, patch):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     a, b = _both_forms(monkeypatch, lambda: ops.ffn_bwd_dx(x, wfb, pf, hid, gate_scale=1.0))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# mover-wave form (csrc/strip_gemm4.hip, opt-in with HFTT_STRIP_V4=1): compute waves + mover waves, one barrier per ring slot.
-# Same operand order and epilogue arithmetic as the second form -> bit-identical, also on ragged last blocks and when a workgroup walks
-# several blocks (M = 70,016 = 547 blocks on 256 CUs).
-# ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.skipif(os.environ.get('HFTT_BUILD_EXPERIMENTS') != '1', reason='csrc/experiments/ is only in HFTT_BUILD_EXPERIMENTS=1 builds')
-@pytest.mark.parametrize('M', [128, 4096, 38432, 70016])
-def test_mover_wave_linear_is_bit_identical(dev, monkeypatch, M):
-    ops = _ops()
-    g = torch.Generator().manual_seed(M + 7)
-    for (N, K) in ((768, 256), (512, 256), (256, 256), (256, 512), (256, 768)):
-        x = torch.randn(M, K, generator=g).to(dev).to(BF)
-        W = (torch.randn(N, K, generator=g) / 16).to(dev); b = torch.randn(N, generator=g).to(dev)
-        w = ops.strip_pack(W)
-        for kw in ({}, {'relu': True, 'drop_p': 0.1, 'drop_site': 2, 'drop_seed': 5}):
-            monkeypatch.setenv('HFTT_STRIP_V4', '0')
-            _scrub_lds(dev)
-            a = ops.strip_linear(x, w, N, bias=b, **kw)
-            monkeypatch.setenv('HFTT_STRIP_V4', '1')
-            _scrub_lds(dev)
-            c = ops.strip_linear(x, w, N, bias=b, **kw)
-            torch.cuda.synchronize()
-            assert torch.equal(a, c), (N, K, kw)
-    monkeypatch.setenv('HFTT_STRIP_V4', '0')
-
-
-# two-strips-per-wave form (csrc/strip_gemm5.hip, opt-in with HFTT_STRIP_V5=1): 256-token blocks, 128-column passes, with / without residual
-@pytest.mark.skipif(os.environ.get('HFTT_BUILD_EXPERIMENTS') != '1', reason='csrc/experiments/ is only in HFTT_BUILD_EXPERIMENTS=1 builds')
-@pytest.mark.parametrize('M', [128, 4096, 38432, 70016])
-def test_two_strip_linear_is_bit_identical(dev, monkeypatch, M):
-    ops = _ops()
-    g = torch.Generator().manual_seed(M + 11)
-    for (N, K) in ((768, 256), (512, 256), (256, 256), (256, 512), (256, 768)):
-        x = torch.randn(M, K, generator=g).to(dev).to(BF)
-        W = (torch.randn(N, K, generator=g) / 16).to(dev); b = torch.randn(N, generator=g).to(dev)
-        res = torch.randn(M, N, generator=g).to(dev).to(BF)
-        w = ops.strip_pack(W)
-        for kw in ({}, {'relu': True, 'drop_p': 0.1, 'drop_site': 2, 'drop_seed': 5}, {'residual': res}, {'residual': res, 'drop_p': 0.1, 'drop_site': 1, 'drop_seed': 9}):
-            if 'residual' in kw and N != 256:
-                continue                              # (the model's residual forms are the dX projections, N = 256)
-            monkeypatch.setenv('HFTT_STRIP_V5', '0')
-            _scrub_lds(dev)
-            a = ops.strip_linear(x, w, N, bias=b, **kw)
-            monkeypatch.setenv('HFTT_STRIP_V5', '1')
-            _scrub_lds(dev)
-            c = ops.strip_linear(x, w, N, bias=b, **kw)
-            torch.cuda.synchronize()
-            assert torch.equal(a, c), (N, K, sorted(kw))
-    monkeypatch.setenv('HFTT_STRIP_V5', '0')
 
 
 # ---------------------------------------------------------------------------------------------------------------------
