@@ -27,6 +27,14 @@ if os.environ.get('HFTT_BUILD_GRAD_HI') == '1':
     LIB = os.path.join(LIBDIR, 'libhftt_hip_g.so')
 
 
+# HFTT_BUILD_TAG=<tag> HFTT_BUILD_EXTRA_FLAGS="...": a side-by-side build for same-box A/B runs (objects *.<tag>.o, library libhftt_hip_<tag>.so,
+# selected at run time with HFTT_LIB_PATH); the product library is never touched by it
+_TAG = os.environ.get('HFTT_BUILD_TAG', '')
+if _TAG:
+    FLAGS += os.environ.get('HFTT_BUILD_EXTRA_FLAGS', '').split()
+    LIB = os.path.join(LIBDIR, 'libhftt_hip_%s.so' % _TAG)
+
+
 def _hipcc():
     for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -42,7 +50,7 @@ def _stale(target, deps):
 
 
 def _compile(src):
-    obj = os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + (('.g' if 'HFTT_GRAD_HI_BUILD' in ' '.join(FLAGS) else '') + '.o'))
+    obj = os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + (('.g' if 'HFTT_GRAD_HI_BUILD' in ' '.join(FLAGS) else '') + (('.' + _TAG) if _TAG else '') + '.o'))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
         cmd = [_hipcc()] + FLAGS + ['-x', 'hip', '-c', path, '-o', obj]

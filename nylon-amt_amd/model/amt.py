@@ -25,10 +25,18 @@ from hftt_hip._capi import HfttError   # noqa: E402
 
 
 class AMT():
-    def __init__(self, config, model_path, batch_size=1, verbose_flag=False, rank=None, world=None, device=None):
+    def __init__(self, config, model_path, batch_size=1, verbose_flag=False, rank=None, world=None, device=None, gather='host'):
         """rank / world (default: those of torch.distributed when it is initialised, else 0 / 1): the clip batches of a file are dealt
-        to the ranks round-robin, each rank runs its share on ITS GPU and the results are all-gathered, so every rank returns the whole
-        transcription (the reference runs one clip at a time on one device, amt.py:88)."""
+        to the ranks round-robin and each rank runs its share on ITS GPU -- replicas only, NO collective on the data path (the reference
+        runs one clip at a time on one device, amt.py:88).  gather='host' (default): every rank copies its own results to the host and
+        rank 0 collects them by clip index through a host (gloo) channel, so RANK 0 returns the whole transcription (amt.py:104-113
+        stitching order) and writes the files; the other ranks return arrays in which only their own clips are filled.  gather='all': the
+        round-1..5 behaviour, an all_gather that leaves the whole result on every rank (only sensible for a few clips).  gather='none':
+        no exchange at all (every rank keeps its shard; for callers that shard by FILE with hftt_hip.ddp.shard_indices)."""
+        if gather not in ('host', 'all', 'none'):
+            raise HfttError("gather must be 'host', 'all' or 'none'")
+        self.gather = gather
+        self._host_group = None
         if verbose_flag is True:
             print('torch version: ' + torch.__version__)
             print('torch cuda   : ' + str(torch.cuda.is_available()))
@@ -105,13 +113,38 @@ class AMT():
         return self._collect(parts, batches, mine)
 
     def _collect(self, parts, batches, mine):
-        """per-rank device results -> 8 numpy arrays [n_clips, num_frame, num_note] in clip order, on every rank"""
+        """per-rank device results -> 8 numpy arrays [n_clips, num_frame, num_note] in clip order (complete on rank 0; see __init__: gather)"""
         cin, cm = self.config['input'], self.config['midi']
         T, N = cin['num_frame'], cm['num_note']
         n_clips = sum(len(b) for b in batches)
         if self.world == 1:
             return [torch.cat(l, dim=0).to('cpu').numpy() for l in parts]
         import torch.distributed as dist
+        if self.gather != 'all':
+            # replicas only: each rank's results go to ITS host; rank 0 collects the shards by clip index over a host channel (gloo),
+            # never over RCCL -- no device collective anywhere on the inference path (SURVEY.md section 8(e))
+            my_clips = [i for bi in mine for i in range(bi * self.batch_size, bi * self.batch_size + len(batches[bi]))]
+            local = [torch.cat(l, dim=0).to('cpu').numpy() if l else np.zeros((0, T, N), np.int64 if k % 4 == 3 else np.float32) for k, l in enumerate(parts)]
+            shards = [(my_clips, local)]
+            if self.gather == 'host':
+                if dist.get_backend() == 'gloo':
+                    grp = None
+                else:
+                    if self._host_group is None:
+                        self._host_group = dist.new_group(backend='gloo')      # (collective over all ranks: every rank of the job runs the same AMT calls)
+                    grp = self._host_group
+                got = [None] * self.world if self.rank == 0 else None
+                dist.gather_object((my_clips, local), got, dst=0, group=grp)
+                if self.rank == 0:
+                    shards = got
+            res = []
+            for k in range(8):
+                full = np.zeros((n_clips, T, N), np.int64 if k % 4 == 3 else np.float32)
+                for clips, arrs in shards:
+                    if len(clips):
+                        full[np.asarray(clips)] = arrs[k]
+                res.append(full)
+            return res
         gdev = 'cpu' if dist.get_backend() == 'gloo' else self.device          # gloo moves host memory; RCCL ('nccl') device memory
         per = -(-len(batches) // self.world) * self.batch_size                # clips per rank, padded: equal-sized all_gather
         res = []

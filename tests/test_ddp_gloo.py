@@ -100,9 +100,10 @@ def _amt_worker(rank, world, port, tmp):
     from hftt_hip import ddp
     g = util.golden('amt')
     assert ddp.rank_world() == (rank, world) and ddp.is_main() == (rank == 0)
-    for bs in (1, 3):
-        amt = AMT(H.CFG, None, batch_size=bs, device='cpu')        # rank / world picked up from torch.distributed
+    for bs, gather in ((1, 'host'), (3, 'host'), (3, 'all'), (3, 'none')):
+        amt = AMT(H.CFG, None, batch_size=bs, device='cpu', gather=gather)        # rank / world picked up from torch.distributed
         assert (amt.rank, amt.world) == (rank, world)
+        T = H.CFG['input']['num_frame']
         calls = []
         echo = H.EchoModel(H.CFG)
         amt.model = type('Counting', (), {'eval': lambda s: s, '__call__': lambda s, x: (calls.append(x.shape[0]), echo(x))[1]})()
@@ -113,12 +114,23 @@ def _amt_worker(rank, world, port, tmp):
             n_clips = -(-n // 8)
             n_batches = -(-n_clips // bs)
             assert len(calls) == len(range(rank, n_batches, world))      # this rank ran only its share of the batches ...
-            for i, o in enumerate(outs):                                  # ... and holds the whole file's result, equal to the reference's
+            # ... rank 0 (gather='host': the default, a host-side gather by clip index; 'all': every rank) holds the whole file's result, equal
+            # to the reference's; the other ranks hold their own clips (replicas only: no collective on the data path)
+            whole = gather == 'all' or (gather == 'host' and rank == 0)
+            mine = np.zeros(n_clips * T, bool)
+            for bi in range(rank, n_batches, world):
+                mine[bi * bs * T:min((bi + 1) * bs, n_clips) * T] = True
+            for i, o in enumerate(outs):
                 ref = g[f'tr.{n}.out{i}']
                 assert o.dtype == ref.dtype and o.shape == ref.shape
-                np.testing.assert_array_equal(o, ref)
+                if whole:
+                    np.testing.assert_array_equal(o, ref)
+                else:
+                    np.testing.assert_array_equal(o[mine[:len(o)]], ref[mine[:len(o)]])
+                    assert not o[~mine[:len(o)]].any()
             for i, o in enumerate(amt.transcript_stride(feat, 2)):
-                np.testing.assert_array_equal(o, g[f'trs.{n}.2.out{i}'])
+                if whole:
+                    np.testing.assert_array_equal(o, g[f'trs.{n}.2.out{i}'])
     # clip sharding: disjoint, equal-sized, covering all but the n % world tail
     ids = [ddp.shard_indices(11, r, world) for r in range(world)]
     assert ids == [[0, 2, 4, 6, 8], [1, 3, 5, 7, 9]] and ddp.shard_indices(11) == ids[rank]
