@@ -25,7 +25,7 @@ def test_constructor_signatures_match_the_reference():
     assert sig(M.PositionwiseFeedforwardLayer.__init__) == ['hid_dim', 'pf_dim', 'dropout']
     from model.amt import AMT
     assert sig(AMT.__init__)[:4] == ['config', 'model_path', 'batch_size', 'verbose_flag']       # the reference's four, positional order kept
-    assert sig(AMT.__init__)[4:] == ['rank', 'world', 'device']                                     # keyword additions of the multi-GPU scatter (all default None)
+    assert sig(AMT.__init__)[4:] == ['rank', 'world', 'device', 'gather']                           # keyword additions of the multi-GPU scatter (defaults: None, None, None, 'host')
     assert sig(AMT.transcript) == ['a_feature', 'mode', 'ablation_flag']
     assert sig(AMT.transcript_stride) == ['a_feature', 'n_offset', 'mode', 'ablation_flag']
     assert sig(AMT.mpe2note) == ['a_onset', 'a_offset', 'a_mpe', 'a_velocity', 'thred_onset', 'thred_offset', 'thred_mpe',
