@@ -38,6 +38,10 @@ int hftt_abi_version(void);
  * HFTT_BUILD_GRAD_HI=1 (nylon-amt_amd/build.py); the default library rejects those flags. */
 int hftt_build_options(void);
 const char* hftt_last_error(void);
+/* ONE PROCESS DRIVES ONE DEVICE (one process per GPU, as torch.distributed launches them): the launchers keep per-kernel state -- dynamic-LDS
+ * attributes, the CU count, the resident-workgroup grids of the persistent kernels -- in process-wide caches made for the device of the
+ * first launch.  A launch from the same process with another device current returns 3 with a message instead of running with the first
+ * device's cached state.  Every entry point may be called from any host thread; launches go to the stream that is passed in. */
 /* number of compute units of the current device (for workspace sizing on the host side) */
 int hftt_device_cus(void);
 
@@ -438,7 +442,9 @@ int hftt_logmel(const hftt_logmel_desc* d, void* stream);
  * sr_out), down = sr_in / g, up = sr_out / g, width = ceil(6 * down / (min(down, up) * 0.99)): the host builds the kernel table
  * kernel[up, taps], taps = 2 * width + down (row p = the windowed sinc sampled for output phase p), and
  *     out[f * up + p] = sum_t wave[f * down - width + t] * kernel[p, t]          (samples outside [0, n_in) are zeros)
- * for the first n_out = ceil(n_in * up / down) outputs.  fp32 accumulate in tap order.
+ * for the first n_out = ceil(n_in * up / down) outputs.  fp32 accumulate, four interleaved partial sums over the taps (t mod 4), added at the end.
+ * The input window of 256 consecutive outputs, (255 / up + 1) * down + taps samples, is staged in LDS: it must fit 64 KB (it does for every
+ * audio rate down to 16 kHz from <= 768 kHz).
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
   const float* wave; int64_t n_in;

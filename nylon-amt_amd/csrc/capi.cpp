@@ -1,6 +1,7 @@
 // C ABI plumbing: version, thread-local error string, device query.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <atomic>
 #include <stdio.h>
 #include "../../include/hftt_hip.h"
 #include "hftt_host.h"
@@ -12,6 +13,17 @@ void hftt_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int hftt_device_guard(const char* what) {
+  static std::atomic<int> first{-1};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;      // (the launch check in front of this has already reported a broken runtime)
+  int seen = -1;
+  if (first.compare_exchange_strong(seen, dev) || seen == dev) return 0;
+  hftt_set_error("%s: this process launched on device %d before and is now on device %d -- one process drives one device (the launch "
+                 "caches of libhftt_hip.so are per process: LDS attributes, CU count, resident-workgroup grids); start one process per GPU", what, seen, dev);
+  return 3;
 }
 
 extern "C" int hftt_abi_version(void) { return HFTT_ABI_VERSION; }

@@ -61,6 +61,8 @@ class _Flat:
 
 
 class HfttEngine:
+    _dropout_notice_given = False
+
     def __init__(self, cfg, device, precision='parity', dropout=0.0, seed=1234):
         """cfg: dict with n_margin,n_frame,n_bin,cnn_channel,cnn_kernel,hid_dim,pf_dim,enc_layer,dec_layer,
         enc_head,dec_head,n_note,n_velocity (the constructor arguments of the reference classes)."""
@@ -94,6 +96,16 @@ class HfttEngine:
         self.planes_opt = os.environ.get('HFTT_X3_PLANES', '1') != '0'      # x3 strip plans: q / k / v between projection and attention as f16-pair planes
         self.set_precision(precision)
         self.dropout = float(dropout)
+        # The device generator decides per element with ONE byte of a hash word (csrc/hftt_common.h: hftt_keep_thr), so the keep probability is
+        # quantised to 1/256: `-dropout 0.1` of m_training.py is applied as 26/256 = 0.1016 (kept elements are scaled by 256/230, the reciprocal of
+        # the probability actually applied: E[dropout(x)] = x).  Not silent: the applied rate is an attribute and a one-time notice.
+        self.dropout_applied = (1.0 - 1.0 / keep_scale(self.dropout)) if self.dropout > 0.0 else 0.0
+        if self.dropout > 0.0 and abs(self.dropout_applied - self.dropout) > 1e-6 and not HfttEngine._dropout_notice_given:
+            HfttEngine._dropout_notice_given = True
+            import warnings
+            warnings.warn('hftt_hip: dropout p = %g is applied as %d/256 = %.4f (8-bit keep decisions of the device generator; kept elements are '
+                          'scaled by the reciprocal of the applied keep probability, so the expectation is unchanged)'
+                          % (self.dropout, round(self.dropout_applied * 256), self.dropout_applied), stacklevel=2)
         self.base_seed = int(seed)
         self.step_counter = 0
         self.generation = 0
