@@ -51,21 +51,42 @@ def frame_metrics(ref_roll, est_roll, threshold=None):
 
 
 def _max_matching(adj, n_right):
-    """Size and pairs of a maximum bipartite matching; adj[i] = list of right vertices reachable from left vertex i."""
+    """Size and pairs of a maximum bipartite matching; adj[i] = list of right vertices reachable from left vertex i.
+    Kuhn's augmenting paths with an explicit stack (the recursive form used one Python frame per hop of a path: dense label sets could
+    exceed the interpreter's recursion limit -- ADVICE r05); vertices are tried in the same order, so the matching is the same."""
     match_r = {}
-
-    def try_left(i, seen):
-        for j in adj[i]:
-            if j not in seen:
-                seen.add(j)
-                if j not in match_r or try_left(match_r[j], seen):
-                    match_r[j] = i
-                    return True
-        return False
-
     size = 0
-    for i in range(len(adj)):
-        if adj[i] and try_left(i, set()):
+    for root in range(len(adj)):
+        if not adj[root]:
+            continue
+        seen = set()
+        stack = [(root, iter(adj[root]))]           # the alternating path being grown: (left vertex, its untried right neighbours)
+        via = []                                    # via[d] = the right vertex through which stack[d + 1] was entered
+        found = False
+        while stack:
+            i, it = stack[-1]
+            advanced = False
+            for j in it:
+                if j in seen:
+                    continue
+                seen.add(j)
+                if j not in match_r:                # free right vertex: flip the whole path
+                    via.append(j)
+                    for d in range(len(stack)):
+                        match_r[via[d]] = stack[d][0]
+                    found = True
+                    break
+                via.append(j)
+                stack.append((match_r[j], iter(adj[match_r[j]])))
+                advanced = True
+                break
+            if found:
+                break
+            if not advanced:
+                stack.pop()
+                if via:
+                    via.pop()
+        if found:
             size += 1
     return size, [(match_r[j], j) for j in sorted(match_r)]
 
