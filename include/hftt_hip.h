@@ -193,7 +193,9 @@ int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_p
  * with bf16 halves (hftt_x3_strip_pack element type 4), of which these kernels read the hi fragment; one MFMA pass; every tensor bf16, statistics
  * fp32; results leave as whole 128-byte lines. */
 /* HFTT_SL_X3_F16 without LayerNorm, K == 256 (the output-tile-major kernel): C is written as f16-pair planes per 32-column group (see
- * HFTT_ATTN_Q_F16PAIR) -- the q / k / v projections of the attention layers (model_spec2midi.py:328-330) */
+ * HFTT_ATTN_Q_F16PAIR) -- the q / k / v projections of the attention layers (model_spec2midi.py:328-330).  N = 256, 512, 768 and, since
+ * round 6, 1024 / 1536: the cross-attention K / V projections of two / three decoder layers stacked along N (they share their input, the
+ * encoder output: model_spec2midi.py:259,296), one launch that reads it once. */
 #define HFTT_SL_C_F16PAIR 512u
 /* C[M,N] = epi(x[M,K] . Wl[N,K]^T + bias): same epilogue order as hftt_gemm_nt (relu, out_scale, gate, dropout, residual,
  * LayerNorm over N == 256).  N % 256 == 0; K % 32 == 0 and (K <= 256 or K % 256 == 0); gate is bf16. */

@@ -1260,7 +1260,11 @@ int dispatch_xl(const hftt_strip_desc& d, hipStream_t st) {
     if (d.flags & HFTT_SL_C_F16PAIR) {                // (validated by the caller: no LayerNorm, no residual, K == 256)
       if (passes == 1) return launch_xn<E, 8, false, true>(d, st);
       if (passes == 2) return launch_xn<E, 16, false, true>(d, st);
-      return launch_xn<E, 24, false, true>(d, st);
+      if (passes == 3) return launch_xn<E, 24, false, true>(d, st);
+      if (passes == 4) return launch_xn<E, 32, false, true>(d, st);      // the cross-attention K / V of two / three decoder layers in one launch
+      if (passes == 6) return launch_xn<E, 48, false, true>(d, st);
+      hftt_set_error("x3_strip_linear: the plane form covers N = 256, 512, 768, 1024, 1536 (got %d)", d.N);
+      return 1;
     }
   }
   // K == 256 without LayerNorm: the output-tile-major kernel (tile-major pack, two workgroups per CU)
@@ -1297,8 +1301,8 @@ int hftt_x3_strip_linear(const hftt_strip_desc& d0, hipStream_t st) {
   HFTT_REQUIRE(d.ldx % 4 == 0 && d.ldc % 4 == 0 && (d.residual == nullptr || d.ldr % 4 == 0), "x3_strip_linear: rows must be 16-byte aligned");
   HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_GRAD_HI) || (d.flags & HFTT_SL_X3_BF16), "x3_strip_linear: HFTT_SL_X3_GRAD_HI goes with HFTT_SL_X3_BF16");
   if (d.flags & HFTT_SL_C_F16PAIR) {
-    HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_BF16) && d.K == 256 && d.N <= 768 && d.ln_gamma == nullptr && d.residual == nullptr && !(d.flags & HFTT_SL_RELU) && !(d.drop_p > 0.f),
-                 "x3_strip_linear: HFTT_SL_C_F16PAIR is the plain forward projection (HFTT_SL_X3_F16, K == 256, N <= 768, no LayerNorm / residual / ReLU / dropout)");
+    HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_BF16) && d.K == 256 && d.N <= 1536 && d.ln_gamma == nullptr && d.residual == nullptr && !(d.flags & HFTT_SL_RELU) && !(d.drop_p > 0.f),
+                 "x3_strip_linear: HFTT_SL_C_F16PAIR is the plain forward projection (HFTT_SL_X3_F16, K == 256, N <= 1536, no LayerNorm / residual / ReLU / dropout)");
     HFTT_REQUIRE(((uintptr_t)d.C & 15) == 0, "x3_strip_linear: C must be 16-byte aligned");
   }
 #ifdef HFTT_GRAD_HI_BUILD

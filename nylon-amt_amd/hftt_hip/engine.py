@@ -94,6 +94,9 @@ class HfttEngine:
         self.store_bf16_opt = os.environ.get('HFTT_BF16_STORE', '1') != '0'
         self.strip_opt = os.environ.get('HFTT_STRIP', '1') != '0'
         self.planes_opt = os.environ.get('HFTT_X3_PLANES', '1') != '0'      # x3 strip plans: q / k / v between projection and attention as f16-pair planes
+        # x3 strip plans: the cross-attention K / V projections of ALL decoder layers (the same input: the encoder output, model_spec2midi.py:259,296)
+        # as ONE launch with N = Ld * 2d instead of Ld launches that each re-read the encoder output
+        self.merge_ckv_opt = os.environ.get('HFTT_X3_MERGE_CKV', '1') != '0'
         self.set_precision(precision)
         self.dropout = float(dropout)
         # The device generator decides per element with ONE byte of a hash word (csrc/hftt_common.h: hftt_keep_thr), so the keep probability is
@@ -328,7 +331,8 @@ class HfttEngine:
             tm = 1 if x3 else 0                       # x3: the K == 256 linears without LayerNorm take the tile-major pack (csrc/x3_strip.hip)
             if cross:
                 spack(key + '.q', [(wq, 0, 0)], d, order=tm, numel=d * d)
-                spack(key + '.kv', [(wk, 0, 0), (wv, d, 0)], d, order=tm, numel=2 * d * d)
+                if not getattr(self, 'merge_ckv', False):   # (merged: one stream for all layers, 'dec.ca.kv_all' below)
+                    spack(key + '.kv', [(wk, 0, 0), (wv, d, 0)], d, order=tm, numel=2 * d * d)
                 spack(key + '.q_t', [(wq, 0, 0)], d, transpose=True, order=tm, numel=d * d)
                 spack(key + '.kv_t', [(wk, 0, 0), (wv, 0, d)], 2 * d, transpose=True, numel=2 * d * d)
             else:
@@ -347,6 +351,7 @@ class HfttEngine:
             base = spack(key + '.ffn_t', [(w2, 0, 0)], d, transpose=True, order=1, stride=2, offset=0, numel=2 * d * p)
             spack(key + '.ffn_t', [(w1, 0, 0)], p, transpose=True, order=0, stride=2, offset=1, base=base)
 
+        self.merge_ckv = bool(self.strip and x3 and not self.strip_small and self.merge_ckv_opt and self.Ld in (2, 3) and self._planes(self.Hd, self.N, self.F))
         W['embed'] = wl.add('embed', _align(d, 64) * self.Kp, 64)
         W['embed_b'] = fl.add('embed_b', d, 8)
         blocks = []                                  # (prefix, key, has self attention, has cross attention)
@@ -372,6 +377,13 @@ class HfttEngine:
                     strip_attn(pre + 'encoder_attention.', key + '.ca', True)
                 strip_ffn(pre + 'positionwise_feedforward.', key)
         heads('time', 'heads_t')
+        if self.merge_ckv:
+            cross = [('decoder_spec2midi.layer_zero_freq.' if j == 0 else f'decoder_spec2midi.layers_freq.{j - 1}.') + 'encoder_attention.' for j in range(self.Ld)]
+            parts = []
+            for j, pre in enumerate(cross):
+                parts += [(pre + 'fc_k.weight', 2 * j * d, 0), (pre + 'fc_v.weight', (2 * j + 1) * d, 0)]
+            spack('dec.ca.kv_all', parts, d, order=1, numel=self.Ld * 2 * d * d)
+            W['dec.ca.kv_all_b'] = vec('dec.ca.kv_all_b', [pre + n + '.bias' for pre in cross for n in ('fc_k', 'fc_v')], d)
         if self.bfs:                                 # bf16 copy of the note position table: the (broadcast) residual of decoder layer zero
             off = wl.add('dec_pos_bf', self.N * d, 64)
             W['dec_pos_bf'] = off
@@ -937,7 +949,14 @@ class HfttEngine:
                     plan.append((self.lib.hftt_x3_to_planes, (q0.data_ptr(), d, q0p.data_ptr(), d, N, d), 'x3_to_planes', None))
                     qaddr = q0p.data_ptr()
                 res, res_mod = (self.wbf.data_ptr() + 2 * self.Woff['dec_pos_bf'] if bs else pos_dec), N
-            ckv = self._buf(ws, tag + '.ckv', Se, 2 * d, half=True)
+            merged = st and getattr(self, 'merge_ckv', False)
+            ldkv = (self.Ld if merged else 1) * 2 * d
+            if merged:
+                ckv = self._buf(ws, 'dec.ckv_all', Se, ldkv)
+                if j == 0:                            # one projection for every layer's K / V (the layers' column blocks of one [Se, Ld * 2d] plane tensor)
+                    self._sl(plan, ws, Se, ldkv, d, enc, d, 'dec.ca.kv_all', self.Fp('dec.ca.kv_all_b'), ckv.data_ptr(), ldkv, c_planes=True)
+            else:
+                ckv = self._buf(ws, tag + '.ckv', Se, 2 * d, half=True)
             cctx = self._buf(ws, tag + '.cctx', Sn, d, half=True)
             clse = self._buf(ws, tag + '.clse', BT * H * N * 2)
             cr = self._pbuf(ws, tag + '.cr', Sn, d); cx = self._abuf(ws, tag + '.cx', Sn, d)
@@ -945,12 +964,15 @@ class HfttEngine:
             c_a, c_o = self._new_site(), self._new_site()
             sites['cross'] = (c_a, c_o)
             plc = st and self._planes(H, N, F)
-            if st:
+            if merged:
+                pass
+            elif st:
                 self._sl(plan, ws, Se, 2 * d, d, enc, d, tag + '.ca.kv', self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d, c_planes=plc)
             else:
                 self._nt(plan, ws, Se, 2 * d, d, enc, d, self.Wp(tag + '.ca.kv'), self.Fp(tag + '.ca.kv_b'), ckv.data_ptr(), 2 * d, c_bf=True)
-            kk = ckv.data_ptr()
-            ad = self._attn(plan, ws, False, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
+            kk = ckv.data_ptr() + (j * 2 * d * hz if merged else 0)
+            ws.setdefault('ckv_at', {})[tag] = (kk, ldkv)
+            ad = self._attn(plan, ws, False, BT, H, N, F, qaddr, qss, d, kk, F * ldkv, ldkv, kk + hz * d, F * ldkv, ldkv,
                             cctx.data_ptr(), N * d, d, clse.data_ptr(), drop_site=c_a, flags=1 | 2 | 4, planes=plc, map_out=(j == self.Ld - 1))
             if j == self.Ld - 1:
                 ws.setdefault('attn_out_descs', []).append(ad)
@@ -1180,7 +1202,7 @@ class HfttEngine:
                 self._sl(plan, ws, Sn, d, d, dbr, d, tag + '.ca.o_t', 0, nGx, d)
             else:
                 self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.ca.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
-            kk = b[tag + '.ckv'].data_ptr()
+            kk, ldkv = ws['ckv_at'][tag]
             plc = st and self._planes(H, N, F)
             if j > 0:
                 qaddr, qss = b[tag + '.cq'].data_ptr(), N * d
@@ -1190,7 +1212,7 @@ class HfttEngine:
             # per-sequence dq stays fp32 (layer zero sums it over sequences with the fp32 colsum); dk, dv are "half" tensors
             # strip mode: dq of the layers with their own query projection is a GEMM operand only -> bf16; layer zero keeps fp32 (q1f)
             dq_buf = Q1 if not bs else (Q1 if j > 0 else q1f)
-            self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * 2 * d, 2 * d, kk + hz * d, F * 2 * d, 2 * d,
+            self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * ldkv, ldkv, kk + hz * d, F * ldkv, ldkv,
                        b[tag + '.cctx'].data_ptr(), N * d, d, b[tag + '.clse'].data_ptr(), drop_site=c_a, dout=nGx,
                        dq=dq_buf, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + hz * d, dvss=F * 2 * d, lddv=2 * d,
                        flags=1 | 2 | 4 | 16 | (8 if (st and j > 0) else 0), planes=plc)
