@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HFTT_ABI_VERSION 6
+#define HFTT_ABI_VERSION 7
 
 int hftt_abi_version(void);
 /* bit 0: the library carries the opt-in gradient-rounding forms (HFTT_SL_X3_GRAD_HI, HFTT_TN_DY_HI, HFTT_NT_A_HI: a gradient operand enters a
@@ -243,7 +243,7 @@ int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream);       /* mode 1 */
  * TN GEMM (weight gradient):  dW[N,K] = out_scale * dY[M,N]^T . X[M,K],  db[N] = colsum(dY)
  * Replaces the weight/bias gradient of every nn.Linear in loss.backward() (training/train.py:158).
  * Two launches: partial products per M-split into `ws`, then a reduce that writes (beta=0) or
- * accumulates (beta=1) into up to 4 row segments of the destination (fused QKV / packed heads).
+ * accumulates (beta=1) into up to 8 row segments of the destination (fused QKV / packed heads / stacked cross-attention K, V).
  * --------------------------------------------------------------------------------------------- */
 #define HFTT_TN_DY_BF16 1u
 #define HFTT_TN_X_BF16 2u
@@ -253,10 +253,10 @@ typedef struct {
   const float* dY; int64_t lddy;
   const float* X; int64_t ldx;
   float out_scale; float beta;
-  int32_t n_seg;
-  int32_t seg_row0[4]; int32_t seg_rows[4];
-  float* seg_dw[4];          /* [seg_rows, K] row-major (ld = K_out) */
-  float* seg_db[4];          /* [seg_rows] or NULL */
+  int32_t n_seg;             /* 1 .. 8 (ABI v7; 4 before: the cross-attention K / V gradients of three decoder layers are six segments of one product) */
+  int32_t seg_row0[8]; int32_t seg_rows[8];
+  float* seg_dw[8];          /* [seg_rows, K] row-major (ld = K_out) */
+  float* seg_db[8];          /* [seg_rows] or NULL */
   int32_t K_out;             /* number of K columns to write (<= K), destination leading dim */
   uint32_t io_flags;         /* HFTT_TN_*: npass 1 (either / both), npass 4 (ONE of them: that operand is its own hi half, two MFMA passes) */
   void* ws; int64_t ws_bytes;

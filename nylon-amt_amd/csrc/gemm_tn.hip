@@ -519,7 +519,7 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
   HFTT_REQUIRE(d->io_flags == 0 || d->npass == 1 || (d->npass == 4 && (d->io_flags & 3u) != (HFTT_TN_DY_BF16 | HFTT_TN_X_BF16)),
                "gemm_tn: bf16-stored operands need npass == 1, or npass == 4 with ONE of them");
   HFTT_REQUIRE(!(d->io_flags & HFTT_TN_DY_HI) || d->npass == 4, "gemm_tn: HFTT_TN_DY_HI goes with npass == 4");
-  HFTT_REQUIRE(d->n_seg >= 1 && d->n_seg <= 4, "gemm_tn: n_seg must be 1..4");
+  HFTT_REQUIRE(d->n_seg >= 1 && d->n_seg <= 8, "gemm_tn: n_seg must be 1..8");
   HFTT_REQUIRE(d->K_out > 0 && d->K_out <= d->K, "gemm_tn: K_out out of range");
   for (int s = 0; s < d->n_seg; s++) {
     HFTT_REQUIRE(d->seg_dw[s] != nullptr, "gemm_tn: null segment pointer");

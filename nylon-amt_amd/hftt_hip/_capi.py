@@ -43,8 +43,8 @@ class GemmTnDesc(C.Structure):
                 ('X', c_f32p), ('ldx', C.c_int64),
                 ('out_scale', C.c_float), ('beta', C.c_float),
                 ('n_seg', C.c_int32),
-                ('seg_row0', C.c_int32 * 4), ('seg_rows', C.c_int32 * 4),
-                ('seg_dw', c_f32p * 4), ('seg_db', c_f32p * 4),
+                ('seg_row0', C.c_int32 * 8), ('seg_rows', C.c_int32 * 8),
+                ('seg_dw', c_f32p * 8), ('seg_db', c_f32p * 8),
                 ('K_out', C.c_int32), ('io_flags', C.c_uint32),
                 ('ws', C.c_void_p), ('ws_bytes', C.c_int64)]
 
@@ -193,7 +193,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HfttError(RuntimeError):

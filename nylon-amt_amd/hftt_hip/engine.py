@@ -334,7 +334,8 @@ class HfttEngine:
                 if not getattr(self, 'merge_ckv', False):   # (merged: one stream for all layers, 'dec.ca.kv_all' below)
                     spack(key + '.kv', [(wk, 0, 0), (wv, d, 0)], d, order=tm, numel=2 * d * d)
                 spack(key + '.q_t', [(wq, 0, 0)], d, transpose=True, order=tm, numel=d * d)
-                spack(key + '.kv_t', [(wk, 0, 0), (wv, 0, d)], 2 * d, transpose=True, numel=2 * d * d)
+                if not getattr(self, 'merge_ckv_bwd', False):      # (merged backward: 'dec.ca.kv_all_t0/1' below)
+                    spack(key + '.kv_t', [(wk, 0, 0), (wv, 0, d)], 2 * d, transpose=True, numel=2 * d * d)
             else:
                 spack(key + '.qkv', [(wq, 0, 0), (wk, d, 0), (wv, 2 * d, 0)], d, order=tm, numel=3 * d * d)
                 spack(key + '.qkv_t', [(wq, 0, 0), (wk, 0, d), (wv, 0, 2 * d)], 3 * d, transpose=True, numel=3 * d * d)
@@ -352,6 +353,8 @@ class HfttEngine:
             spack(key + '.ffn_t', [(w1, 0, 0)], p, transpose=True, order=0, stride=2, offset=1, base=base)
 
         self.merge_ckv = bool(self.strip and x3 and not self.strip_small and self.merge_ckv_opt and self.Ld in (2, 3) and self._planes(self.Hd, self.N, self.F))
+        # ... and their backward (three layers): one weight-gradient product with six segments, the encoder-output gradient as two K = 768 halves
+        self.merge_ckv_bwd = self.merge_ckv and self.Ld == 3 and os.environ.get('HFTT_X3_MERGE_CKV_BWD', '1') != '0'
         W['embed'] = wl.add('embed', _align(d, 64) * self.Kp, 64)
         W['embed_b'] = fl.add('embed_b', d, 8)
         blocks = []                                  # (prefix, key, has self attention, has cross attention)
@@ -383,6 +386,10 @@ class HfttEngine:
             for j, pre in enumerate(cross):
                 parts += [(pre + 'fc_k.weight', 2 * j * d, 0), (pre + 'fc_v.weight', (2 * j + 1) * d, 0)]
             spack('dec.ca.kv_all', parts, d, order=1, numel=self.Ld * 2 * d * d)
+            if self.merge_ckv_bwd:                       # backward: dX of the stacked projection as two K = 768 halves of the [d, 6d] transposed matrix
+                names = [pre + n + '.weight' for pre in cross for n in ('fc_k', 'fc_v')]
+                for half in range(2):
+                    spack('dec.ca.kv_all_t%d' % half, [(names[3 * half + i], 0, i * d) for i in range(3)], 3 * d, transpose=True, numel=3 * d * d)
             W['dec.ca.kv_all_b'] = vec('dec.ca.kv_all_b', [pre + n + '.bias' for pre in cross for n in ('fc_k', 'fc_v')], d)
         if self.bfs:                                 # bf16 copy of the note position table: the (broadcast) residual of decoder layer zero
             off = wl.add('dec_pos_bf', self.N * d, 64)
@@ -1212,13 +1219,36 @@ class HfttEngine:
             # per-sequence dq stays fp32 (layer zero sums it over sequences with the fp32 colsum); dk, dv are "half" tensors
             # strip mode: dq of the layers with their own query projection is a GEMM operand only -> bf16; layer zero keeps fp32 (q1f)
             dq_buf = Q1 if not bs else (Q1 if j > 0 else q1f)
+            # merged (x3 strip plans, three decoder layers): dk / dv of every layer go into the column blocks of ONE [Se, 6d] tensor; the weight
+            # gradients (one product, six segments) and the encoder-output gradient (two K = 768 halves) are formed once, behind layer zero --
+            # the encoder output is read once instead of three times, the accumulating gradient makes one round trip less
+            mb = st and getattr(self, 'merge_ckv_bwd', False)
+            if mb:
+                gkv = self._buf(ws, 'g.ekv_all', Se, self.Ld * 2 * d).data_ptr() + j * 2 * d * 4
+                ldg = self.Ld * 2 * d
+            else:
+                gkv, ldg = eGq, 2 * d
             self._attn(plan, ws, True, BT, H, N, F, qaddr, qss, d, kk, F * ldkv, ldkv, kk + hz * d, F * ldkv, ldkv,
                        b[tag + '.cctx'].data_ptr(), N * d, d, b[tag + '.clse'].data_ptr(), drop_site=c_a, dout=nGx,
-                       dq=dq_buf, dqss=N * d, lddq=d, dk=eGq, dkss=F * 2 * d, lddk=2 * d, dv=eGq + hz * d, dvss=F * 2 * d, lddv=2 * d,
+                       dq=dq_buf, dqss=N * d, lddq=d, dk=gkv, dkss=F * ldg, lddk=ldg, dv=gkv + hz * d, dvss=F * ldg, lddv=ldg,
                        flags=1 | 2 | 4 | 16 | (8 if (st and j > 0) else 0), planes=plc)
-            self._tn(plan, ws, Se, 2 * d, d, eGq, 2 * d, enc, d,
-                     [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
-            if st:                                   # (in place: a lane reads exactly the residual elements it then overwrites)
+            if mb:
+                if j == 0:
+                    gall = ws['bufs']['g.ekv_all'].data_ptr()
+                    segs = []
+                    for jj in range(self.Ld):
+                        pcj = dd + ('layer_zero_freq.' if jj == 0 else f'layers_freq.{jj - 1}.') + 'encoder_attention.'
+                        segs += [(2 * jj * d, d, self.G(pcj + 'fc_k.weight'), self.G(pcj + 'fc_k.bias')), ((2 * jj + 1) * d, d, self.G(pcj + 'fc_v.weight'), self.G(pcj + 'fc_v.bias'))]
+                    self._tn(plan, ws, Se, ldg, d, gall, ldg, enc, d, segs, dy_bf=True, x_bf=self.strip)
+                    self._sl(plan, ws, Se, d, 3 * d, gall, ldg, 'dec.ca.kv_all_t0', 0, eGA, d)
+                    self._sl(plan, ws, Se, d, 3 * d, gall + 3 * d * 4, ldg, 'dec.ca.kv_all_t1', 0, eGA, d, residual=eGA, ldr=d)
+                    first_enc_grad = False
+            else:
+                self._tn(plan, ws, Se, 2 * d, d, eGq, 2 * d, enc, d,
+                         [(0, d, self.G(pc + 'fc_k.weight'), self.G(pc + 'fc_k.bias')), (d, d, self.G(pc + 'fc_v.weight'), self.G(pc + 'fc_v.bias'))], dy_bf=True, x_bf=self.strip)
+            if mb:
+                pass
+            elif st:                                 # (in place: a lane reads exactly the residual elements it then overwrites)
                 self._sl(plan, ws, Se, d, 2 * d, eGq, 2 * d, tag + '.ca.kv_t', 0, eGA, d, residual=0 if first_enc_grad else eGA, ldr=d)
                 first_enc_grad = False
             elif first_enc_grad:
