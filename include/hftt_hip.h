@@ -197,6 +197,10 @@ int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_p
  * round 6, 1024 / 1536: the cross-attention K / V projections of two / three decoder layers stacked along N (they share their input, the
  * encoder output: model_spec2midi.py:259,296), one launch that reads it once. */
 #define HFTT_SL_C_F16PAIR 512u
+/* ABI v7, HFTT_SL_X3_BF16 (backward products), N == K == 256 without LayerNorm / residual: the strip x is the gradient of a dropout OUTPUT of
+ * width K and is masked with (drop_p, drop_site, drop_seed) while it is loaded (element (m, k) = element m * K + k of the site); no epilogue
+ * dropout in this form.  hftt_ffn_bwd_dx does the same with site_o when drop_p > 0 (the gradient of the block's output dropout). */
+#define HFTT_SL_X_DROP 2048u
 /* C[M,N] = epi(x[M,K] . Wl[N,K]^T + bias): same epilogue order as hftt_gemm_nt (relu, out_scale, gate, dropout, residual,
  * LayerNorm over N == 256).  N % 256 == 0; K % 32 == 0 and (K <= 256 or K % 256 == 0); gate is bf16. */
 typedef struct {
@@ -248,6 +252,11 @@ int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream);       /* mode 1 */
 #define HFTT_TN_DY_BF16 1u
 #define HFTT_TN_X_BF16 2u
 #define HFTT_TN_DY_HI 4u       /* npass 4: dY (the gradient) enters as its bf16 rounding only; X keeps its bf16 pair (two MFMA passes) */
+/* ABI v7, npass 4, fp32 dY with N == lddy == the width of the dropped tensor: dY is the gradient of a dropout OUTPUT and the kernel applies
+ * the mask of (drop_p, drop_site, drop_seed) while it loads it -- element (m, n) is element m * N + n of the site -- so that the LayerNorm
+ * backward does not have to write a masked copy of its result for this product (hftt_ln_bwd with dr_drop == NULL); db = colsum of the
+ * masked rows.  Tiles: N >= 256 and K >= 256. */
+#define HFTT_TN_DY_DROP 8u
 typedef struct {
   int32_t M, N, K, npass;
   const float* dY; int64_t lddy;
@@ -260,6 +269,7 @@ typedef struct {
   int32_t K_out;             /* number of K columns to write (<= K), destination leading dim */
   uint32_t io_flags;         /* HFTT_TN_*: npass 1 (either / both), npass 4 (ONE of them: that operand is its own hi half, two MFMA passes) */
   void* ws; int64_t ws_bytes;
+  float drop_p; uint32_t drop_site; uint64_t drop_seed;      /* HFTT_TN_DY_DROP (ABI v7) */
 } hftt_gemm_tn_desc;          /* npass 4 (split bf16): dY and X fp32, split on their way into LDS (or one of them stored as bf16) */
 int64_t hftt_gemm_tn_ws_bytes(int32_t M, int32_t N, int32_t K);
 int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream);

@@ -69,7 +69,7 @@ TnPlan tn_plan(int M, int N, int K) {
 template <int TM, int TN, int NPASS, bool DYB = false, bool XB = false>
 struct TnCfg {
   static constexpr bool F32 = (NPASS == 3);
-  static constexpr bool X3M = (NPASS == 2 || NPASS == 4 || NPASS == 5);   // 5 = npass 4 with HFTT_TN_DY_HI: dY (the gradient) enters as its bf16 rounding
+  static constexpr bool X3M = (NPASS == 2 || NPASS == 4 || NPASS == 5 || NPASS == 6);   // 5 = npass 4 with HFTT_TN_DY_HI: dY (the gradient) enters as its bf16 rounding; 6 = npass 4 with HFTT_TN_DY_DROP: dY is masked as it is loaded
   static constexpr int PLANES = X3M ? 2 : 1;       // x3: hi plane, then lo plane of each tile
   static constexpr int YE = DYB ? 8 : 4;           // elements per 16-byte global slot (bf16- or fp32-stored operand)
   static constexpr int XE = XB ? 8 : 4;
@@ -96,8 +96,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
                                                      const long nws, const long kws, const int n_tiles_total, const int n_splits) {
   using Cfg = TnCfg<TM, TN, NPASS, DYB, XB>;
   constexpr bool F32 = Cfg::F32, X3M = Cfg::X3M;
-  constexpr int EX = X3M ? (NPASS == 5 ? 4 : NPASS) : X3_BF16;         // element type of the split
+  constexpr int EX = X3M ? ((NPASS == 5 || NPASS == 6) ? 4 : NPASS) : X3_BF16;         // element type of the split
   constexpr bool DYH = (NPASS == 5);
+  constexpr bool DYD = (NPASS == 6);                 // dY = the gradient of a dropout output: the mask of (drop_p, drop_site, drop_seed) applied on load
+  static_assert(!DYD || !DYB, "the masked form takes an fp32 dY");
+  const uint32_t dthr = hftt_keep_thr(g.drop_p);
+  const float dinv = hftt_keep_scale(g.drop_p);
   static_assert(!F32 || (!DYB && !XB), "bf16-stored operands: bf16 mode, or ONE side of a split-bf16 product");
   // x3 with a bf16-stored operand (the saved FFN hidden / its gradient, kept as bf16 for this product only): that operand IS its hi
   // half, the lo half is zero and the pass that would multiply it is skipped (two MFMAs per fragment pair instead of three)
@@ -206,7 +210,14 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
     for (int j = 0; j < Cfg::YL; j++) {
       const int i = tid + 512 * j;
       const int row = i / YSPR;
-      const uint4 yv = (ycol_ok && mb + row < mend) ? yreg[j] : zero4;      // slots past the split / past N count as zeros
+      uint4 yv = (ycol_ok && mb + row < mend) ? yreg[j] : zero4;            // slots past the split / past N count as zeros
+      if (DYD && g.drop_p > 0.f) {                    // elements (m, ycol .. ycol + 3) = one hash quad of the site's [M, N] tensor
+        const uint32_t w = hftt_hash(g.drop_seed, g.drop_site, ((uint64_t)(mb + row) * (uint64_t)g.N + (uint64_t)ycol) >> 2);
+        yv.x = ((w & 0xFFu) < dthr) ? __float_as_uint(__uint_as_float(yv.x) * dinv) : 0u;
+        yv.y = (((w >> 8) & 0xFFu) < dthr) ? __float_as_uint(__uint_as_float(yv.y) * dinv) : 0u;
+        yv.z = (((w >> 16) & 0xFFu) < dthr) ? __float_as_uint(__uint_as_float(yv.z) * dinv) : 0u;
+        yv.w = ((w >> 24) < dthr) ? __float_as_uint(__uint_as_float(yv.w) * dinv) : 0u;
+      }
       if (Cfg::Y_EXACT || row < BMT) {      // (a per-lane branch here would also turn the register-set wait into vmcnt(0))
         if (DYB) {
           csum[0] += bf2f(yv.x & 0xFFFFu); csum[1] += bf2f(yv.x >> 16); csum[2] += bf2f(yv.y & 0xFFFFu); csum[3] += bf2f(yv.y >> 16);
@@ -547,6 +558,11 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
     else rc = HFTT_TN_GO5(1, 1);
 #undef HFTT_TN_GO5
 #endif
+  } else if (d->npass == 4 && (d->io_flags & HFTT_TN_DY_DROP)) {
+    HFTT_REQUIRE(!dyb && d->lddy == d->N && d->drop_p >= 0.f && d->drop_p < 1.f, "gemm_tn: HFTT_TN_DY_DROP takes an fp32 dY with lddy == N and 0 <= drop_p < 1");
+    if (p.tm == 2) rc = xb ? launch_tn<2, 4, 6, false, true>(*d, p, st) : launch_tn<2, 4, 6, false, false>(*d, p, st);
+    else if (p.tn == 4) rc = xb ? launch_tn<1, 4, 6, false, true>(*d, p, st) : launch_tn<1, 4, 6, false, false>(*d, p, st);
+    else { hftt_set_error("gemm_tn: HFTT_TN_DY_DROP covers N >= 256 and K >= 256 (got N=%d K=%d)", d->N, d->K); return 1; }
   } else if (d->npass == 4) {
 #define HFTT_TN_GO4(TM_, TN_)                                                     \
     (dyb ? launch_tn<TM_, TN_, 4, true, false>(*d, p, st) : (xb ? launch_tn<TM_, TN_, 4, false, true>(*d, p, st) : launch_tn<TM_, TN_, 4, false, false>(*d, p, st)))

@@ -100,6 +100,20 @@ __device__ __forceinline__ void drop16(float* v, uint64_t seed, uint32_t site, u
     for (int f = 0; f < 4; f++) v[4 * e + f] = __uint_as_float(__float_as_uint(v[4 * e + f] * inv_keep) & m[f]);
   }
 }
+// the same for 8 consecutive elements (two hash quads): the backward of a dropout applied to a strip chunk as it is loaded
+__device__ __forceinline__ void drop8(float* v, uint64_t seed, uint32_t site, uint64_t q0, uint32_t thr, float inv_keep) {
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const uint32_t w = hftt_hash(seed, site, q0 + e);
+    uint32_t m[4];
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[0]) : "v"((w & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[1]) : "v"(((w >> 8) & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[2]) : "v"(((w >> 16) & 0xFFu) - thr));
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m[3]) : "v"((w >> 24) - thr));
+#pragma unroll
+    for (int f = 0; f < 4; f++) v[4 * e + f] = __uint_as_float(__float_as_uint(v[4 * e + f] * inv_keep) & m[f]);
+  }
+}
 __device__ __forceinline__ bf16x8 as_frag(const u4v& u) { return __builtin_bit_cast(bf16x8, u); }
 
 // The 16 weight fragments of a slot -> 16 MFMAs.  With ONE wave per SIMD nobody else covers an LDS round trip, and left alone hipcc

@@ -167,6 +167,15 @@ __device__ __forceinline__ void chunk_convert(XChunk& c) {
   x3_split8<E>(v, hi, lo);
   c.a = __builtin_bit_cast(u4v, hi); c.b = __builtin_bit_cast(u4v, lo);
 }
+// a RAW chunk (elements 8 q .. 8 q + 7 of a dropout site's tensor) times its keep mask: the backward of a dropout whose output this strip is the
+// gradient of, applied as the strip arrives (the LayerNorm backward then writes no masked copy of its result)
+__device__ __forceinline__ void chunk_drop(XChunk& c, uint64_t seed, uint32_t site, uint64_t q0, uint32_t thr, float inv_keep) {
+  float v[8] = {__uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
+                __uint_as_float(c.b.x), __uint_as_float(c.b.y), __uint_as_float(c.b.z), __uint_as_float(c.b.w)};
+  drop8(v, seed, site, q0, thr, inv_keep);
+  c.a = u4v{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  c.b = u4v{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+}
 // hi + lo of a converted chunk back to fp32 (the residual of the fused FFN: the block input itself, to 2^-22)
 template <int E>
 __device__ __forceinline__ void chunk_values(const XChunk& c, float* v) {
@@ -516,9 +525,11 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
 // other: QKV at 262,144 tokens 560 us = 250 us of MFMA + 240 us of stores + 120 us of loads, HFTT_X3_DEBUG.)
 // ---------------------------------------------------------------------------------------------------------------------
 // PLN: C leaves as f16-pair planes (HFTT_SL_C_F16PAIR; forward products only, no residual)
-template <int E, int NT, bool HR, bool PLN = false>
+// XD: the strip is the gradient of a dropout output (HFTT_SL_X_DROP): masked while it is converted; no epilogue dropout
+template <int E, int NT, bool HR, bool PLN = false, bool XD = false>
 __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_desc g) {
   static_assert(!PLN || (E == X3_F16 && !HR), "f16-pair output: a forward projection without residual");
+  static_assert(!XD || (E != X3_F16 && !PLN), "masked strip: a backward product");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -566,6 +577,11 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
     int zero = 0;
     asm volatile("" : "+s"(zero));
     const float* prm_b = prm + zero;
+    if (XD && g.drop_p > 0.f) {
+      const uint64_t rowq_x = ((uint64_t)lane_tok(blk) * (uint64_t)g.K) >> 2;
+#pragma unroll
+      for (int c = 0; c < 16; c++) chunk_drop(xr[c], g.drop_seed, g.drop_site, rowq_x + ((chunk_off(c) + 16 * hb) >> 2), thr, inv_keep);
+    }
 #pragma unroll
     for (int c = 0; c < 16; c++) chunk_convert<E>(xr[c]);       // this block's strip (loaded during the previous block's last tile)
     XPre pre;
@@ -613,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void x3_linear_n_kernel(const hftt_strip_de
         if (relu) a = fmaxf(a, 0.f);
         v[q] = a * g.out_scale;
       }
-      if (g.drop_p > 0.f) {
+      if (!XD && g.drop_p > 0.f) {
         int l_ = lane; asm volatile("" : "+v"(l_));
         const uint64_t rowq = ((uint64_t)(blk * 128 + wave * 32 + (l_ & 31)) * (uint64_t)g.N) >> 2;
         drop16(v, g.drop_seed, g.drop_site, rowq + ((t * 32 + 16 * hb) >> 2), thr, inv_keep);
@@ -694,7 +710,13 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
     int zero = 0;
     asm volatile("" : "+s"(zero));
     const float* prm_b = prm + zero;
-    // this block's strip: loaded by the previous block's epilogue (or the prologue), converted here
+    // this block's strip: loaded by the previous block's epilogue (or the prologue), converted here.  Mode 1 with drop_p > 0: dy is the gradient
+    // of the block's OUTPUT dropout (site_o) and is masked here (the LayerNorm backward in front writes no masked copy)
+    if (MODE == 1 && g.drop_p > 0.f) {
+      const uint64_t rowq_x = ((uint64_t)tokc * 256ull) >> 2;
+#pragma unroll
+      for (int c = 0; c < 16; c++) chunk_drop(xr[c], g.drop_seed, g.site_o, rowq_x + ((chunk_off(c) + 16 * hb) >> 2), thr, inv_keep);
+    }
 #pragma unroll
     for (int c = 0; c < 16; c++) chunk_convert<E>(xr[c]);
 
@@ -1218,15 +1240,15 @@ int launch_xl(const hftt_strip_desc& d, hipStream_t st) {
   HFTT_CHECK_LAUNCH("x3_strip_linear");
   return 0;
 }
-template <int E, int NT, bool HR, bool PLN = false>
+template <int E, int NT, bool HR, bool PLN = false, bool XD = false>
 int launch_xn(const hftt_strip_desc& d, hipStream_t st) {
   const int lds = RING_BYTES + 4 * d.N + 4 * STG_BYTES_PER_WAVE;
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(x3_linear_n_kernel<E, NT, HR, PLN>, lds, "x3_strip_linear")) return rc; attr = lds; }
+  if (lds > attr) { if (int rc = set_lds(x3_linear_n_kernel<E, NT, HR, PLN, XD>, lds, "x3_strip_linear")) return rc; attr = lds; }
   const int cus = n_cus();
   if (cus <= 0) { hftt_set_error("x3_strip_linear: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  hipLaunchKernelGGL((x3_linear_n_kernel<E, NT, HR, PLN>), dim3((unsigned)(nblk < 2 * cus ? nblk : 2 * cus)), dim3(256), lds, st, d);
+  hipLaunchKernelGGL((x3_linear_n_kernel<E, NT, HR, PLN, XD>), dim3((unsigned)(nblk < 2 * cus ? nblk : 2 * cus)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("x3_strip_linear");
   return 0;
 }
@@ -1267,6 +1289,9 @@ int dispatch_xl(const hftt_strip_desc& d, hipStream_t st) {
       return 1;
     }
   }
+  if constexpr (E == X3_BF16) {
+    if (d.flags & HFTT_SL_X_DROP) return launch_xn<E, 8, false, false, true>(d, st);      // (validated by the caller: N == K == 256, no residual)
+  }
   // K == 256 without LayerNorm: the output-tile-major kernel (tile-major pack, two workgroups per CU)
   if (kch == 1 && passes == 1) return hr ? launch_xn<E, 8, true>(d, st) : launch_xn<E, 8, false>(d, st);
   if (kch == 1 && passes == 2) return hr ? launch_xn<E, 16, true>(d, st) : launch_xn<E, 16, false>(d, st);
@@ -1300,6 +1325,11 @@ int hftt_x3_strip_linear(const hftt_strip_desc& d0, hipStream_t st) {
   HFTT_REQUIRE(!(d.flags & (HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16)), "x3_strip_linear: tensors are fp32 in the split modes");
   HFTT_REQUIRE(d.ldx % 4 == 0 && d.ldc % 4 == 0 && (d.residual == nullptr || d.ldr % 4 == 0), "x3_strip_linear: rows must be 16-byte aligned");
   HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_GRAD_HI) || (d.flags & HFTT_SL_X3_BF16), "x3_strip_linear: HFTT_SL_X3_GRAD_HI goes with HFTT_SL_X3_BF16");
+  if (d.flags & HFTT_SL_X_DROP) {
+    HFTT_REQUIRE((d.flags & HFTT_SL_X3_BF16) && !(d.flags & HFTT_SL_X3_GRAD_HI) && d.K == 256 && d.N == 256 && d.ldx == 256 && d.ln_gamma == nullptr && d.residual == nullptr &&
+                 !(d.flags & (HFTT_SL_RELU | HFTT_SL_C_F16PAIR)),
+                 "x3_strip_linear: HFTT_SL_X_DROP is the backward of a dropout in front of a 256 -> 256 projection (HFTT_SL_X3_BF16, N == K == ldx == 256, no LayerNorm / residual / ReLU)");
+  }
   if (d.flags & HFTT_SL_C_F16PAIR) {
     HFTT_REQUIRE(!(d.flags & HFTT_SL_X3_BF16) && d.K == 256 && d.N <= 1536 && d.ln_gamma == nullptr && d.residual == nullptr && !(d.flags & HFTT_SL_RELU) && !(d.drop_p > 0.f),
                  "x3_strip_linear: HFTT_SL_C_F16PAIR is the plain forward projection (HFTT_SL_X3_F16, K == 256, N <= 1536, no LayerNorm / residual / ReLU / dropout)");

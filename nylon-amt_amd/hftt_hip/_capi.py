@@ -46,7 +46,8 @@ class GemmTnDesc(C.Structure):
                 ('seg_row0', C.c_int32 * 8), ('seg_rows', C.c_int32 * 8),
                 ('seg_dw', c_f32p * 8), ('seg_db', c_f32p * 8),
                 ('K_out', C.c_int32), ('io_flags', C.c_uint32),
-                ('ws', C.c_void_p), ('ws_bytes', C.c_int64)]
+                ('ws', C.c_void_p), ('ws_bytes', C.c_int64),
+                ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
 
 
 class AttnDesc(C.Structure):
@@ -119,6 +120,7 @@ SL_PRE_BF16 = 128                           # split modes, LayerNorm forms: pre_
 SL_X3_GRAD_HI = 256                         # with SL_X3_BF16: the gradient strip enters as its bf16 rounding (two MFMA passes)
 SL_H_BF16 = 64                              # fused block in a split mode: h_out / gate stored as bf16
 SL_X3_F16, SL_X3_BF16 = 16, 32               # split-operand forms of the strip kernels (fp32 tensors; fp16 / bf16 hi + lo halves)
+SL_X_DROP = 2048                            # backward strip linear: x (the gradient of a dropout output) is masked on load
 SL_C_F16PAIR = 512                          # SL_X3_F16 projection: C written as f16-pair planes (the attention kernels' operand form)
 ATTN_Q_F16PAIR, ATTN_KV_F16PAIR = 32, 64    # npass 2, dh 64: q / k, v are f16-pair planes
 TE_X_BF16, TE_Y_BF16, TE_M_BF16 = 1, 2, 4          # hftt_time_embed_fwd / _bwd io_flags

@@ -23,7 +23,7 @@ import torch
 
 from . import _capi
 from ._capi import (AttnDesc, FfnDesc, FoldDesc, GemmNtDesc, GemmTnDesc, LnBwdDesc, LossDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_C_F16PAIR, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16,
+                    SL_C_BF16, SL_C_F16PAIR, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, SL_X_DROP,
                     ATTN_Q_F16PAIR, ATTN_KV_F16PAIR, check, lib)
 
 # precision -> the descriptors' `npass` code (include/hftt_hip.h): 'x3' = split fp16 on forward products (2) and split bf16 on products with a
@@ -97,6 +97,9 @@ class HfttEngine:
         # x3 strip plans: the cross-attention K / V projections of ALL decoder layers (the same input: the encoder output, model_spec2midi.py:259,296)
         # as ONE launch with N = Ld * 2d instead of Ld launches that each re-read the encoder output
         self.merge_ckv_opt = os.environ.get('HFTT_X3_MERGE_CKV', '1') != '0'
+        # x3 strip plans (d = 256): the LayerNorm backward writes NO dropout-masked copy of its result; its consumers -- the weight-gradient
+        # product (HFTT_TN_DY_DROP), the fused FFN's dX (site_o) and the fc_o dX (HFTT_SL_X_DROP) -- apply the mask while they load dr
+        self.ln_mask_in_consumers_opt = os.environ.get('HFTT_X3_LN_MASK_IN_CONSUMERS', '1') != '0'
         self.set_precision(precision)
         self.dropout = float(dropout)
         # The device generator decides per element with ONE byte of a hash word (csrc/hftt_common.h: hftt_keep_thr), so the keep probability is
@@ -588,14 +591,17 @@ class HfttEngine:
         return dsc
 
     def _sl(self, plan, ws, M, N, K, x, ldx, wkey, bias, Cp, ldc, relu=False, out_scale=1.0, gate=0, ldg=0, gate_scale=1.0, drop_site=0,
-            residual=0, ldr=0, res_mod=0, res_bf=True, ln=None, x_bf=True, c_bf=True, c_planes=False):
+            residual=0, ldr=0, res_mod=0, res_bf=True, ln=None, x_bf=True, c_bf=True, c_planes=False, x_drop_site=0):
         """hftt_strip_linear plan entry (bf16 mode, N % 256 == 0): C = epi(x . Wl^T + bias), Wl = strip pack `wkey`."""
         dsc = StripDesc()
         dsc.M, dsc.N, dsc.K = M, N, K
         if self.x3:                                  # fp32 tensors, fp16 halves on forward products, bf16 halves where a gradient is an operand
             x_bf = c_bf = res_bf = False
             dsc.flags = (SL_X3_BF16 if self._in_backward else SL_X3_F16) | (SL_RELU if relu else 0) | (SL_PRE_BF16 if (self.hh and ln is not None) else 0) \
-                | (SL_X3_GRAD_HI if (self._in_backward and self.g8) else 0) | (SL_C_F16PAIR if c_planes else 0)
+                | (SL_X3_GRAD_HI if (self._in_backward and self.g8) else 0) | (SL_C_F16PAIR if c_planes else 0) | (SL_X_DROP if x_drop_site else 0)
+            if x_drop_site:                          # HFTT_SL_X_DROP: x (the LayerNorm backward's dr) is masked while it is loaded
+                assert self._in_backward and not drop_site and N == 256 and K == 256
+                drop_site = x_drop_site
         else:
             dsc.flags = (SL_X_BF16 if x_bf else 0) | (SL_C_BF16 if c_bf else 0) | (SL_RES_BF16 if (residual and res_bf) else 0) | (SL_RELU if relu else 0)
         dsc.x, dsc.ldx, dsc.w, dsc.bias = x, ldx, self.Ws(wkey), bias
@@ -631,7 +637,7 @@ class HfttEngine:
             xe = (5 if self.g8 else 4) if self._in_backward else 2
             kname = 'x3_linear_kernel<%d, %s, %d, %d, %s>' % (xe, tf(ln is not None), passes, kch, tf(bool(residual)))
             if ln is None and kch == 1:
-                kname = 'x3_linear_n_kernel<%d, %d, %s, %s>' % (xe, N // 32, tf(bool(residual)), tf(c_planes))
+                kname = 'x3_linear_n_kernel<%d, %d, %s, %s, %s>' % (xe, N // 32, tf(bool(residual)), tf(c_planes), tf(bool(x_drop_site)))
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
         plan.append((self.lib.hftt_strip_linear, (C.byref(dsc),), 'strip_linear', meta))
         return dsc
@@ -657,7 +663,7 @@ class HfttEngine:
             dsc.ln_gamma, dsc.ln_beta, dsc.pre_ln_out, dsc.ln_mean, dsc.ln_rstd = ln
             pre_saved = bool(ln[2])
         dsc.y, dsc.ldy = y, d
-        if mode == 0 and (site_h or site_o):
+        if (mode == 0 and (site_h or site_o)) or (mode == 1 and site_o):      # mode 1: site_o = the dropout whose OUTPUT gradient the strip dy is (masked on load)
             ws['drop'].append(dsc)
         ws['keep'].append(dsc)
         esz = 4.0 if self.x3 else 2.0
@@ -676,7 +682,7 @@ class HfttEngine:
         plan.append((self.lib.hftt_ffn_res_ln_fwd if mode == 0 else self.lib.hftt_ffn_bwd_dx, (C.byref(dsc),), 'ffn_fwd' if mode == 0 else 'ffn_bwd_dx', meta))
         return dsc
 
-    def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0, dy_bf=False, x_bf=False, dy_hid=False, x_hid=False):
+    def _tn(self, plan, ws, M, N, K, dY, lddy, X, ldx, segs, K_out=None, out_scale=1.0, beta=0.0, dy_bf=False, x_bf=False, dy_hid=False, x_hid=False, dy_drop_site=0):
         """segs: list of (row0, rows, dw_addr, db_addr or 0)"""
         need = self.lib.hftt_gemm_tn_ws_bytes(M, N, K)
         ws['tn_need'] = max(ws.get('tn_need', 0), need)
@@ -684,7 +690,11 @@ class HfttEngine:
         dsc.M, dsc.N, dsc.K, dsc.npass = M, N, K, (4 if self.npass == 2 else self.npass)
         # dy_hid / x_hid: this operand is the FFN hidden's gradient / the stored hidden (bf16 in the x3 strip plans as well)
         dy_bf, x_bf = (dy_bf and self.sb) or (dy_hid and self.hh), (x_bf and self.sb) or (x_hid and self.hh)
-        dsc.io_flags = (1 if dy_bf else 0) | (2 if x_bf else 0) | (4 if (self.g8 and not dy_bf) else 0)
+        dsc.io_flags = (1 if dy_bf else 0) | (2 if x_bf else 0) | (4 if (self.g8 and not dy_bf) else 0) | (8 if dy_drop_site else 0)
+        if dy_drop_site:                             # HFTT_TN_DY_DROP: dY (fp32, the LayerNorm backward's dr) is masked while it is loaded
+            assert not dy_bf and lddy == N and not self.g8
+            dsc.drop_p, dsc.drop_site, dsc.drop_seed = 0.0, dy_drop_site, 0
+            ws['drop'].append(dsc)
         dsc.dY, dsc.lddy, dsc.X, dsc.ldx = dY, lddy, X, ldx
         dsc.out_scale, dsc.beta = out_scale, beta
         dsc.n_seg = len(segs)
@@ -696,7 +706,7 @@ class HfttEngine:
         tile = '2, 4' if (N >= 256 and K >= 256) else ('1, 2' if (N >= 128 and K >= 128) else '1, 1')
         if tile == '2, 4' and N <= 256 and K <= 256:
             tile = '1, 4'                           # (csrc/gemm_tn.hip tn_plan: the 128 x 256 tile for single-tile shapes)
-        meta = {'kernel': 'gemm_tn_kernel<%s, %d, %s, %s>' % (tile, 5 if (dsc.io_flags & 4) else dsc.npass, 'true' if dy_bf else 'false', 'true' if x_bf else 'false'), 'flops': 2.0 * M * N * K,
+        meta = {'kernel': 'gemm_tn_kernel<%s, %d, %s, %s>' % (tile, 6 if dy_drop_site else (5 if (dsc.io_flags & 4) else dsc.npass), 'true' if dy_bf else 'false', 'true' if x_bf else 'false'), 'flops': 2.0 * M * N * K,
                 'bytes': (2.0 if dy_bf else 4.0) * M * N + (2.0 if x_bf else 4.0) * M * K + 4.0 * N * K, 'shape': (M, N, K)}
         plan.append((self.lib.hftt_gemm_tn, (C.byref(dsc),), 'gemm_tn', meta))
         return dsc
@@ -755,6 +765,10 @@ class HfttEngine:
             return False
         nqb = (Lq + 31) // 32
         return nqb <= (8 if Lk > 128 else 4)
+
+    def _mic(self):
+        """masked-in-consumers: this plan's LayerNorm backward writes no masked copy (x3 strip plans at d = 256, dropout on)"""
+        return bool(self.strip and self.x3 and not self.strip_small and not self.g8 and self.ln_mask_in_consumers_opt and self.dropout > 0.0)
 
     def _lnb(self, plan, ws, M, dy, r, mean, rstd, gamma, dr, dr_drop, drop_site, dgamma, dbeta, beta, drop_bf=True, dy_bf=False, dr_bf=False):
         r_bf = self.bfs or self.hh                  # the strip forward kernels (bf16, and x3) save the pre-LayerNorm sum as bf16
@@ -1067,18 +1081,21 @@ class HfttEngine:
         pf = pre + 'positionwise_feedforward.'
         pa = pre + 'self_attention.'
         use_drop = self.dropout > 0.0
-        dbr = GC if use_drop else GB
+        mic = self._mic()                           # the consumers of dr apply the dropout mask themselves: no masked copy GC
+        dbr = GB if (mic or not use_drop) else GC
         # LN2 -> FFN
         self._lnb(plan, ws, S, GA, b[tag + '.r2'].data_ptr(), b[tag + '.m2'].data_ptr(), b[tag + '.s2'].data_ptr(), gam,
-                  GB, GC if use_drop else 0, sf, dgam, dbet, 0.0, dy_bf=True, dr_bf=True)
-        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True, x_hid=True)
-        self._mlp(plan, ws, 1, S, dbr, key + '.ffn_t', GA, h_out=Gh, gate=b[tag + '.h'].data_ptr(), gate_scale=('inv_keep',), residual=GB)
+                  GB, GC if (use_drop and not mic) else 0, sf, dgam, dbet, 0.0, dy_bf=True, dr_bf=True)
+        self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True, x_hid=True,
+                 dy_drop_site=sf if mic else 0)
+        self._mlp(plan, ws, 1, S, dbr, key + '.ffn_t', GA, h_out=Gh, gate=b[tag + '.h'].data_ptr(), gate_scale=('inv_keep',), residual=GB, site_o=sf if mic else 0)
         self._tn(plan, ws, S, p, d, Gh, p, b[tag + '.x1'].data_ptr(), d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=True, dy_hid=True)
         # LN1 -> attention
         self._lnb(plan, ws, S, GA, b[tag + '.r1'].data_ptr(), b[tag + '.m1'].data_ptr(), b[tag + '.s1'].data_ptr(), gam,
-                  GB, GC if use_drop else 0, so, dgam, dbet, 1.0, dy_bf=True, dr_bf=True)
-        self._tn(plan, ws, S, d, d, dbr, d, b[tag + '.ctx'].data_ptr(), d, [(0, d, self.G(pa + 'fc_o.weight'), self.G(pa + 'fc_o.bias'))], dy_bf=True, x_bf=True)
-        self._sl(plan, ws, S, d, d, dbr, d, key + '.sa.o_t', 0, Gx, d)
+                  GB, GC if (use_drop and not mic) else 0, so, dgam, dbet, 1.0, dy_bf=True, dr_bf=True)
+        self._tn(plan, ws, S, d, d, dbr, d, b[tag + '.ctx'].data_ptr(), d, [(0, d, self.G(pa + 'fc_o.weight'), self.G(pa + 'fc_o.bias'))], dy_bf=True, x_bf=True,
+                 dy_drop_site=so if mic else 0)
+        self._sl(plan, ws, S, d, d, dbr, d, key + '.sa.o_t', 0, Gx, d, x_drop_site=so if mic else 0)
         qkv = b[tag + '.qkv'].data_ptr()
         hz = 2 if self.sb else 4
         self._attn(plan, ws, True, n_seq, H, L, L, qkv, L * 3 * d, 3 * d, qkv + hz * d, L * 3 * d, 3 * d, qkv + 2 * hz * d, L * 3 * d, 3 * d,
@@ -1101,11 +1118,13 @@ class HfttEngine:
         pf = pre + 'positionwise_feedforward.'
         use_drop = self.dropout > 0.0
         if self.strip:
-            dbr = GC if use_drop else GB
+            mic = self._mic()
+            dbr = GB if (mic or not use_drop) else GC
             self._lnb(plan, ws, S, GA, b[tag + '.fr'].data_ptr(), b[tag + '.fm'].data_ptr(), b[tag + '.fs'].data_ptr(), gam,
-                      GB, GC if use_drop else 0, sf, dgam, dbet, ln_beta, dy_bf=True, dr_bf=True)
-            self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True, x_hid=True)
-            self._mlp(plan, ws, 1, S, dbr, key + '.ffn_t', GA, h_out=Gh, gate=b[tag + '.h'].data_ptr(), gate_scale=('inv_keep',), residual=GB)
+                      GB, GC if (use_drop and not mic) else 0, sf, dgam, dbet, ln_beta, dy_bf=True, dr_bf=True)
+            self._tn(plan, ws, S, d, p, dbr, d, b[tag + '.h'].data_ptr(), p, [(0, d, self.G(pf + 'fc_2.weight'), self.G(pf + 'fc_2.bias'))], dy_bf=True, x_bf=True, x_hid=True,
+                     dy_drop_site=sf if mic else 0)
+            self._mlp(plan, ws, 1, S, dbr, key + '.ffn_t', GA, h_out=Gh, gate=b[tag + '.h'].data_ptr(), gate_scale=('inv_keep',), residual=GB, site_o=sf if mic else 0)
             self._tn(plan, ws, S, p, d, Gh, p, x_in, d, [(0, p, self.G(pf + 'fc_1.weight'), self.G(pf + 'fc_1.bias'))], dy_bf=True, x_bf=True, dy_hid=True)
             return
         self._lnb(plan, ws, S, GA, b[tag + '.fr'].data_ptr(), b[tag + '.fm'].data_ptr(), b[tag + '.fs'].data_ptr(), gam,
@@ -1189,7 +1208,8 @@ class HfttEngine:
         #      the encoder-output gradient accumulates in eGA ----
         A, Bf, Cf, Q1 = nGD, nGB, nGC, nGA
         Gd = (A, Bf, Cf, nGh, nGq, nGx)
-        dbr, dbr_bf = (Cf, True) if use_drop else (Bf, bs)
+        mic = st and self._mic()                      # (the LayerNorm backward writes no masked copy: its consumers mask dr themselves)
+        dbr, dbr_bf = (Cf, True) if (use_drop and not mic) else (Bf, bs)
         first_enc_grad = True
         enc = ws['enc']
         for j in reversed(range(self.Ld)):
@@ -1202,11 +1222,11 @@ class HfttEngine:
             self._ffn_bwd(plan, ws, tag, tag, pre, Sn, b[tag + '.cx'].data_ptr(), Gd, 0.0)
             c_a, c_o = sites['cross']
             self._lnb(plan, ws, Sn, A, b[tag + '.cr'].data_ptr(), b[tag + '.cm'].data_ptr(), b[tag + '.cs'].data_ptr(), gam,
-                      Bf, Cf if use_drop else 0, c_o, dgam, dbet, 1.0, dy_bf=st, dr_bf=st)
+                      Bf, Cf if (use_drop and not mic) else 0, c_o, dgam, dbet, 1.0, dy_bf=st, dr_bf=st)
             self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.cctx'].data_ptr(), d, [(0, d, self.G(pc + 'fc_o.weight'), self.G(pc + 'fc_o.bias'))],
-                     dy_bf=dbr_bf, x_bf=True)
+                     dy_bf=dbr_bf, x_bf=True, dy_drop_site=c_o if mic else 0)
             if st:
-                self._sl(plan, ws, Sn, d, d, dbr, d, tag + '.ca.o_t', 0, nGx, d)
+                self._sl(plan, ws, Sn, d, d, dbr, d, tag + '.ca.o_t', 0, nGx, d, x_drop_site=c_o if mic else 0)
             else:
                 self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.ca.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
             kk, ldkv = ws['ckv_at'][tag]
@@ -1268,11 +1288,11 @@ class HfttEngine:
                 ps = pre + 'self_attention.'
                 trg = ws['dec_out'][j - 1]
                 self._lnb(plan, ws, Sn, A, b[tag + '.sr'].data_ptr(), b[tag + '.sm'].data_ptr(), b[tag + '.ss'].data_ptr(), gam,
-                          Bf, Cf if use_drop else 0, s_o, dgam, dbet, 1.0, dy_bf=st, dr_bf=st)
+                          Bf, Cf if (use_drop and not mic) else 0, s_o, dgam, dbet, 1.0, dy_bf=st, dr_bf=st)
                 self._tn(plan, ws, Sn, d, d, dbr, d, b[tag + '.sctx'].data_ptr(), d, [(0, d, self.G(ps + 'fc_o.weight'), self.G(ps + 'fc_o.bias'))],
-                         dy_bf=dbr_bf, x_bf=True)
+                         dy_bf=dbr_bf, x_bf=True, dy_drop_site=s_o if mic else 0)
                 if st:
-                    self._sl(plan, ws, Sn, d, d, dbr, d, tag + '.sa.o_t', 0, nGx, d)
+                    self._sl(plan, ws, Sn, d, d, dbr, d, tag + '.sa.o_t', 0, nGx, d, x_drop_site=s_o if mic else 0)
                 else:
                     self._nt(plan, ws, Sn, d, d, dbr, d, self.Wp(tag + '.sa.o_t'), 0, nGx, d, a_bf=dbr_bf, c_bf=True)
                 q = b[tag + '.sqkv'].data_ptr()
