@@ -854,364 +854,6 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
   P.drain();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 6: the fused FFN FORWARD with its two cross terms on the block-scaled fp8 matrix pipe.
-//   a.b ~ a_hi.b_hi  (fp16 halves, v_mfma_f32_32x32x16_f16: as before)
-//        + a_hi8.b_lo8 + a_lo8.b_hi8  (v_mfma_scale_f32_32x32x64_f8f6f4: e4m3 of the fp16 hi half and of the fp32 remainder lo = a - hi, one
-//          power-of-two scale per 32 k-elements of a row; 64 k per instruction at twice the bf16 rate)
-// The cross terms carry 2^-11 of a product; with both factors at e4m3's 2^-4 their error is ~2^-15 of the result (measured on the GPU with the
-// prototype tools/probes/x3f8_gemm_proto.hip: 1.5e-5 of the largest result per GEMM against 6e-7 for three fp16 passes and 4.8e-4 for hi.hi
-// alone; end to end in the two Linear layers of every feed-forward block: 7.5e-5 on the posteriors -- profiles/r05_fp8_cross_terms.txt).
-// Per (tile, 64 k): 4 fp16 + 2 fp8 instructions = 256 matrix cycles instead of 12 x 32 = 384.
-// Operand maps (pinned by tools/probes/mfma_f8_*.hip): a lane (row r = lane & 31, half hk = lane >> 5) holds 32 bytes of a 64-k group, byte p <->
-// k = 32 (p >> 4) + 16 hk + (p & 15): in the strip layout exactly the lane's 16 features of the two 32-feature groups, i.e. the chunks
-// (pt even: u = 0, 1 | pt odd: u = 0, 1) it already owns.  One E8M0 scale byte covers bytes 0 - 15 of lanes r and r + 32 (read from lane r),
-// another bytes 16 - 31 (read from lane r + 32): the two 32-feature blocks.  Results land in the bf16 instruction's accumulator map.
-// Weight stream (hftt_x3f_ffn_pack), 16 KB slots of sixteen 1 KB pieces (64 lanes x 16 B), per PAIR of hidden tiles (2 tp, 2 tp + 1):
-//   slot A(t): the 16 fp16 hi fragments of fc_1 tile t;   slot B(t): per 64-k group g: [hi8 bytes 0-15 | hi8 bytes 16-31 | lo8 0-15 | lo8 16-31];
-//   A, B of tile 2 tp, A, B of tile 2 tp + 1, then four slots C: per output tile (two per slot) of fc_2's K-slice 64 tp .. + 63:
-//   [4 fp16 hi fragments | hi8 0-15 | hi8 16-31 | lo8 0-15 | lo8 16-31].  Behind the 1 MB stream: 32 KB of scale words (lane-linear, byte 0 =
-//   scale of the hi block this lane supplies, byte 1 = of the lo block), copied to LDS once per launch.
-// The block input is the residual: it is re-read from global memory in the final epilogue (the strip registers no longer hold an exact copy).
-// ---------------------------------------------------------------------------------------------------------------------
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-constexpr int F8_STREAM_BYTES = 2 * 256 * 512 * 2;      // one FFN block's stream: 64 slots x 16 KB
-constexpr int F8_SCALE_WORDS = 2 * 64 * 64;             // (16 tiles x 4 groups + 8 pairs x 8 output tiles) x 64 lanes
-
-// E8M0 byte b of a block whose largest magnitude is amax: the block times 2^(127 - b) lands in [128, 256) (e4m3 reaches 448)
-__device__ __forceinline__ int f8_scale_byte(float amax) {
-  const int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu) - 7;
-  return e < 1 ? 1 : e;
-}
-__device__ __forceinline__ float f8_scale_mul(int b) { return __uint_as_float((unsigned)(254 - b) << 23); }
-__device__ __forceinline__ float f8_hi_times(unsigned hi_pair, int which, float m) {      // float(fp16 half `which` of hi_pair) * m in one v_fma_mix_f32
-  float r;
-  if (which == 0) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pair), "v"(m));
-  else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pair), "v"(m));
-  return r;
-}
-// the lane's 16 values of ONE 32-feature block -> fp16 hi (two chunks), e4m3 of hi and of lo = v - hi (four words each), and the block's two
-// scale bytes (maxima exchanged with the partner lane ^ 32, which holds the block's other 16 features)
-__device__ __forceinline__ void f8_convert16(const float* v, u4v& hi0, u4v& hi1, int* h8, int* l8, int& sh, int& sl) {
-  unsigned hp[8];
-  float lo[16];
-  float mx = 0.f, ml = 0.f;
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const float a = __builtin_amdgcn_fmed3f(v[2 * q], -65504.f, 65504.f), b = __builtin_amdgcn_fmed3f(v[2 * q + 1], -65504.f, 65504.f);
-    hp[q] = X3<X3_F16>::pk_lo(a, b);
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * q]) : "v"(hp[q]), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * q + 1]) : "v"(hp[q]), "v"(b));
-    mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
-    ml = fmaxf(ml, fmaxf(fabsf(lo[2 * q]), fabsf(lo[2 * q + 1])));
-  }
-  hi0 = u4v{hp[0], hp[1], hp[2], hp[3]};
-  hi1 = u4v{hp[4], hp[5], hp[6], hp[7]};
-  mx = xor32_max(mx);                                 // |hi| <= |v| (1 + 2^-11): the block maximum of v bounds it inside the binade of headroom
-  ml = xor32_max(ml);
-  sh = f8_scale_byte(mx);
-  sl = f8_scale_byte(ml);
-  const float mh = f8_scale_mul(sh), mlo = f8_scale_mul(sl);
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    int ph = 0, pl = 0;
-    ph = __builtin_amdgcn_cvt_pk_fp8_f32(f8_hi_times(hp[2 * w], 0, mh), f8_hi_times(hp[2 * w], 1, mh), ph, false);
-    ph = __builtin_amdgcn_cvt_pk_fp8_f32(f8_hi_times(hp[2 * w + 1], 0, mh), f8_hi_times(hp[2 * w + 1], 1, mh), ph, true);
-    pl = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4 * w] * mlo, lo[4 * w + 1] * mlo, pl, false);
-    pl = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4 * w + 2] * mlo, lo[4 * w + 3] * mlo, pl, true);
-    h8[w] = ph; l8[w] = pl;
-  }
-}
-__device__ __forceinline__ i32x8 f8_join(const bf16x8& a, const bf16x8& b) {
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  return __builtin_shufflevector(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), 0, 1, 2, 3, 4, 5, 6, 7);
-}
-__device__ __forceinline__ i32x8 f8_join(const int* a, const int* b) { return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
-__device__ __forceinline__ f32x16 f8_mma(i32x8 a, i32x8 b, f32x16 c, int sa, int sb) {
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);      // A, B e4m3; the scale is byte 0 of the lane's register
-}
-// one 64-feature group of the strip: raw (eight 16-byte pieces: chunk c = r[2c], r[2c + 1]) or converted (r[0..3]: fp16 hi of chunks 0..3,
-// r[4..5]: hi8, r[6..7]: lo8; sc: byte 0 = hi scale, byte 1 = lo scale of the block THIS lane supplies to the instruction)
-struct F8Group { u4v r[8]; int sc; };
-__device__ __forceinline__ void f8_group_convert(F8Group& gq, int h) {
-  float v[32];
-#pragma unroll
-  for (int c = 0; c < 8; c++) { v[4 * c] = __uint_as_float(gq.r[c].x); v[4 * c + 1] = __uint_as_float(gq.r[c].y); v[4 * c + 2] = __uint_as_float(gq.r[c].z); v[4 * c + 3] = __uint_as_float(gq.r[c].w); }
-  int h8[8], l8[8], sh[2], sl[2];
-  u4v hi[4];
-  f8_convert16(v, hi[0], hi[1], h8, l8, sh[0], sl[0]);               // block 0: pt even (chunks 0, 1)
-  f8_convert16(v + 16, hi[2], hi[3], h8 + 4, l8 + 4, sh[1], sl[1]);    // block 1: pt odd (chunks 2, 3)
-#pragma unroll
-  for (int c = 0; c < 4; c++) gq.r[c] = hi[c];
-  gq.r[4] = u4v{(unsigned)h8[0], (unsigned)h8[1], (unsigned)h8[2], (unsigned)h8[3]}; gq.r[5] = u4v{(unsigned)h8[4], (unsigned)h8[5], (unsigned)h8[6], (unsigned)h8[7]};
-  gq.r[6] = u4v{(unsigned)l8[0], (unsigned)l8[1], (unsigned)l8[2], (unsigned)l8[3]}; gq.r[7] = u4v{(unsigned)l8[4], (unsigned)l8[5], (unsigned)l8[6], (unsigned)l8[7]};
-  gq.sc = (h ? sh[1] : sh[0]) | ((h ? sl[1] : sl[0]) << 8);
-}
-__device__ __forceinline__ i32x8 f8_pair(const u4v& a, const u4v& b) {
-  return i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
-}
-// sixteen 1 KB pieces of a ring slot, read in order four ahead of their use (the first four arrive in `pre`, requested by the previous slot);
-// step(s, fr) is called when piece s has been REQUESTED AND ORDERED in front of it (the compiler places the wait), in program order
-template <typename F>
-__device__ __forceinline__ void f8_slot(const unsigned char* slot, const unsigned char* next, XPre& pre, F&& step) {
-  bf16x8 fr[16];
-#pragma unroll
-  for (int i = 0; i < 4; i++) fr[i] = pre.f[i];
-  static_for<16>([&](auto s_c) __attribute__((always_inline)) {
-    constexpr int s = decltype(s_c)::value;
-    step(s_c, fr);
-    if (s + 4 < 16) fr[s + 4] = *reinterpret_cast<const bf16x8*>(slot + (s + 4) * 1024);
-    else pre.f[s + 4 - 16] = *reinterpret_cast<const bf16x8*>(next + (s + 4 - 16) * 1024);
-    __builtin_amdgcn_sched_barrier(0);
-  });
-}
-
-template <int PT, bool HH>
-__global__ __launch_bounds__(256, 1) void x3f_mlp_kernel(const hftt_ffn_desc g) {
-  static_assert(PT == 16, "d = 256, p = 512");
-  constexpr int E = X3_F16;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  constexpr int p = PT * 32;
-  const long nblk = ((long)g.M + 127) / 128;
-  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // b1[p] | b2[256] | gamma[256] | beta[256] | four wave-private store patches | weight scales
-  float* stage = reinterpret_cast<float*>(smem + RING_BYTES + 4 * (PT * 32 + 768) + wave * STG_BYTES_PER_WAVE);
-  unsigned* wsc = reinterpret_cast<unsigned*>(smem + RING_BYTES + 4 * (PT * 32 + 768) + 4 * STG_BYTES_PER_WAVE);
-  const float* xb = reinterpret_cast<const float*>(g.x);
-  float* yb = reinterpret_cast<float*>(g.y);
-  float* preb = reinterpret_cast<float*>(g.pre_ln_out);
-  float* hob = reinterpret_cast<float*>(g.h_out);
-  unsigned short* hob16 = reinterpret_cast<unsigned short*>(g.h_out);
-
-  XPipe P;
-  P.w = g.w; P.S = 4 * PT; P.fill_pos = 0;
-  P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
-  P.wave = wave; P.lane = lane;
-  P.nofill = false; P.nobar = false;
-
-  auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
-
-  for (int i = tid; i < p; i += 256) prm[i] = g.b1 != nullptr ? g.b1[i] : 0.f;
-  prm[p + tid] = g.b2 != nullptr ? g.b2[tid] : 0.f;
-  prm[p + 256 + tid] = g.ln_gamma[tid]; prm[p + 512 + tid] = g.ln_beta[tid];
-  {
-    const unsigned* gs = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(g.w) + F8_STREAM_BYTES);
-    for (int i = tid; i < F8_SCALE_WORDS; i += 256) wsc[i] = gs[i];
-  }
-
-  F8Group xg[4];
-  auto strip_load = [&](const float* row) {           // the lane's 128 features: group q = chunks 4q .. 4q + 3
-#pragma unroll
-    for (int c = 0; c < 16; c++) {
-      xg[c >> 2].r[2 * (c & 3)] = stream_load16(row + chunk_off(c));
-      xg[c >> 2].r[2 * (c & 3) + 1] = stream_load16(row + chunk_off(c) + 4);
-    }
-  };
-  strip_load(xb + tok_of(blockIdx.x) * g.ldx + 16 * h);
-  P.fill<0>(); P.fill<1>(); P.fill<2>();
-  static_assert(FILL_AHEAD == 3, "prologue fills");
-  wait_lgkm0();
-  P.prologue_sync();
-
-  const uint32_t thr = hftt_keep_thr(g.drop_p);
-  const float inv_keep = hftt_keep_scale(g.drop_p);
-  const unsigned char* abase = smem + lane * 16;
-  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    int hb = h;
-    asm volatile("" : "+v"(hb));
-    const long tok = blk * 128 + wave * 32 + j;
-    const bool wave_ok = (blk * 128 + wave * 32) < g.M;
-    const long tokc = tok_of(blk);
-    const long nxt = blk + gridDim.x;
-    const float* xrow_cur = xb + tokc * g.ldx + 16 * hb;
-    const float* xrow_next = xb + (nxt < nblk ? tok_of(nxt) : tokc) * g.ldx + 16 * hb;
-    const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)p) >> 2;
-    int zero = 0;
-    asm volatile("" : "+s"(zero));
-    const float* prm_b = prm + zero;
-    const unsigned* wsc_b = wsc + zero + lane;
-#pragma unroll
-    for (int q = 0; q < 4; q++) f8_group_convert(xg[q], hb);
-
-    f32x16 yacc[8];
-#pragma unroll
-    for (int ot = 0; ot < 8; ot++) {
-      float b[16];
-      lds16f(prm_b + p + ot * 32 + 16 * hb, b);
-#pragma unroll
-      for (int q = 0; q < 16; q++) yacc[ot][q] = b[q];
-    }
-    XPre pre;
-    slot_head(abase, pre);
-    for (int tp = 0; tp < PT / 2; tp++) {
-      u4v hh[4];                                      // fp16 hi of the pair's hidden chunks: tile 2 tp (u = 0, 1), tile 2 tp + 1 (u = 0, 1)
-      int hid_h8[8], hid_l8[8], hsh[2], hsl[2];
-      static_for<2>([&](auto half_c) __attribute__((always_inline)) {
-        constexpr int half = decltype(half_c)::value;
-        const int t = 2 * tp + half;
-        f32x16 hacc;
-        {
-          float b[16];
-          lds16f(prm_b + t * 32 + 16 * hb, b);
-#pragma unroll
-          for (int q = 0; q < 16; q++) hacc[q] = b[q];
-        }
-        // ---- first GEMM, hidden tile t: hi.hi (slot A), then the cross terms (slot B) ----
-        P.begin_slot();
-        f8_slot(abase + (2 * half) * SLOT_BYTES, abase + (2 * half + 1) * SLOT_BYTES, pre, [&](auto s_c, bf16x8 (&fr)[16]) __attribute__((always_inline)) {
-          constexpr int s = decltype(s_c)::value;
-          hacc = X3<E>::mma(fr[s], __builtin_bit_cast(bf16x8, xg[s >> 2].r[s & 3]), hacc);
-          if (s == 1) P.template refill<2 * half>();
-        });
-        P.begin_slot();
-        f8_slot(abase + (2 * half + 1) * SLOT_BYTES, abase + ((2 * half + 2) & 3) * SLOT_BYTES, pre, [&](auto s_c, bf16x8 (&fr)[16]) __attribute__((always_inline)) {
-          constexpr int s = decltype(s_c)::value;
-          if (s & 1) {
-            constexpr int m = s >> 1, gq = m >> 1, which = m & 1;
-            const unsigned ws = wsc_b[(t * 4 + gq) * 64];
-            const i32x8 a = f8_join(fr[s - 1], fr[s]);
-            if (which == 0) hacc = f8_mma(a, f8_pair(xg[gq].r[6], xg[gq].r[7]), hacc, (int)(ws & 0xFFu), (xg[gq].sc >> 8) & 0xFF);      // W_hi8 . x_lo8
-            else hacc = f8_mma(a, f8_pair(xg[gq].r[4], xg[gq].r[5]), hacc, (int)((ws >> 8) & 0xFFu), xg[gq].sc & 0xFF);               // W_lo8 . x_hi8
-          }
-          if (s == 1) P.template refill<2 * half + 1>();
-        });
-        // ---- middle epilogue: ReLU, dropout, the stored copy, operands of the second GEMM ----
-        float v[16];
-        const int hcol0 = t * 32 + 16 * hb;
-#pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = fmaxf(hacc[q], 0.f);
-        if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 2), thr, inv_keep);
-        if (hob != nullptr) {                                                 // (wave-uniform)
-          if (HH) tile_store_rows_bf16(stage, v, j, hb, lane, hob16 + (blk * 128 + wave * 32) * g.ldh + t * 32, g.ldh, wave_ok);
-          else tile_store_rows(stage, v, j, hb, lane, hob + (blk * 128 + wave * 32) * g.ldh + t * 32, g.ldh, wave_ok);
-        }
-        f8_convert16(v, hh[2 * half], hh[2 * half + 1], hid_h8 + 4 * half, hid_l8 + 4 * half, hsh[half], hsl[half]);
-      });
-      if (tp == PT / 2 - 1) strip_load(xrow_next);       // the strip has fed its last first-GEMM of the block: its registers take the next block's rows
-      const i32x8 bh8 = f8_join(hid_h8, hid_h8 + 4), bl8 = f8_join(hid_l8, hid_l8 + 4);
-      const int bsh = hb ? hsh[1] : hsh[0], bsl = hb ? hsl[1] : hsl[0];
-      // ---- second GEMM, K-slice 64 tp .. + 63: two output tiles per slot ----
-      static_for<4>([&](auto q_c) __attribute__((always_inline)) {
-        constexpr int q = decltype(q_c)::value;
-        P.begin_slot();
-        f8_slot(abase + q * SLOT_BYTES, abase + ((q + 1) & 3) * SLOT_BYTES, pre, [&](auto s_c, bf16x8 (&fr)[16]) __attribute__((always_inline)) {
-          constexpr int s = decltype(s_c)::value, ot = 2 * q + (s >> 3), r = s & 7;
-          if (r < 4) yacc[ot] = X3<E>::mma(fr[s], __builtin_bit_cast(bf16x8, hh[r]), yacc[ot]);
-          else if (r == 5) { const unsigned ws = wsc_b[(64 + tp * 8 + ot) * 64]; yacc[ot] = f8_mma(f8_join(fr[s - 1], fr[s]), bl8, yacc[ot], (int)(ws & 0xFFu), bsl); }
-          else if (r == 7) { const unsigned ws = wsc_b[(64 + tp * 8 + ot) * 64]; yacc[ot] = f8_mma(f8_join(fr[s - 1], fr[s]), bh8, yacc[ot], (int)((ws >> 8) & 0xFFu), bsh); }
-          if (s == 1) P.template refill<q>();
-        });
-      });
-    }
-
-    // ---------------- final epilogue of the block ----------------
-    const uint64_t rowq = ((uint64_t)tok * 256ull) >> 2;
-    float* ywave = yb + (blk * 128 + wave * 32) * g.ldy;
-    float rn[16];
-    load16f(xrow_cur, rn);
-#pragma unroll
-    for (int ot = 0; ot < 8; ot++) {
-      const int col0 = ot * 32 + 16 * hb;
-      float v[16], r[16];
-#pragma unroll
-      for (int q = 0; q < 16; q++) { v[q] = yacc[ot][q]; r[q] = rn[q]; }
-      if (ot + 1 < 8) load16f(xrow_cur + (ot + 1) * 32, rn);      // the residual = the block input, re-read (L2 / Infinity Cache: it was read a block ago)
-      if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_o, rowq + (col0 >> 2), thr, inv_keep);
-#pragma unroll
-      for (int q = 0; q < 16; q++) yacc[ot][q] = v[q] + r[q];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const bool p16 = g.flags & HFTT_SL_PRE_BF16;
-    x3_ln_rows(yacc, prm_b + p + 256, prm_b + p + 512, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, stage, j, lane,
-               (preb != nullptr && !p16) ? preb + (blk * 128 + wave * 32) * g.ldy : nullptr, ywave, g.ldy,
-               (preb != nullptr && p16) ? reinterpret_cast<unsigned short*>(preb) + (blk * 128 + wave * 32) * g.ldy : nullptr);
-  }
-  P.drain();
-}
-
-// the stream of one FFN block (see above): one thread per (matrix, row, 32-k block)
-struct x3f_pack_entry { int64_t w1_off, w2_off, dst_off; };      // element offsets into params (fp32) / byte offset into dst
-__global__ __launch_bounds__(256) void x3f_ffn_pack_kernel(const float* __restrict__ params, unsigned char* __restrict__ dst, const x3f_pack_entry* __restrict__ table) {
-  const x3f_pack_entry e = table[blockIdx.y];
-  constexpr int D = 256, PF = 512;
-  const int n_w1 = PF * (D / 32), n_w2 = D * (PF / 32);           // (row, block) items of fc_1 [PF, D] and fc_2 [D, PF]
-  unsigned char* out = dst + e.dst_off;
-  unsigned* sc_out = reinterpret_cast<unsigned*>(out + F8_STREAM_BYTES);
-  for (int it = blockIdx.x * 256 + threadIdx.x; it < n_w1 + n_w2; it += gridDim.x * 256) {
-    const bool second = it >= n_w1;
-    const int idx = second ? it - n_w1 : it;
-    const int nb = second ? PF / 32 : D / 32;
-    const int n = idx / nb, b = idx % nb;                         // row, 32-k block
-    const float* src = params + (second ? e.w2_off + (long)n * PF : e.w1_off + (long)n * D) + 32 * b;
-    float v[32], lo[32];
-    unsigned short hi[32];
-    float mx = 0.f, ml = 0.f;
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-      const float a = src[k];
-      bad = bad || !(a - a == 0.f);
-      v[k] = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
-      const _Float16 t = (_Float16)v[k];
-      hi[k] = __builtin_bit_cast(unsigned short, t);
-      lo[k] = v[k] - (float)t;
-      mx = fmaxf(mx, fabsf(v[k])); ml = fmaxf(ml, fabsf(lo[k]));
-    }
-    if (bad) {                                                   // a NaN / infinite parameter poisons its block (as x3_split2_checked does)
-#pragma unroll
-      for (int k = 0; k < 32; k++) hi[k] = 0x7E00u;
-    }
-    const int sh = f8_scale_byte(mx), sl = f8_scale_byte(ml);
-    const float mh = f8_scale_mul(sh), mlo = f8_scale_mul(sl);
-    // destination pieces.  tile / lane of the row; the block's place in the slot structure
-    const int tile = n >> 5, li = x3_i_of_c(n & 31);
-    long base;                                                   // byte offset of the slot group this block belongs to
-    int fp16_piece0, f8_piece0;                                  // piece index (1 KB units inside the 16 KB slot) of fp16 chunk (pt = b, u = 0) / of hi8 bytes 0-15 of the block's group
-    long slotA, slotB;
-    if (!second) {                                               // fc_1 tile `tile`: pair tp = tile >> 1, slots 8 tp + 2 (tile & 1) (A), + 1 (B)
-      slotA = (long)(8 * (tile >> 1) + 2 * (tile & 1)) * SLOT_BYTES;
-      slotB = slotA + SLOT_BYTES;
-      fp16_piece0 = 2 * b;                                       // chunk ch = 2 b + u
-      f8_piece0 = 4 * (b >> 1);                                  // group g = b >> 1: [h8 sub0, h8 sub1, l8 sub0, l8 sub1]
-    } else {                                                     // fc_2 output tile `tile`, K-slice pair tp = b >> 1: slot 8 tp + 4 + (tile >> 1), half (tile & 1)
-      slotA = (long)(8 * (b >> 1) + 4 + (tile >> 1)) * SLOT_BYTES + (long)(tile & 1) * 8 * 1024;
-      slotB = slotA;
-      fp16_piece0 = 2 * (b & 1);                                 // c = 2 (b & 1) + u
-      f8_piece0 = 4;
-    }
-    (void)base;
-#pragma unroll
-    for (int hk = 0; hk < 2; hk++) {
-#pragma unroll
-      for (int u = 0; u < 2; u++) {                               // fp16 fragment (pt = b, u): lane (li, hk) holds k = 16 hk + 8 u + 0..7 of the block
-        uint4 w;
-        const unsigned short* q = hi + 16 * hk + 8 * u;
-        w.x = q[0] | ((unsigned)q[1] << 16); w.y = q[2] | ((unsigned)q[3] << 16); w.z = q[4] | ((unsigned)q[5] << 16); w.w = q[6] | ((unsigned)q[7] << 16);
-        *reinterpret_cast<uint4*>(out + slotA + (long)(fp16_piece0 + u) * 1024 + (hk * 32 + li) * 16) = w;
-      }
-      // fp8: lane (li, hk) bytes 16 (b & 1) + 0..15 <-> k = 16 hk + 0..15 of this block: sub-piece (b & 1) of hi8 / lo8
-      int ph[4], pl[4];
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
-        const int k0 = 16 * hk + 4 * w;
-        int a = 0, c = 0;
-        a = __builtin_amdgcn_cvt_pk_fp8_f32((float)__builtin_bit_cast(_Float16, hi[k0]) * mh, (float)__builtin_bit_cast(_Float16, hi[k0 + 1]) * mh, a, false);
-        a = __builtin_amdgcn_cvt_pk_fp8_f32((float)__builtin_bit_cast(_Float16, hi[k0 + 2]) * mh, (float)__builtin_bit_cast(_Float16, hi[k0 + 3]) * mh, a, true);
-        c = __builtin_amdgcn_cvt_pk_fp8_f32(lo[k0] * mlo, lo[k0 + 1] * mlo, c, false);
-        c = __builtin_amdgcn_cvt_pk_fp8_f32(lo[k0 + 2] * mlo, lo[k0 + 3] * mlo, c, true);
-        ph[w] = a; pl[w] = c;
-      }
-      *reinterpret_cast<int4*>(out + slotB + (long)(f8_piece0 + (b & 1)) * 1024 + (hk * 32 + li) * 16) = make_int4(ph[0], ph[1], ph[2], ph[3]);
-      *reinterpret_cast<int4*>(out + slotB + (long)(f8_piece0 + 2 + (b & 1)) * 1024 + (hk * 32 + li) * 16) = make_int4(pl[0], pl[1], pl[2], pl[3]);
-    }
-    // scale word of lane (li, hk = b & 1): the lane that supplies this block's scale to the instruction
-    const int entry = second ? 64 + (b >> 1) * 8 + tile : tile * 4 + (b >> 1);
-    sc_out[entry * 64 + (b & 1) * 32 + li] = (unsigned)sh | ((unsigned)sl << 8);
-  }
-}
-
 int n_cus() {
   static int n = 0;
   if (n == 0) {
