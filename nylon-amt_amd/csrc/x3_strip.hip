@@ -136,7 +136,7 @@ struct XChunk { u4v a, b; };
 #define HFTT_STRIP_NT 0
 #endif
 __device__ __forceinline__ u4v stream_load16(const void* p) {
-#if HFTT_STRIP_NT
+#if HFTT_STRIP_NT == 1                               // (2: the hint on the result stores only)
   return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
 #else
   return *reinterpret_cast<const u4v*>(p);
