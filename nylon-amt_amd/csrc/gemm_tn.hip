@@ -102,6 +102,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
   static_assert(!DYD || !DYB, "the masked form takes an fp32 dY");
   const uint32_t dthr = hftt_keep_thr(g.drop_p);
   const float dinv = hftt_keep_scale(g.drop_p);
+  const uint64_t dkey = hftt_hash_key(g.drop_seed, g.drop_site);      // (wave-uniform: scalar registers)
   static_assert(!F32 || (!DYB && !XB), "bf16-stored operands: bf16 mode, or ONE side of a split-bf16 product");
   // x3 with a bf16-stored operand (the saved FFN hidden / its gradient, kept as bf16 for this product only): that operand IS its hi
   // half, the lo half is zero and the pass that would multiply it is skipped (two MFMAs per fragment pair instead of three)
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const hftt_gemm_tn_desc g,
       const int row = i / YSPR;
       uint4 yv = (ycol_ok && mb + row < mend) ? yreg[j] : zero4;            // slots past the split / past N count as zeros
       if (DYD && g.drop_p > 0.f) {                    // elements (m, ycol .. ycol + 3) = one hash quad of the site's [M, N] tensor
-        const uint32_t w = hftt_hash(g.drop_seed, g.drop_site, ((uint64_t)(mb + row) * (uint64_t)g.N + (uint64_t)ycol) >> 2);
+        // quad index (m * N + ycol) / 4 in 32 bits with one full-rate 24-bit multiply (host: M < 2^24, M * N / 4 < 2^32: the hash's high index word is 0)
+        const uint32_t w = hftt_hash_mix(dkey, __umul24((uint32_t)(mb + row), (uint32_t)g.N >> 2) + ((uint32_t)ycol >> 2), 0u);
         yv.x = ((w & 0xFFu) < dthr) ? __float_as_uint(__uint_as_float(yv.x) * dinv) : 0u;
         yv.y = (((w >> 8) & 0xFFu) < dthr) ? __float_as_uint(__uint_as_float(yv.y) * dinv) : 0u;
         yv.z = (((w >> 16) & 0xFFu) < dthr) ? __float_as_uint(__uint_as_float(yv.z) * dinv) : 0u;
@@ -560,6 +562,7 @@ extern "C" int hftt_gemm_tn(const hftt_gemm_tn_desc* d, void* stream) {
 #endif
   } else if (d->npass == 4 && (d->io_flags & HFTT_TN_DY_DROP)) {
     HFTT_REQUIRE(!dyb && d->lddy == d->N && d->drop_p >= 0.f && d->drop_p < 1.f, "gemm_tn: HFTT_TN_DY_DROP takes an fp32 dY with lddy == N and 0 <= drop_p < 1");
+    HFTT_REQUIRE(d->M < (1 << 24) && d->N % 4 == 0 && (((int64_t)d->M * d->N) >> 2) < (1ll << 32), "gemm_tn: HFTT_TN_DY_DROP indexes the site with 32-bit quads (M < 2^24, M * N < 2^34)");
     if (p.tm == 2) rc = xb ? launch_tn<2, 4, 6, false, true>(*d, p, st) : launch_tn<2, 4, 6, false, false>(*d, p, st);
     else if (p.tn == 4) rc = xb ? launch_tn<1, 4, 6, false, true>(*d, p, st) : launch_tn<1, 4, 6, false, false>(*d, p, st);
     else { hftt_set_error("gemm_tn: HFTT_TN_DY_DROP covers N >= 256 and K >= 256 (got N=%d K=%d)", d->N, d->K); return 1; }

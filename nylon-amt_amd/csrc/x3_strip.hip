@@ -125,15 +125,17 @@ struct XPipe {
 
 // a strip chunk: 8 features of the lane's token in 8 registers -- raw fp32 (a = first four, b = last four) or converted (a = hi, b = lo)
 struct XChunk { u4v a, b; };
-// Streaming accesses of the strip kernels, with an optional non-temporal hint (-DHFTT_STRIP_NT=1; OFF by default).  Why it exists: the
+// Streaming accesses of the strip kernels and the non-temporal hint (-DHFTT_STRIP_NT=0 none, 1 loads only, 2 result stores only = the default:
+// round 6, same box, three interleaved runs each way, 280.8 against 278.3 clips/s -- profiles/r06_ab_nontemporal_result_stores.txt).  Why: the
 // request-size counters (profiles/r04a_pmc_fetch_detail.json: all 128-byte requests, so FETCH_SIZE x 2 is exact here) show the QKV projection
 // fetching 1.58 x its activation bytes and the training FFN 1.49 x -- lines evicted from the 4 MB L2 between their uses (the weight stream
 // every 128-token block re-reads; 16-byte pieces of an activation line taken by different instructions) and fetched again from the fabric,
 // i.e. from the 256 MB Infinity Cache.  Measured with the hint on every strip load and result store (same box, paper-size step): the FFN's
 // fetch fell (225 -> 196 MB) but the QKV projection's rose (250 -> 283 MB) and the K = 768 dX form's rose from 698 to 909 MB -- a
-// non-temporal load does not keep the line for the next instruction's pieces -- and the step went from 266 to 251 clips/s.  Kept as a switch.
+// non-temporal load does not keep the line for the next instruction's pieces -- and the step went from 266 to 251 clips/s.  A result store
+// has no such second use inside the kernel (its consumer is a later launch, tens of MB of other traffic away), so the hint only spares L2 lines.
 #ifndef HFTT_STRIP_NT
-#define HFTT_STRIP_NT 0
+#define HFTT_STRIP_NT 2
 #endif
 __device__ __forceinline__ u4v stream_load16(const void* p) {
 #if HFTT_STRIP_NT == 1                               // (2: the hint on the result stores only)
