@@ -485,12 +485,18 @@ def resample_kernel_table(sr_in, sr_out, lowpass_filter_width=6, rolloff=0.99):
     return kern, up, down, width
 
 
+_RESAMPLE_TABLES = {}
+
+
 def resample(wave_mono, sr_in, sr_out):
     """wave [n] fp32 device tensor at sr_in -> [ceil(n * sr_out / sr_in)] at sr_out (hftt_resample: polyphase, fp32)."""
     _need_cuda(wave_mono)
-    kern, up, down, width = resample_kernel_table(sr_in, sr_out)
     wave = wave_mono.contiguous().float()
-    kd = kern.float().contiguous().to(wave.device)
+    key = (int(sr_in), int(sr_out), str(wave.device))
+    if key not in _RESAMPLE_TABLES:                  # (the table is a pure function of the two rates: built and uploaded once per device)
+        kern, up, down, width = resample_kernel_table(sr_in, sr_out)
+        _RESAMPLE_TABLES[key] = (kern.float().contiguous().to(wave.device), up, down, width)
+    kd, up, down, width = _RESAMPLE_TABLES[key]
     n = wave.numel()
     n_out = -(-n * up // down)
     out = torch.empty(n_out, device=wave.device)
