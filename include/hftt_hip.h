@@ -255,7 +255,7 @@ int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream);       /* mode 1 */
 /* ABI v7, npass 4, fp32 dY with N == lddy == the width of the dropped tensor: dY is the gradient of a dropout OUTPUT and the kernel applies
  * the mask of (drop_p, drop_site, drop_seed) while it loads it -- element (m, n) is element m * N + n of the site -- so that the LayerNorm
  * backward does not have to write a masked copy of its result for this product (hftt_ln_bwd with dr_drop == NULL); db = colsum of the
- * masked rows.  Tiles: N >= 256 and K >= 256. */
+ * masked rows.  Tiles: N >= 256 and K >= 256; the loader indexes the site's hash quads in 32 bits: M < 2^24 and M * N < 2^34 (status 1 beyond). */
 #define HFTT_TN_DY_DROP 8u
 typedef struct {
   int32_t M, N, K, npass;

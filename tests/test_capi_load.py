@@ -69,6 +69,15 @@ def test_argument_validation_without_gpu(lib):
         fs.x = fs.w = fs.y = 0x1000
         assert fn(C.byref(fs), None) != 0
         assert b'all-bf16' in lib.hftt_last_error(), lib.hftt_last_error()
+    # the masked weight-gradient loader indexes its dropout site with 32-bit hash quads: a site beyond that range is refused, not wrapped
+    td = _capi.GemmTnDesc()
+    td.M, td.N, td.K, td.npass, td.lddy, td.ldx, td.n_seg = 1 << 24, 256, 256, 4, 256, 256, 1
+    td.io_flags, td.drop_p, td.K_out, td.out_scale = 8, 0.1, 256, 1.0      # HFTT_TN_DY_DROP
+    td.dY = td.X = td.ws = 0x1000
+    td.ws_bytes = lib.hftt_gemm_tn_ws_bytes(td.M, td.N, td.K)
+    td.seg_dw[0], td.seg_rows[0] = 0x1000, 256
+    rc = lib.hftt_gemm_tn(C.byref(td), None)
+    assert rc != 0 and b'32-bit quads' in lib.hftt_last_error(), lib.hftt_last_error()
     with pytest.raises(_capi.HfttError):
         _capi.check(1, 'x')
 
