@@ -1,7 +1,7 @@
 """dev: x3 / exact-fp32 modes against the CPU checker on configurations the test-suite does not use (generic x3 path at d = 256 with ff = 1024,
 d = 128, odd batch), dropout 0: every output tensor's max |difference| and magnitude."""
 import sys, os, torch
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'nylon-amt_amd'))
 import util
 from util import O, OUT_NAMES

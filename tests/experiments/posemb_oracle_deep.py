@@ -1,5 +1,5 @@
 """CPU experiment (round 5): as posemb_oracle_mini.py at the paper's width and depth (d 256, ff 512, 3+3 layers, 4 heads) on short
-axes.   python tools/experiments/posemb_oracle_deep.py <position-table scale> <steps> <lr>"""
+axes.   python tests/experiments/posemb_oracle_deep.py <position-table scale> <steps> <lr>"""
 import sys, time, math
 import os; R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0]=[os.path.join(R,'tests'),os.path.join(R,'nylon-amt_amd'),R]
 import torch, util

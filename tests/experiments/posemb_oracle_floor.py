@@ -1,5 +1,5 @@
 """CPU experiment (round 5): as posemb_oracle_mini.py on FLOOR-dominated clips (most bins at the log-mel floor -18.42, sparse
-active bands: the shape of the plucked-string corpus).   python tools/experiments/posemb_oracle_floor.py 1 30 300 3000"""
+active bands: the shape of the plucked-string corpus).   python tests/experiments/posemb_oracle_floor.py 1 30 300 3000"""
 import sys, time, math
 import os; R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0]=[os.path.join(R,'tests'),os.path.join(R,'nylon-amt_amd'),R]
 import torch, util

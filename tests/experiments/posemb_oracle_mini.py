@@ -1,6 +1,6 @@
 """CPU experiment (round 5): the reference's own step (oracle forward, train.py loss, torch Adam, fp32, dropout 0) on the
 convergence test's clips at the mini size, with the three position tables multiplied by 1 / 30 / 300 at initialisation.  Prints
-(step, mean loss, held-out ranking AUC, held-out frame-F1) per 100 steps.   python tools/experiments/posemb_oracle_mini.py"""
+(step, mean loss, held-out ranking AUC, held-out frame-F1) per 100 steps.   python tests/experiments/posemb_oracle_mini.py"""
 import sys, time, math
 import os; R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0]=[os.path.join(R,'tests'),os.path.join(R,'nylon-amt_amd'),R]
 import torch, util

@@ -86,6 +86,23 @@ def test_no_cpu_fallback():
     assert 'oracle' not in src                      # the product path never touches the oracle
 
 
+def test_only_tests_smoke_and_the_cpu_baseline_reach_the_oracle():
+    """oracle/ is test infrastructure: no file of the package or of tools/ imports it, directly or through tests/util (which holds it as `O`)."""
+    import os
+    import re
+    pat = re.compile(r'^\s*(from oracle|import oracle|import util\b|from util import|import test_)', re.M)
+    offenders = []
+    for top in ('nylon-amt_amd', 'tools'):
+        for dp, dn, fn in os.walk(os.path.join(util.ROOT, top)):
+            dn[:] = [d for d in dn if d not in ('__pycache__', 'build', 'lib')]
+            for f in fn:
+                if f.endswith(('.py', '.sh')):
+                    src = open(os.path.join(dp, f), errors='replace').read()
+                    if pat.search(src) or re.search(r'oracle[/.]hftt_oracle', src):
+                        offenders.append(os.path.relpath(os.path.join(dp, f), util.ROOT))
+    assert offenders == [], offenders
+
+
 def test_bench_measured_leg_is_oracle_free_and_configs_match():
     """bench.py may use oracle/ only for its reported cpu_baseline; its own workload tables must equal the oracle's configurations
     (both restate m_training.py's defaults), and its model builder must produce the reference's parameter set."""
