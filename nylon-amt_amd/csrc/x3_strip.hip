@@ -381,8 +381,11 @@ __device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_
 // ---------------------------------------------------------------------------------------------------------------------
 // C = epi(x . Wl^T + bias), fp32 tensors, K = 256 * KCH, N = 256 * PASSES; LN: N == 256 with dropout / residual / LayerNorm
 // ---------------------------------------------------------------------------------------------------------------------
-template <int E, bool LN, int PASSES, int KCH, bool HR>
-__global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc g) {
+// XR: strip chunks resident per wave.  16 = a whole 256-feature set (one wave per SIMD, 512 registers); 8 = half a set (PASSES == 1, no LayerNorm):
+// chunk c + 8 is loaded into the registers of chunk c one slot after it was consumed, the kernel fits 256 registers and TWO workgroups share a CU.
+template <int E, bool LN, int PASSES, int KCH, bool HR, int XR = 16>
+__global__ __launch_bounds__(256, XR == 16 ? 1 : 2) void x3_linear_kernel(const hftt_strip_desc g) {
+  static_assert(XR == 16 || (XR == 8 && PASSES == 1 && !LN), "the half-set form reloads every set (one pass); the LayerNorm epilogue does not fit 256 registers");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -408,11 +411,11 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
 
   for (int i = tid; i < g.N; i += 256) prm[i] = g.bias != nullptr ? g.bias[i] : 0.f;
   if (LN) { prm[g.N + tid] = g.ln_gamma[tid]; prm[g.N + 256 + tid] = g.ln_beta[tid]; }
-  XChunk xr[16];
+  XChunk xr[XR];
   {
     const float* p0 = xb + tok_of(blockIdx.x) * g.ldx + 16 * h;
 #pragma unroll
-    for (int c = 0; c < 16; c++) chunk_load(xr[c], p0 + chunk_off(c));
+    for (int c = 0; c < XR; c++) chunk_load(xr[c], p0 + chunk_off(c));
   }
   P.fill<0>(); P.fill<1>(); P.fill<2>();
   static_assert(FILL_AHEAD == 3, "prologue fills");
@@ -455,19 +458,25 @@ __global__ __launch_bounds__(256, 1) void x3_linear_kernel(const hftt_strip_desc
         const bool convert = ((KCH > 1) || (pass == 0)) && !dbg_noconv;
         // (past the last block: a harmless re-read of this block's rows)
         const float* nsrc = xb + lane_tok(last_step ? (nxt < nblk ? nxt : blk) : blk) * g.ldx + 16 * hb + (last_step ? 0 : ((kc + 1 == KCH) ? 0 : kc + 1) * 256);
+        const float* csrc = (XR == 16) ? nsrc : xb + lane_tok(blk) * g.ldx + 16 * hb + kc * 256;       // XR == 8: the second half of THIS step's set
         static_for<16>([&](auto c_c) __attribute__((always_inline)) {
           constexpr int c = decltype(c_c)::value;
           constexpr int BUF = c & 3;
           P.begin_slot();
-          x3_slot_tiles<E>(abase + BUF * SLOT_BYTES, abase + ((BUF + 1) & 3) * SLOT_BYTES, pre, xr[c], acc, [&](auto i_c) __attribute__((always_inline)) {
+          x3_slot_tiles<E>(abase + BUF * SLOT_BYTES, abase + ((BUF + 1) & 3) * SLOT_BYTES, pre, xr[c % XR], acc, [&](auto i_c) __attribute__((always_inline)) {
             constexpr int i = decltype(i_c)::value;
             if (i == 1) P.template refill<BUF>();
-            if (i == 5 && c > 0) { if (reload) chunk_load(xr[c - 1], nsrc + chunk_off(c - 1)); }
-            if (i == 9 && c < 15) { if (convert) chunk_convert<E>(xr[c + 1]); }
+            if (XR == 16) {
+              if (i == 5 && c > 0) { if (reload) chunk_load(xr[(c - 1) % XR], nsrc + chunk_off(c - 1)); }
+            } else {                                  // the registers of chunk c - 1 take chunk c - 1 + XR (of this set, then of the next)
+              if (i == 5 && c > 0) chunk_load(xr[(c - 1) % XR], (c - 1 + XR < 16) ? csrc + chunk_off((c - 1 + XR) & 15) : nsrc + chunk_off((c - 1 + XR) & 15));
+            }
+            if (i == 9 && c < 15) { if (convert) chunk_convert<E>(xr[(c + 1) % XR]); }
           });
         });
-        // the last chunk of the set is replaced here, and chunk 0 of the next set converted (its load is 15 slots old)
-        if (reload) chunk_load(xr[15], nsrc + chunk_off(15));
+        // the last chunk of the set is replaced here, and chunk 0 of the next set converted (its load is 15 slots old; XR == 8: 7 slots)
+        if (XR == 16) { if (reload) chunk_load(xr[15], nsrc + chunk_off(15)); }
+        else chunk_load(xr[XR - 1], nsrc + chunk_off(XR - 1));
         if (((KCH > 1) || last_step) && !dbg_noconv) chunk_convert<E>(xr[0]);
       }
       // ---------------- epilogue of this pass ----------------
@@ -872,15 +881,24 @@ int set_lds(K kernel, int lds, const char* what) {
   if (e != hipSuccess) { hftt_set_error("%s: hipFuncSetAttribute(%d B LDS) failed: %s", what, lds, hipGetErrorString(e)); return 2; }
   return 0;
 }
+// Resident strip chunks of the one-pass K-outer forms without LayerNorm (the K = 512 / 768 dX products): 8 = half a set, 256 registers (24 bytes
+// of scratch on the K = 768 residual form), two workgroups per CU -- one's epilogue under the other's MFMAs.  Same box, three interleaved runs each
+// way: 277.07 against 276.17 clips/s (+0.3 %, profiles/r06_ab_dx_two_workgroups.txt).  The LayerNorm form (fc_o + residual + LayerNorm) stays at
+// 16: at 256 registers its epilogue spills (620 B per lane with 8 chunks, 468 B with 4, 332 B with the next block's strip loaded only behind
+// the epilogue) and the step LOSES 1.1 - 1.2 % in every one of those forms (same file).
+#ifndef HFTT_XL_XR
+#define HFTT_XL_XR 8
+#endif
 template <int E, bool LN, int PASSES, int KCH, bool HR>
 int launch_xl(const hftt_strip_desc& d, hipStream_t st) {
+  constexpr int XR = (PASSES == 1 && !LN) ? HFTT_XL_XR : 16;
   const int lds = RING_BYTES + 4 * (PASSES * 256 + 512) + 4 * STG_BYTES_PER_WAVE;
   static int attr = 0;
-  if (lds > attr) { if (int rc = set_lds(x3_linear_kernel<E, LN, PASSES, KCH, HR>, lds, "x3_strip_linear")) return rc; attr = lds; }
-  const int cus = n_cus();
+  if (lds > attr) { if (int rc = set_lds(x3_linear_kernel<E, LN, PASSES, KCH, HR, XR>, lds, "x3_strip_linear")) return rc; attr = lds; }
+  const int cus = n_cus() * (XR == 16 ? 1 : 2);
   if (cus <= 0) { hftt_set_error("x3_strip_linear: device query failed"); return 2; }
   const long nblk = ((long)d.M + 127) / 128;
-  hipLaunchKernelGGL((x3_linear_kernel<E, LN, PASSES, KCH, HR>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
+  hipLaunchKernelGGL((x3_linear_kernel<E, LN, PASSES, KCH, HR, XR>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("x3_strip_linear");
   return 0;
 }

@@ -635,7 +635,8 @@ class HfttEngine:
             kname = 'bs_linear_kernel<%d, %d, %s, %s>' % (K // 32, N // 32, tf(ln is not None), tf(bool(residual)))
         elif self.x3:
             xe = (5 if self.g8 else 4) if self._in_backward else 2
-            kname = 'x3_linear_kernel<%d, %s, %d, %d, %s>' % (xe, tf(ln is not None), passes, kch, tf(bool(residual)))
+            # (last argument: resident strip chunks -- the one-pass forms without LayerNorm keep half a set and run two workgroups per CU: x3_strip.hip launch_xl)
+            kname = 'x3_linear_kernel<%d, %s, %d, %d, %s, %d>' % (xe, tf(ln is not None), passes, kch, tf(bool(residual)), 8 if (ln is None and passes == 1) else 16)
             if ln is None and kch == 1:
                 kname = 'x3_linear_n_kernel<%d, %d, %s, %s, %s>' % (xe, N // 32, tf(bool(residual)), tf(c_planes), tf(bool(x_drop_site)))
         meta = {'kernel': kname, 'flops': 2.0 * M * N * K, 'bytes': float(nbytes), 'shape': (M, N, K)}
