@@ -351,8 +351,11 @@ def test_attention_on_planes_shared_query(dev):
 # strip kernels of the x3 mode (csrc/x3_strip.hip): token strips as (hi, lo) register pairs, split weight fragments through the ring
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('elem', [2, 4])
-@pytest.mark.parametrize('M,N,K', [(384, 256, 256), (1056, 768, 256), (640, 512, 256), (416, 256, 512), (992, 256, 768), (40000, 768, 256)])
+@pytest.mark.parametrize('M,N,K', [(384, 256, 256), (1056, 768, 256), (640, 512, 256), (416, 256, 512), (992, 256, 768), (40000, 768, 256),
+                                   (70048, 256, 768), (70048, 256, 512), (70048, 768, 256)])
 def test_strip_linear(dev, M, N, K, elem):
+    """(M = 70,048 = 548 blocks of 128 tokens, the last one ragged: more blocks than the 512 workgroups the two-per-CU forms keep resident, so the
+    path that hands a workgroup its NEXT block -- strip chunks loaded across the block boundary -- runs under a reference too, not only in the bench.)"""
     ops = _ops()
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
@@ -374,9 +377,10 @@ def test_strip_linear(dev, M, N, K, elem):
 
 @pytest.mark.parametrize('elem', [2, 4])
 @pytest.mark.parametrize('K', [256, 512])
-def test_strip_linear_layernorm(dev, K, elem):
+@pytest.mark.parametrize('M', [1120, 40032])       # 40,032 tokens = 313 blocks: more than the 256 resident workgroups (next-block strip prefetch)
+def test_strip_linear_layernorm(dev, K, elem, M):
     ops = _ops()
-    M, N = 1120, 256
+    N = 256
     g = torch.Generator().manual_seed(K)
     x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
     res = torch.randn(M, N, generator=g) * 3.0; gam = torch.randn(N, generator=g); bet = torch.randn(N, generator=g)
