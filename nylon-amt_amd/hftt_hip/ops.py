@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ._capi import (AttnDesc, FfnDesc, GemmNtDesc, GemmTnDesc, HfttError, LnBwdDesc, LogmelDesc, LossDesc, ResampleDesc, PrepEntry, StripDesc, StripPackEntry,
-                    SL_C_BF16, SL_C_F16PAIR, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16,
+                    SL_C_BF16, SL_C_F16PAIR, SL_H_BF16, SL_PRE_BF16, SL_RELU, SL_X3_GRAD_HI, SL_RES_BF16, SL_X_BF16, SL_X3_F16, SL_X3_BF16, SL_X_DROP,
                     ATTN_Q_F16PAIR, ATTN_KV_F16PAIR, check, lib)
 
 
@@ -27,7 +27,7 @@ def _need_cuda(*ts):
 
 BF16 = torch.bfloat16
 NT_A_BF16, NT_C_BF16, NT_GATE_BF16, NT_RES_BF16, NT_A_HI = 1, 2, 4, 8, 16
-TN_DY_BF16, TN_X_BF16, TN_DY_HI = 1, 2, 4
+TN_DY_BF16, TN_X_BF16, TN_DY_HI, TN_DY_DROP = 1, 2, 4, 8
 ATTN_Q_BF16, ATTN_KV_BF16, ATTN_O_BF16, ATTN_DQ_BF16, ATTN_DKV_BF16 = 1, 2, 4, 8, 16
 
 
@@ -189,9 +189,11 @@ def x3s_ffn_pack(w1: torch.Tensor, w2: torch.Tensor, backward=False, bf16=False)
 
 
 def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, drop_seed=0,
-                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0, pre_bf16=False, grad_hi=False, c_planes=False):
+                 residual=None, res_mod=0, ln=None, out_dtype=BF16, save_pre=True, x3=0, pre_bf16=False, grad_hi=False, c_planes=False, x_drop=False):
     """C = epi(x @ Wl.T + bias) with Wl given as its strip pack.  ln = (gamma, beta) -> (C, pre_ln, mean, rstd).
-    x3 = 2 / 4: the split-operand form (fp32 tensors, wpack from x3_strip_pack with the same element type)."""
+    x3 = 2 / 4: the split-operand form (fp32 tensors, wpack from x3_strip_pack with the same element type).
+    x_drop (x3 = 4, N == K == 256): HFTT_SL_X_DROP -- x is the gradient of a dropout output; the mask of (drop_p, drop_site, drop_seed) is applied
+    to x while it is loaded (no dropout on the result)."""
     _need_cuda(x, wpack)
     M, K = x.shape
     if x3:
@@ -201,7 +203,8 @@ def strip_linear(x, wpack, N, bias=None, relu=False, out_scale=1.0, gate=None, g
     d.M, d.N, d.K = M, N, K
     d.flags = (SL_X_BF16 if x.dtype == BF16 else 0) | (SL_C_BF16 if out_dtype == BF16 else 0) | (SL_RELU if relu else 0) \
         | (SL_RES_BF16 if (residual is not None and residual.dtype == BF16) else 0) | (SL_X3_F16 if x3 == 2 else 0) | (SL_X3_BF16 if x3 == 4 else 0) \
-        | (SL_PRE_BF16 if (x3 and pre_bf16 and ln is not None) else 0) | (SL_X3_GRAD_HI if (x3 == 4 and grad_hi) else 0) | (SL_C_F16PAIR if c_planes else 0)
+        | (SL_PRE_BF16 if (x3 and pre_bf16 and ln is not None) else 0) | (SL_X3_GRAD_HI if (x3 == 4 and grad_hi) else 0) | (SL_C_F16PAIR if c_planes else 0) \
+        | (SL_X_DROP if x_drop else 0)
     d.x, d.ldx, d.w = x.data_ptr(), x.stride(0), wpack.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else 0
     d.C, d.ldc, d.out_scale, d.gate_scale = Cout.data_ptr(), N, out_scale, gate_scale
@@ -249,8 +252,9 @@ def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_
     return y, hid, pre, mean, rstd
 
 
-def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False, grad_hi=False):
-    """dh = (hidden > 0) * (dy @ fc_2.weight) * gate_scale;  dx = dh @ fc_1.weight (+ residual) -> (dx, dh); all bf16 (x3: all fp32)."""
+def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False, grad_hi=False, dy_drop=None):
+    """dh = (hidden > 0) * (dy @ fc_2.weight) * gate_scale;  dx = dh @ fc_1.weight (+ residual) -> (dx, dh); all bf16 (x3: all fp32).
+    dy_drop = (p, site, seed) (x3): dy is the gradient of the block's OUTPUT dropout and is masked with that site while it is loaded."""
     _need_cuda(dy, wpack_bwd, hidden)
     M, dm = dy.shape
     dt = torch.float32 if x3 else BF16
@@ -262,6 +266,8 @@ def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False
     d.x, d.ldx, d.w = dy.data_ptr(), dy.stride(0), wpack_bwd.data_ptr()
     d.h_out, d.ldh = dh.data_ptr(), p
     d.gate, d.ldg, d.gate_scale = hidden.data_ptr(), hidden.stride(0), gate_scale
+    if dy_drop is not None:
+        d.drop_p, d.site_o, d.drop_seed = dy_drop
     if residual is not None:
         d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
     d.y, d.ldy = dx.data_ptr(), dm
@@ -269,8 +275,9 @@ def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False
     return dx, dh
 
 
-def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True, grad_hi=False):
-    """dW[N,K] = out_scale * dY[M,N].T @ X[M,K]; db[N] = colsum(dY)."""
+def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True, grad_hi=False, dy_drop=None):
+    """dW[N,K] = out_scale * dY[M,N].T @ X[M,K]; db[N] = colsum(dY).
+    dy_drop = (p, site, seed) (npass 4, fp32 dY): HFTT_TN_DY_DROP -- dY is masked with that dropout site while it is loaded."""
     _need_cuda(dY, X)
     M, N = dY.shape
     K = X.shape[1]
@@ -283,7 +290,10 @@ def gemm_tn(dY, X, npass=3, out_scale=1.0, with_bias=True, grad_hi=False):
     d.M, d.N, d.K, d.npass = M, N, K, npass
     d.dY, d.lddy, d.X, d.ldx = dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0)
     d.out_scale, d.beta, d.n_seg = out_scale, 0.0, 1
-    d.io_flags = (TN_DY_BF16 if dY.dtype == BF16 else 0) | (TN_X_BF16 if X.dtype == BF16 else 0) | (TN_DY_HI if (grad_hi and dY.dtype != BF16) else 0)
+    d.io_flags = (TN_DY_BF16 if dY.dtype == BF16 else 0) | (TN_X_BF16 if X.dtype == BF16 else 0) | (TN_DY_HI if (grad_hi and dY.dtype != BF16) else 0) \
+        | (TN_DY_DROP if dy_drop is not None else 0)
+    if dy_drop is not None:
+        d.drop_p, d.drop_site, d.drop_seed = dy_drop
     d.seg_row0[0], d.seg_rows[0], d.seg_dw[0], d.seg_db[0] = 0, N, dW.data_ptr(), (db.data_ptr() if with_bias else 0)
     d.K_out = K
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4

@@ -404,6 +404,60 @@ def test_strip_linear_layernorm(dev, K, elem, M):
     assert max_err(out3, out) == 0.0 and max_err(mean3, mean) == 0.0 and max_err(rstd3, rstd) == 0.0
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The three consumers of a LayerNorm backward's result that mask it with the dropout site WHILE THEY LOAD IT (round 6: the LayerNorm backward
+# writes no masked copy): HFTT_SL_X_DROP (fc_o dX), HFTT_TN_DY_DROP (weight-gradient product), site_o of hftt_ffn_bwd_dx.  Each against fp64
+# on the masked input, with more token blocks than resident workgroups and -- for the product -- a site of 2^26 elements (32-bit quad index).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M', [992, 70048])
+def test_strip_linear_masks_a_dropout_gradient_on_load(dev, M):
+    ops = _ops()
+    N = K = 256
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    p, site, seed = 0.1, 21, 777
+    xm = x.double() * keep_mask_t(seed, site, (M, K), p).double() * keep_scale(p)
+    wp = ops.x3_strip_pack(W.to(dev), 4, order=1)
+    out = ops.strip_linear(x.to(dev), wp, N, None, drop_p=p, drop_site=site, drop_seed=seed, x3=4, x_drop=True)
+    assert rel_err(out, xm @ W.double().T) < TOL[4]
+    wrong = ops.strip_linear(x.to(dev), wp, N, None, drop_p=p, drop_site=site + 1, drop_seed=seed, x3=4, x_drop=True)
+    assert rel_err(wrong, xm @ W.double().T) > 0.1            # (the neighbouring site is a different mask)
+
+
+@pytest.mark.parametrize('x_bf', [False, True])
+@pytest.mark.parametrize('M,N,K', [(5000, 256, 256), (5000, 256, 512), (262144, 256, 256)])
+def test_gemm_tn_masks_a_dropout_gradient_on_load(dev, M, N, K, x_bf):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K)
+    dY = torch.randn(M, N, generator=g); X = torch.randn(M, K, generator=g)
+    if x_bf:
+        X = X.bfloat16()
+    p, site, seed = 0.1, 5, 31337
+    dYm = dY.double() * keep_mask_t(seed, site, (M, N), p).double() * keep_scale(p)
+    dW, db = ops.gemm_tn(dY.to(dev), X.to(dev), npass=4, out_scale=0.5, dy_drop=(p, site, seed))
+    assert rel_err(dW, 0.5 * dYm.T @ X.double()) < TOL[4]
+    assert rel_err(db, 0.5 * dYm.sum(0)) < 3e-5
+    dW0, db0 = ops.gemm_tn(dY.to(dev), X.to(dev), npass=4, out_scale=0.5, dy_drop=(0.0, site, seed))      # p = 0: the unmasked product
+    assert rel_err(dW0, 0.5 * dY.double().T @ X.double()) < TOL[4] and rel_err(db0, 0.5 * dY.double().sum(0)) < 3e-5
+
+
+@pytest.mark.parametrize('M', [992, 33024])
+def test_fused_ffn_dx_masks_the_output_dropout_gradient_on_load(dev, M):
+    ops = _ops()
+    d, pf = 256, 512
+    g = torch.Generator().manual_seed(M + 1)
+    dy = torch.randn(M, d, generator=g); hid = torch.randn(M, pf, generator=g)
+    W1 = torch.randn(pf, d, generator=g) / math.sqrt(d); W2 = torch.randn(d, pf, generator=g) / math.sqrt(pf)
+    res = torch.randn(M, d, generator=g)
+    p, site, seed = 0.1, 9, 4711
+    wb = ops.x3_ffn_pack(W1.to(dev), W2.to(dev), backward=True)
+    dym = dy.double() * keep_mask_t(seed, site, (M, d), p).double() * keep_scale(p)
+    dh_ref = (hid.double() > 0) * (dym @ W2.double()) * 1.25
+    dx, dh = ops.ffn_bwd_dx(dy.to(dev), wb, pf, hid.to(dev), gate_scale=1.25, residual=res.to(dev), x3=True, dy_drop=(p, site, seed))
+    assert rel_err(dh, dh_ref) < TOL[4]
+    assert rel_err(dx, dh_ref @ W1.double() + res.double()) < TOL[4]
+
+
 @pytest.mark.parametrize('side', ['dY', 'X'])
 @pytest.mark.parametrize('M,N,K', [(5000, 256, 512), (5000, 512, 256), (1000, 192, 256), (777, 128, 96), (88, 64, 64), (3000, 256, 256)])
 def test_gemm_tn_with_one_operand_stored_as_bf16(dev, M, N, K, side):
