@@ -285,6 +285,19 @@ def test_to_planes_and_the_projection_epilogue_write_the_same_bytes(dev):
         full = ops.strip_linear(xx.to(dev), wp, N, b.to(dev), x3=2)
         pln = ops.strip_linear(xx.to(dev), wp, N, b.to(dev), x3=2, c_planes=True)
         assert torch.equal(pln.view(torch.int32), ops.to_planes(full).view(torch.int32)), (M, N)
+    # N = 1024 / 1536 (the cross-attention K / V projections of two / three decoder layers as ONE launch, round 6) exist as planes only: against
+    # the fp32 results of the same rows of W taken 768 columns at a time (an output tile depends on its own rows of W only); 70,048 tokens =
+    # 548 blocks for 512 resident workgroups
+    for M, N in ((640, 1024), (1056, 1536), (70048, 1536)):
+        xx = torch.randn(M, 256, generator=g); W = torch.randn(N, 256, generator=g) / 16.0; b = torch.randn(N, generator=g)
+        pln = ops.strip_linear(xx.to(dev), ops.x3_strip_pack(W.to(dev), 2, order=1), N, b.to(dev), x3=2, c_planes=True)
+        parts = []
+        for n0 in range(0, N, 768):
+            n1 = min(N, n0 + 768)
+            parts.append(ops.strip_linear(xx.to(dev), ops.x3_strip_pack(W[n0:n1].contiguous().to(dev), 2, order=1), n1 - n0, b[n0:n1].contiguous().to(dev), x3=2))
+        full = torch.cat(parts, 1).contiguous()
+        assert torch.equal(pln.view(torch.int32), ops.to_planes(full).view(torch.int32)), (M, N)
+        assert rel_err(full, xx.double() @ W.double().T + b.double()) < TOL[2]
 
 
 PLANE_GEOMS = [(5, 4, 256, 256), (37, 4, 256, 256), (80, 4, 256, 256), (5, 4, 88, 256), (300, 4, 88, 256), (5, 4, 88, 88), (6, 4, 128, 128), (700, 2, 128, 128), (3, 2, 48, 48),
