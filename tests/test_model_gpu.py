@@ -334,6 +334,9 @@ DROPOUT_CASES = {
                                     enc_head=2, dec_head=2, n_note=12, n_velocity=16)),
     'x3_256': ('x3', O.HfttConfig(n_frame=16, n_bin=32, n_note=8, **_WIDE)),
     'x3_256_long': ('x3', O.HfttConfig(n_frame=8, n_bin=256, n_note=40, **_WIDE)),
+    # three decoder layers (the paper's depth): the cross-attention K / V projections of all layers as ONE launch (N = 1536) and, in the backward, ONE
+    # weight-gradient product with six segments + the encoder-output gradient as two K = 768 products (round 6) -- every gradient, not samples
+    'x3_256_dec3': ('x3', O.HfttConfig(n_frame=16, n_bin=32, n_note=8, **dict(_WIDE, dec_layer=3))),
 }
 
 
@@ -381,6 +384,12 @@ def test_dropout_on_outputs_and_gradients_with_the_device_masks_exported_to_the_
                 assert 'x3p_attn_fwd_kernel<8, 4, true, 1>' in fk, fk      # cross attention of the last decoder layer (writes the attention map)
             else:
                 assert 'x3_attn_bwd_kernel<1, 64, true, 1>' in bk, bk
+            if case == 'x3_256_dec3':
+                assert eng.merge_ckv and eng.merge_ckv_bwd
+                assert 'x3_linear_n_kernel<2, 48, false, true, false>' in fk, fk           # the stacked K / V projection
+                assert sum(k == 'x3_linear_kernel<4, false, 1, 3, true, 8>' for k in bk) >= 2 and 'x3_linear_kernel<4, false, 1, 3, false, 8>' in bk, bk
+            elif case in ('x3_256', 'x3_256_long'):
+                assert eng.merge_ckv and not eng.merge_ckv_bwd
     seed, n_sites = ws['seed'], eng._site
 
     def oracle_with_sites(order):
