@@ -266,8 +266,12 @@ __device__ __forceinline__ void store16f(float* p, const float* v) {
 // way (HFTT_X3_DEBUG=16).  LDS operations of one wave execute in order, so the patch needs no barrier.
 constexpr int STG_RS = 36;                            // floats per staged row (144 B: the 16-byte row pieces of 8 rows fall on 8 different bank quads)
 constexpr int STG_BYTES_PER_WAVE = 16 * STG_RS * 4;
+// Addresses: gtile and the row-group offset (16 * half + 8 * k) * ld are wave-uniform (scalar registers, scalar multiplies); the lane's own part
+// is the 32-bit element offset ro = (lane >> 3) * ld + 4 * (lane & 7), one full-rate 24-bit multiply per call.  (Formed as 64-bit (row * ld) per
+// lane and store, the epilogue of the fc_o + LayerNorm kernel spent 236 v_mul_lo_u32 and 114 v_mad_u64_u32 -- quarter-rate -- on addresses.)
 __device__ __forceinline__ void tile_store_rows(float* stage, const float* v, int j, int h, int lane, float* gtile, long ld, bool ok) {
-  asm volatile("" : "+v"(lane));                    // (row * ld is formed per call: hoisted out of the block loop it is a spilled 64-bit value per row group)
+  asm volatile("" : "+v"(lane));                    // (formed per call: hoisted out of the block loop the per-lane offsets of every tensor are spilled)
+  const unsigned ro = __umul24((unsigned)lane >> 3, (unsigned)ld) + ((unsigned)lane & 7u) * 4u;
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     if ((j >> 4) == half) {
@@ -279,7 +283,7 @@ __device__ __forceinline__ void tile_store_rows(float* stage, const float* v, in
     for (int k = 0; k < 2; k++) {
       const int r = (lane >> 3) + 8 * k;
       const float4 t = *reinterpret_cast<const float4*>(stage + r * STG_RS + (lane & 7) * 4);
-      if (ok) stream_store16(gtile + (long)(half * 16 + r) * ld + (lane & 7) * 4, __builtin_bit_cast(u4v, t));
+      if (ok) stream_store16(gtile + (long)(half * 16 + 8 * k) * ld + ro, __builtin_bit_cast(u4v, t));
     }
   }
 }
@@ -287,7 +291,8 @@ __device__ __forceinline__ void tile_store_rows(float* stage, const float* v, in
 // The same tile as bf16 (the saved FFN hidden and its gradient: operands of the weight-gradient products only, HFTT_SL_H_BF16): 64-byte row
 // segments, 16 rows x 4 lanes per store instruction, through the same patch (rows of 40 shorts = 80 B: 16-byte pieces, 8 rows on 8 bank quads).
 __device__ __forceinline__ void tile_store_rows_bf16(float* stage, const float* v, int j, int h, int lane, unsigned short* gtile, long ld, bool ok) {
-  asm volatile("" : "+v"(lane));                    // (row * ld is formed per call: hoisted out of the block loop it is a spilled 64-bit value per row group)
+  asm volatile("" : "+v"(lane));                    // (formed per call, as in tile_store_rows)
+  const unsigned ro = __umul24((unsigned)lane >> 2, (unsigned)ld) + ((unsigned)lane & 3u) * 8u;
   unsigned short* st16 = reinterpret_cast<unsigned short*>(stage);
   constexpr int RS = 40;
 #pragma unroll
@@ -304,14 +309,15 @@ __device__ __forceinline__ void tile_store_rows_bf16(float* stage, const float* 
     }
     const int r = lane >> 2;
     const uint4 t = *reinterpret_cast<const uint4*>(st16 + r * RS + (lane & 3) * 8);
-    if (ok) stream_store16(gtile + (long)(half * 16 + r) * ld + (lane & 3) * 8, __builtin_bit_cast(u4v, t));
+    if (ok) stream_store16(gtile + (long)(half * 16) * ld + ro, __builtin_bit_cast(u4v, t));
   }
 }
 // The same tile as an f16 PAIR (HFTT_SL_C_F16PAIR: the q / k / v projections, read by the attention kernels as MFMA operands without any
 // further conversion -- x3_attn_pl.hip): the tile's 128 bytes per row hold its 32 hi halves (64 B), then its 32 lo halves -- the same
 // whole-line row segments as the fp32 form, through the same patch.
 __device__ __forceinline__ void tile_store_rows_f16pair(float* stage, const float* v, int j, int h, int lane, float* gtile, long ld, bool ok) {
-  asm volatile("" : "+v"(lane));                    // (row * ld is formed per call: hoisted out of the block loop it is a spilled 64-bit value per row group)
+  asm volatile("" : "+v"(lane));                    // (formed per call, as in tile_store_rows)
+  const unsigned ro = __umul24((unsigned)lane >> 3, (unsigned)ld) + ((unsigned)lane & 7u) * 4u;
   bf16x8 hi0, lo0, hi1, lo1;
   x3_split8<X3_F16>(v, hi0, lo0);
   x3_split8<X3_F16>(v + 8, hi1, lo1);
@@ -328,7 +334,7 @@ __device__ __forceinline__ void tile_store_rows_f16pair(float* stage, const floa
     for (int k = 0; k < 2; k++) {
       const int r = (lane >> 3) + 8 * k;
       const float4 t = *reinterpret_cast<const float4*>(stage + r * STG_RS + (lane & 7) * 4);
-      if (ok) stream_store16(gtile + (long)(half * 16 + r) * ld + (lane & 7) * 4, __builtin_bit_cast(u4v, t));
+      if (ok) stream_store16(gtile + (long)(half * 16 + 8 * k) * ld + ro, __builtin_bit_cast(u4v, t));
     }
   }
 }
