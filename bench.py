@@ -693,9 +693,12 @@ def main():
                                      'bytes': sum(m_['bytes'] for m_, _ in sel), 'stalls': 0}
                             rf = roofline_object(k_ffn, v_sel, 3, PEAK_BF16_TFLOPS, tot_inf, kind='inference', mfma_passes=3 if precision == 'x3' else 1,
                                                  shape=sel[0][0]['shape'], live_mode=precision)
-                            rf['entry_point'] = 'hftt_ffn_res_ln_fwd'
+                            fused = bool(sel[0][0].get('fused'))       # round 6: fc_o + residual + LayerNorm + FFN as one launch (flops and bytes of both halves)
+                            rf['entry_point'] = 'hftt_attn_out_ffn_fwd' if fused else 'hftt_ffn_res_ln_fwd'
                             rf['precision_mode'] = precision
-                            rf['plan'] = 'inference (no hidden / pre-LN stores), tokens per launch %d' % sel[0][0]['shape'][0]
+                            rf['plan'] = 'inference (no hidden / pre-LN stores%s), tokens per launch %d' % (
+                                '; the attention output projection + LayerNorm in front of the block in the same launch, its output never written' if fused else '',
+                                sel[0][0]['shape'][0])
                             out['roofline_ffn'] = rf
                 model.hftt_freeze_weights(False)
                 return out

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HFTT_ABI_VERSION 7
+#define HFTT_ABI_VERSION 8
 
 int hftt_abi_version(void);
 /* bit 0: the library carries the opt-in gradient-rounding forms (HFTT_SL_X3_GRAD_HI, HFTT_TN_DY_HI, HFTT_NT_A_HI: a gradient operand enters a
@@ -242,6 +242,13 @@ typedef struct {
 } hftt_ffn_desc;
 int hftt_ffn_res_ln_fwd(const hftt_ffn_desc* d, void* stream);   /* mode 0 */
 int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream);       /* mode 1 */
+/* ABI v8 (split mode, HFTT_SL_X3_F16; d == 256, p == 512): the second half of a layer behind its attention as ONE launch --
+ *   x1 = LayerNorm(residual + dropout(ctx Wo^T + bo))          model_spec2midi.py:236-237 / :262-263 / :295-296   (descriptor o, exactly as for hftt_strip_linear)
+ *   y  = LayerNorm(x1 + dropout(FFN(x1)))                       model_spec2midi.py:240-242 / :266-268 / :299-301   (descriptor f, exactly as for hftt_ffn_res_ln_fwd)
+ * x1 stays in registers between the two halves: o->C may be NULL (inference plan: x1 is not written at all); when it is given it must be f->x.
+ * f->w must be o->w + 16 slots (one weight stream of 80 slots per 128-token block: fc_o in order 0, then the FFN's interleaved pair).
+ * Results are bit-identical to hftt_strip_linear(o) followed by hftt_ffn_res_ln_fwd(f). */
+int hftt_attn_out_ffn_fwd(const hftt_strip_desc* o, const hftt_ffn_desc* f, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * TN GEMM (weight gradient):  dW[N,K] = out_scale * dY[M,N]^T . X[M,K],  db[N] = colsum(dY)

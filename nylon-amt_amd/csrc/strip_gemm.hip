@@ -704,6 +704,11 @@ extern "C" int hftt_ffn_res_ln_fwd(const hftt_ffn_desc* d, void* stream) {
   return launch_mlp<0>(*d, st);
 }
 
+extern "C" int hftt_attn_out_ffn_fwd(const hftt_strip_desc* o, const hftt_ffn_desc* f, void* stream) {
+  HFTT_REQUIRE(o != nullptr && f != nullptr, "attn_out_ffn_fwd: null descriptor");
+  return hftt_x3_attn_out_ffn(*o, *f, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int hftt_ffn_bwd_dx(const hftt_ffn_desc* d, void* stream) {
   if (d != nullptr && (d->flags & (HFTT_SL_X3_F16 | HFTT_SL_X3_BF16))) {
     if (int rc = check_ffn_x3(d, 1, "ffn_bwd_dx")) return rc;

@@ -349,6 +349,8 @@ __device__ __forceinline__ void load16h(const unsigned short* p, float* v) {    
 }
 
 // LayerNorm over the 256 features of the lane's token (lane: 128 of them in acc, partner lane ^ 32 the rest), fp32 out
+// KEEP: the normalised rows stay in acc (the fused fc_o + FFN kernel feeds them to the next GEMM); y_wave may then be NULL (nothing stored)
+template <bool KEEP = false>
 __device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_lds, const float* beta_lds, int h, float* mean_out, float* rstd_out,
                                            long tok, bool ok, float* stage, int j, int lane, float* pre_wave, float* y_wave, long ld,
                                            unsigned short* pre16_wave = nullptr) {
@@ -379,7 +381,11 @@ __device__ __forceinline__ void x3_ln_rows(f32x16 (&acc)[8], const float* gamma_
     lds16f(beta_lds + ot * 32 + 16 * h, be);
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = (v[q] - mean) * rstd * ga[q] + be[q];
-    tile_store_rows(stage, v, j, h, lane, y_wave + ot * 32, ld, ok);
+    if (!KEEP || y_wave != nullptr) tile_store_rows(stage, v, j, h, lane, y_wave + ot * 32, ld, ok);
+    if (KEEP) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[ot][q] = v[q];
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -871,6 +877,219 @@ __global__ __launch_bounds__(256, 1) void x3_mlp_kernel(const hftt_ffn_desc g) {
   P.drain();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fc_o + dropout + residual + LayerNorm  ->  FFN + residual + LayerNorm on ONE strip (hftt_attn_out_ffn_fwd, d = 256, p = 512, fp16 halves):
+// the two halves of an encoder / decoder layer behind its attention as one launch.  Phase A is x3_linear_kernel<X3_F16, true, 1, 1, true>'s block
+// (16 K-outer slots of fc_o, its epilogue), phase B x3_mlp_kernel<0>'s (64 slots); the LayerNorm output of phase A stays in the accumulator
+// registers, is split into the strip's (hi, lo) chunks there and never read back from memory -- in the inference plan it is not even written.
+// One weight stream of 80 slots per block: fc_o (order 0), then the FFN's interleaved pair.  Results are bit-identical to the two launches.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool HH>
+__global__ __launch_bounds__(256, 1) void x3_oln_mlp_kernel(const hftt_strip_desc o, const hftt_ffn_desc g) {
+  constexpr int E = X3_F16, PT = 16, p = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const long nblk = ((long)g.M + 127) / 128;
+  float* prm = reinterpret_cast<float*>(smem + RING_BYTES);      // bo[256] | gamma1[256] | beta1[256] | b1[512] | b2[256] | gamma2[256] | beta2[256] | store patches
+  float* stage = reinterpret_cast<float*>(smem + RING_BYTES + 4 * 2048 + wave * STG_BYTES_PER_WAVE);
+  const float* cxb = reinterpret_cast<const float*>(o.x);        // the attention output (phase A's strip)
+  float* y1b = reinterpret_cast<float*>(o.C);                    // LayerNorm-1 output: stored for the backward (training plan) or not at all (NULL)
+  float* pre1b = reinterpret_cast<float*>(o.pre_ln_out);
+  const float* r1b = reinterpret_cast<const float*>(o.residual);
+  float* yb = reinterpret_cast<float*>(g.y);
+  float* preb = reinterpret_cast<float*>(g.pre_ln_out);
+  float* hob = reinterpret_cast<float*>(g.h_out);
+  unsigned short* hob16 = reinterpret_cast<unsigned short*>(g.h_out);
+
+  XPipe P;
+  P.w = o.w; P.S = 16 + 4 * PT; P.fill_pos = 0;
+  P.ring = (unsigned)(uintptr_t)HFTT_LDS_PTR(unsigned char, smem);
+  P.wave = wave; P.lane = lane;
+  P.nofill = false; P.nobar = false;
+
+  auto tok_of = [&](long blk) { const long t = blk * 128 + wave * 32 + j; return t < g.M ? t : (long)g.M - 1; };
+
+  prm[tid] = o.bias != nullptr ? o.bias[tid] : 0.f;
+  prm[256 + tid] = o.ln_gamma[tid]; prm[512 + tid] = o.ln_beta[tid];
+  for (int i = tid; i < p; i += 256) prm[768 + i] = g.b1 != nullptr ? g.b1[i] : 0.f;
+  prm[1280 + tid] = g.b2 != nullptr ? g.b2[tid] : 0.f;
+  prm[1536 + tid] = g.ln_gamma[tid]; prm[1792 + tid] = g.ln_beta[tid];
+
+  XChunk xr[16];
+  {
+    const float* p0 = cxb + tok_of(blockIdx.x) * o.ldx + 16 * h;
+#pragma unroll
+    for (int c = 0; c < 16; c++) chunk_load(xr[c], p0 + chunk_off(c));
+  }
+  P.fill<0>(); P.fill<1>(); P.fill<2>();
+  static_assert(FILL_AHEAD == 3, "prologue fills");
+  wait_lgkm0();
+  P.prologue_sync();
+
+  const uint32_t thr_a = hftt_keep_thr(o.drop_p), thr = hftt_keep_thr(g.drop_p);
+  const float inv_keep_a = hftt_keep_scale(o.drop_p), inv_keep = hftt_keep_scale(g.drop_p);
+  const unsigned char* abase = smem + lane * 16;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int hb = h;
+    asm volatile("" : "+v"(hb));
+    const long tok = blk * 128 + wave * 32 + j;
+    const bool wave_ok = (blk * 128 + wave * 32) < g.M;
+    const long tokc = tok_of(blk);
+    const long nxt = blk + gridDim.x;
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    const float* prm_b = prm + zero;
+
+    // ======== phase A: fc_o over the attention-output strip (loaded by the previous block's last epilogue, or the prologue) ========
+    chunk_convert<E>(xr[0]);
+    {
+      f32x16 acc[8];
+#pragma unroll
+      for (int ot = 0; ot < 8; ot++) {
+        float b[16];
+        lds16f(prm_b + ot * 32 + 16 * hb, b);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[ot][q] = b[q];
+      }
+      XPre pre;
+      slot_head(abase, pre);
+      static_for<16>([&](auto c_c) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_c)::value;
+        constexpr int BUF = c & 3;
+        P.begin_slot();
+        x3_slot_tiles<E>(abase + BUF * SLOT_BYTES, abase + ((BUF + 1) & 3) * SLOT_BYTES, pre, xr[c], acc, [&](auto i_c) __attribute__((always_inline)) {
+          constexpr int i = decltype(i_c)::value;
+          if (i == 1) P.template refill<BUF>();
+          if (i == 9 && c < 15) chunk_convert<E>(xr[c + 1]);
+        });
+      });
+      // ---- epilogue A: scale, dropout (the attention branch's output site), residual = the layer input, LayerNorm 1 ----
+      const uint64_t rowq_a = ((uint64_t)tok * 256ull) >> 2;
+      const long rrow = o.res_mod > 0 ? (long)((unsigned)tokc % (unsigned)o.res_mod) : tokc;
+      const float* rrow_p = r1b + rrow * o.ldr + 16 * hb;
+      float rnext[16];
+      load16f(rrow_p, rnext);
+#pragma unroll
+      for (int ot = 0; ot < 8; ot++) {
+        const int col0 = ot * 32 + 16 * hb;
+        float v[16], r[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) r[q] = rnext[q];
+        if (ot < 7) load16f(rrow_p + (ot + 1) * 32, rnext);
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = acc[ot][q] * o.out_scale;
+        if (o.drop_p > 0.f) drop16(v, o.drop_seed, o.drop_site, rowq_a + (col0 >> 2), thr_a, inv_keep_a);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[ot][q] = v[q] + r[q];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bool p16a = o.flags & HFTT_SL_PRE_BF16;
+      x3_ln_rows<true>(acc, prm_b + 256, prm_b + 512, hb, o.ln_mean, o.ln_rstd, tok, wave_ok, stage, j, lane,
+                       (pre1b != nullptr && !p16a) ? pre1b + (blk * 128 + wave * 32) * o.ldc : nullptr,
+                       y1b != nullptr ? y1b + (blk * 128 + wave * 32) * o.ldc : nullptr, o.ldc,
+                       (pre1b != nullptr && p16a) ? reinterpret_cast<unsigned short*>(pre1b) + (blk * 128 + wave * 32) * o.ldc : nullptr);
+      // the normalised rows become the FFN's strip: accumulator register q of tile ot is feature 32 ot + 16 h + q = chunk 2 ot + (q >> 3), element q & 7
+#pragma unroll
+      for (int ot = 0; ot < 8; ot++) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          xr[2 * ot + u].a = u4v{__float_as_uint(acc[ot][8 * u]), __float_as_uint(acc[ot][8 * u + 1]), __float_as_uint(acc[ot][8 * u + 2]), __float_as_uint(acc[ot][8 * u + 3])};
+          xr[2 * ot + u].b = u4v{__float_as_uint(acc[ot][8 * u + 4]), __float_as_uint(acc[ot][8 * u + 5]), __float_as_uint(acc[ot][8 * u + 6]), __float_as_uint(acc[ot][8 * u + 7])};
+          chunk_convert<E>(xr[2 * ot + u]);
+        }
+      }
+    }
+
+    // ======== phase B: the FFN block of x3_mlp_kernel<0> on the strip in the registers ========
+    const float* xrow_next = cxb + (nxt < nblk ? tok_of(nxt) : tokc) * o.ldx + 16 * hb;
+    const uint64_t rowq_h = ((uint64_t)tok * (uint64_t)p) >> 2;
+    f32x16 yacc[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ot++) {
+      float b[16];
+      lds16f(prm_b + 1280 + ot * 32 + 16 * hb, b);
+#pragma unroll
+      for (int q = 0; q < 16; q++) yacc[ot][q] = b[q];
+    }
+    XPre pre;
+    slot_head(abase, pre);
+    for (int t = 0; t < PT; t++) {
+      f32x16 hacc;
+      {
+        float b[16];
+        lds16f(prm_b + 768 + t * 32 + 16 * hb, b);
+#pragma unroll
+        for (int q = 0; q < 16; q++) hacc[q] = b[q];
+      }
+      P.begin_slot();
+      x3_slot_chunks<E, 0>(abase + 0 * SLOT_BYTES, abase + 1 * SLOT_BYTES, pre, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<0>();
+      });
+      P.begin_slot();
+      x3_slot_chunks<E, 8>(abase + 1 * SLOT_BYTES, abase + 2 * SLOT_BYTES, pre, xr, hacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<1>();
+      });
+      float v[16];
+      const int hcol0 = t * 32 + 16 * hb;
+#pragma unroll
+      for (int q = 0; q < 16; q++) v[q] = fmaxf(hacc[q], 0.f);
+      if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_h, rowq_h + (hcol0 >> 2), thr, inv_keep);
+      XChunk hf[2];
+      {
+        bf16x8 hi, lo;
+        x3_split8<E>(v, hi, lo);
+        hf[0].a = __builtin_bit_cast(u4v, hi); hf[0].b = __builtin_bit_cast(u4v, lo);
+        x3_split8<E>(v + 8, hi, lo);
+        hf[1].a = __builtin_bit_cast(u4v, hi); hf[1].b = __builtin_bit_cast(u4v, lo);
+      }
+      const bool st_h = hob != nullptr;
+      float* hwave = hob + (blk * 128 + wave * 32) * g.ldh + t * 32;
+      unsigned short* hwave16 = hob16 + (blk * 128 + wave * 32) * g.ldh + t * 32;
+      P.begin_slot();
+      x3_slot_tiles<E>(abase + 2 * SLOT_BYTES, abase + 3 * SLOT_BYTES, pre, hf[0], yacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<2>();
+        if (i == 4 && st_h) {
+          if (HH) tile_store_rows_bf16(stage, v, j, hb, lane, hwave16, g.ldh, wave_ok);
+          else tile_store_rows(stage, v, j, hb, lane, hwave, g.ldh, wave_ok);
+        }
+      });
+      P.begin_slot();
+      x3_slot_tiles<E>(abase + 3 * SLOT_BYTES, abase + 0 * SLOT_BYTES, pre, hf[1], yacc, [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if (i == 1) P.template refill<3>();
+      });
+    }
+    // ---- final epilogue: output dropout, residual = the strip (hi + lo), LayerNorm 2; the strip registers take the NEXT block's attention output ----
+    const uint64_t rowq = ((uint64_t)tok * 256ull) >> 2;
+    float* ywave = yb + (blk * 128 + wave * 32) * g.ldy;
+#pragma unroll
+    for (int ot = 0; ot < 8; ot++) {
+      const int col0 = ot * 32 + 16 * hb;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) v[q] = yacc[ot][q];
+      if (g.drop_p > 0.f) drop16(v, g.drop_seed, g.site_o, rowq + (col0 >> 2), thr, inv_keep);
+      float r[16];
+      chunk_values<E>(xr[2 * ot], r); chunk_values<E>(xr[2 * ot + 1], r + 8);
+#pragma unroll
+      for (int q = 0; q < 16; q++) yacc[ot][q] = v[q] + r[q];
+      chunk_load(xr[2 * ot], xrow_next + chunk_off(2 * ot));
+      chunk_load(xr[2 * ot + 1], xrow_next + chunk_off(2 * ot + 1));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool p16 = g.flags & HFTT_SL_PRE_BF16;
+    x3_ln_rows(yacc, prm_b + 1536, prm_b + 1792, hb, g.ln_mean, g.ln_rstd, tok, wave_ok, stage, j, lane,
+               (preb != nullptr && !p16) ? preb + (blk * 128 + wave * 32) * g.ldy : nullptr, ywave, g.ldy,
+               (preb != nullptr && p16) ? reinterpret_cast<unsigned short*>(preb) + (blk * 128 + wave * 32) * g.ldy : nullptr);
+  }
+  P.drain();
+}
+
 int n_cus() {
   static int n = 0;
   if (n == 0) {
@@ -930,6 +1149,19 @@ int launch_xm(const hftt_ffn_desc& d, hipStream_t st) {
   const long nblk = ((long)d.M + 127) / 128;
   hipLaunchKernelGGL((x3_mlp_kernel<MODE, 16, HH, GH>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, d);
   HFTT_CHECK_LAUNCH("x3_strip_mlp");
+  return 0;
+}
+
+template <bool HH>
+int launch_xom(const hftt_strip_desc& o, const hftt_ffn_desc& d, hipStream_t st) {
+  const int lds = RING_BYTES + 4 * 2048 + 4 * STG_BYTES_PER_WAVE;
+  static int attr = 0;
+  if (lds > attr) { if (int rc = set_lds(x3_oln_mlp_kernel<HH>, lds, "x3_attn_out_ffn")) return rc; attr = lds; }
+  const int cus = n_cus();
+  if (cus <= 0) { hftt_set_error("x3_attn_out_ffn: device query failed"); return 2; }
+  const long nblk = ((long)d.M + 127) / 128;
+  hipLaunchKernelGGL((x3_oln_mlp_kernel<HH>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(256), lds, st, o, d);
+  HFTT_CHECK_LAUNCH("x3_attn_out_ffn");
   return 0;
 }
 
@@ -1049,6 +1281,26 @@ int hftt_x3_strip_mlp(const hftt_ffn_desc& d0, hipStream_t st) {
 #endif
   return launch_xm<1, false, false>(d, st);
 }
+
+// hftt_attn_out_ffn_fwd: the fc_o + LayerNorm descriptor and the FFN descriptor of the two launches it replaces, unchanged, with o.C (the
+// LayerNorm-1 output) optional and the two weight streams adjacent (fc_o's 16 slots, then the FFN's 64)
+int hftt_x3_attn_out_ffn(const hftt_strip_desc& o, const hftt_ffn_desc& d, hipStream_t st) {
+  HFTT_REQUIRE(o.M == d.M && o.M > 0 && o.M % 32 == 0 && o.N == 256 && o.K == 256 && d.d == 256 && d.p == 512 && d.mode == 0,
+               "attn_out_ffn_fwd: needs M %% 32 == 0, fc_o 256 -> 256, FFN d = 256, p = 512, mode 0 (M=%d/%d N=%d K=%d d=%d p=%d mode=%d)", o.M, d.M, o.N, o.K, d.d, d.p, d.mode);
+  HFTT_REQUIRE((o.flags & HFTT_SL_X3_F16) && (d.flags & HFTT_SL_X3_F16) && !((o.flags | d.flags) & (HFTT_SL_X3_BF16 | HFTT_SL_X_BF16 | HFTT_SL_C_BF16 | HFTT_SL_RES_BF16 | HFTT_SL_RELU | HFTT_SL_C_F16PAIR | HFTT_SL_X_DROP | HFTT_SL_X3_GRAD_HI)),
+               "attn_out_ffn_fwd: both descriptors in the forward split mode (HFTT_SL_X3_F16), fp32 tensors");
+  HFTT_REQUIRE(o.x != nullptr && o.w != nullptr && o.residual != nullptr && o.gate == nullptr && o.ln_gamma != nullptr && o.ln_beta != nullptr,
+               "attn_out_ffn_fwd: the first half is fc_o + residual + LayerNorm (x, w, residual, gamma, beta; no gate)");
+  HFTT_REQUIRE(d.w == o.w + 16 * 16 * 512, "attn_out_ffn_fwd: the FFN's weight stream must follow fc_o's 16 slots (one stream of 80 slots per block)");
+  HFTT_REQUIRE(d.residual == nullptr && d.y != nullptr && d.ln_gamma != nullptr && d.ln_beta != nullptr && d.ldy == 256, "attn_out_ffn_fwd: FFN half needs y, gamma, beta, ldy == 256 and no residual pointer (the residual is the strip)");
+  HFTT_REQUIRE(o.C == nullptr || o.C == d.x, "attn_out_ffn_fwd: the FFN's input IS the first half's output (o.C == f.x, or o.C == NULL when it is not stored)");
+  HFTT_REQUIRE(o.ldx % 4 == 0 && o.ldc % 4 == 0 && o.ldr % 4 == 0 && (d.h_out == nullptr || d.ldh % ((d.flags & HFTT_SL_H_BF16) ? 8 : 4) == 0), "attn_out_ffn_fwd: rows must be 16-byte aligned");
+  HFTT_REQUIRE((((uintptr_t)o.x | (uintptr_t)o.w | (uintptr_t)o.C | (uintptr_t)o.residual | (uintptr_t)o.pre_ln_out | (uintptr_t)d.y | (uintptr_t)d.h_out | (uintptr_t)d.pre_ln_out) & 15) == 0,
+               "attn_out_ffn_fwd: operands must be 16-byte aligned");
+  HFTT_REQUIRE(o.drop_p >= 0.f && o.drop_p < 1.f && d.drop_p >= 0.f && d.drop_p < 1.f && (long)d.M * d.p < (1L << 33), "attn_out_ffn_fwd: drop_p / M out of range");
+  return (d.flags & HFTT_SL_H_BF16) ? launch_xom<true>(o, d, st) : launch_xom<false>(o, d, st);
+}
+
 
 extern "C" int hftt_x3_strip_pack(const float* params, uint16_t* wstrip, const hftt_strip_pack_entry* table_dev, int n_entries, int elem, void* stream) {
   HFTT_REQUIRE(params != nullptr && wstrip != nullptr && table_dev != nullptr && n_entries > 0, "x3_strip_pack: null argument");

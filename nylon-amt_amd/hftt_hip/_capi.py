@@ -164,6 +164,7 @@ SIGNATURES = {
     'hftt_strip_linear': (C.c_int, [C.POINTER(StripDesc), C.c_void_p]),
     'hftt_ffn_res_ln_fwd': (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
     'hftt_ffn_bwd_dx': (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
+    'hftt_attn_out_ffn_fwd': (C.c_int, [C.POINTER(StripDesc), C.POINTER(FfnDesc), C.c_void_p]),
     'hftt_gemm_tn_ws_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'hftt_gemm_tn': (C.c_int, [C.POINTER(GemmTnDesc), C.c_void_p]),
     'hftt_attn_fwd': (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
@@ -195,7 +196,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HfttError(RuntimeError):

@@ -100,6 +100,9 @@ class HfttEngine:
         # x3 strip plans (d = 256): the LayerNorm backward writes NO dropout-masked copy of its result; its consumers -- the weight-gradient
         # product (HFTT_TN_DY_DROP), the fused FFN's dX (site_o) and the fc_o dX (HFTT_SL_X_DROP) -- apply the mask while they load dr
         self.ln_mask_in_consumers_opt = os.environ.get('HFTT_X3_LN_MASK_IN_CONSUMERS', '1') != '0'
+        # round 6 (ABI v8): fc_o + residual + LayerNorm and the FFN block behind it as ONE launch (hftt_attn_out_ffn_fwd) -- 'all' in both forward plans,
+        # 'inference' only in the plan that writes nothing in between, '0' never
+        self.fuse_offn_opt = os.environ.get('HFTT_X3_FUSE_OFFN', 'all')
         self.set_precision(precision)
         self.dropout = float(dropout)
         # The device generator decides per element with ONE byte of a hash word (csrc/hftt_common.h: hftt_keep_thr), so the keep probability is
@@ -342,8 +345,8 @@ class HfttEngine:
             else:
                 spack(key + '.qkv', [(wq, 0, 0), (wk, d, 0), (wv, 2 * d, 0)], d, order=tm, numel=3 * d * d)
                 spack(key + '.qkv_t', [(wq, 0, 0), (wk, 0, d), (wv, 0, 2 * d)], 3 * d, transpose=True, numel=3 * d * d)
-            spack(key + '.o', [(wo, 0, 0)], d, numel=d * d)
             spack(key + '.o_t', [(wo, 0, 0)], d, transpose=True, order=tm, numel=d * d)
+            spack(key + '.o', [(wo, 0, 0)], d, numel=d * d)       # LAST: the block's FFN stream follows it (hftt_attn_out_ffn_fwd reads the two as one)
 
         def strip_ffn(pre, key):
             if self.strip_small:
@@ -1023,8 +1026,36 @@ class HfttEngine:
         logits_t = self._buf(ws, 'logits_t', Sn, self.NHp)
         self._nt(plan, ws, Sn, self.NH, d, y, d, self.Wp('heads_t'), self.Fp('heads_t_b'), logits_t.data_ptr(), self.NHp, a_bf=bs)
         plan.append(('heads', (logits_t.data_ptr(), 1), 'heads_split', None))
+        if self.x3 and self.strip and not self.strip_small and (self.fuse_offn_opt == 'all' or (self.fuse_offn_opt == 'inference' and not save)):
+            plan = self._fuse_attn_out_ffn(plan, save)
         ws['fwd' if save else 'fwd_inf'] = plan
         ws['enc'] = enc
+
+    def _fuse_attn_out_ffn(self, plan, save):
+        """Peephole over a forward plan: hftt_strip_linear (fc_o + dropout + residual + LayerNorm, 256 -> 256) directly followed by the
+        hftt_ffn_res_ln_fwd that reads its output becomes ONE hftt_attn_out_ffn_fwd launch on the same two descriptors (their dropout sites, saved
+        tensors and statistics unchanged); in the inference plan the LayerNorm-1 output is not written at all."""
+        out, i = [], 0
+        while i < len(plan):
+            e = plan[i]
+            nx = plan[i + 1] if i + 1 < len(plan) else None
+            if nx is not None and e[2] == 'strip_linear' and nx[2] == 'ffn_fwd':
+                o, f = e[1][0]._obj, nx[1][0]._obj
+                if (o.ln_gamma and o.N == 256 and o.K == 256 and o.residual and f.mode == 0 and f.d == 256 and f.p == 512 and f.x == o.C
+                        and f.w == o.w + 2 * 2 * 256 * 256 and not o.gate and not f.residual):
+                    if not save:
+                        o.C = 0                           # (x1 lives in registers only)
+                    mo, mf = e[3], nx[3]
+                    M = o.M
+                    meta = {'kernel': 'x3_oln_mlp_kernel<%s>' % ('true' if self.hh else 'false'), 'flops': mo['flops'] + mf['flops'],
+                            'bytes': mo['bytes'] + mf['bytes'] - 4.0 * M * 256 * (1 if save else 2), 'shape': (M, 256, 512), 'saves': mf.get('saves', False),
+                            'fused': ('strip_linear', 'ffn_fwd'), 'ffn_flops': mf['flops']}
+                    out.append((self.lib.hftt_attn_out_ffn_fwd, (e[1][0], nx[1][0]), 'ffn_fwd', meta))
+                    i += 2
+                    continue
+            out.append(e)
+            i += 1
+        return out
 
     # ---- backward of one EncoderLayer; dx_out lives in GA on entry (grad of the layer output) and on exit (grad of input)
     def _enc_layer_bwd(self, plan, ws, tag, key, pre, S, n_seq, L, H, x_in, G, extra_dx=0, in_bf=False, gbf=False, out_bf=False):

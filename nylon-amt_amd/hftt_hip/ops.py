@@ -252,6 +252,52 @@ def ffn_res_ln_fwd(x, wpack, p, b1, b2, gamma, beta, drop_p=0.0, site_h=0, site_
     return y, hid, pre, mean, rstd
 
 
+def x3_attn_out_ffn_pack(wo: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor):
+    """The weight stream of hftt_attn_out_ffn_fwd: fc_o's 16 slots (order 0), then the fused FFN's interleaved stream (x3_ffn_pack), fp16 halves."""
+    out = torch.zeros(2 * (wo.numel() + w1.numel() + w2.numel()), dtype=torch.int16, device=wo.device)
+    x3_strip_pack(wo, 2, False, 0, out[:2 * wo.numel()])
+    x3_strip_pack(w1, 2, False, 1, out[2 * wo.numel():], 4, 0)
+    x3_strip_pack(w2, 2, False, 0, out[2 * wo.numel():], 4, 2)
+    return out
+
+
+def attn_out_ffn_fwd(ctx, wpack, bo, residual, gamma1, beta1, p, b1, b2, gamma2, beta2, drop_p=0.0, site_a=0, site_h=0, site_o=0, seed=0, res_mod=0,
+                     save=True, hidden_bf16=False, pre_bf16=False):
+    """hftt_attn_out_ffn_fwd (x3): x1 = LN1(residual + drop(ctx @ Wo.T + bo)); y = LN2(x1 + drop(FFN(x1))) as ONE launch.
+    save=True (training plan) -> (y, x1, pre1, mean1, rstd1, hidden, pre2, mean2, rstd2); save=False (inference plan) -> y only, x1 is never written."""
+    _need_cuda(ctx, wpack, residual)
+    M, dm = ctx.shape
+    dev = ctx.device
+    y = torch.empty(M, dm, device=dev)
+    mean1 = torch.empty(M, device=dev); rstd1 = torch.empty(M, device=dev); mean2 = torch.empty(M, device=dev); rstd2 = torch.empty(M, device=dev)
+    x1 = torch.empty(M, dm, device=dev) if save else None
+    pre1 = torch.empty(M, dm, device=dev, dtype=BF16 if pre_bf16 else torch.float32) if save else None
+    pre2 = torch.empty(M, dm, device=dev, dtype=BF16 if pre_bf16 else torch.float32) if save else None
+    hid = torch.empty(M, p, device=dev, dtype=BF16 if hidden_bf16 else torch.float32) if save else None
+    o = StripDesc()
+    o.M, o.N, o.K = M, dm, dm
+    o.flags = SL_X3_F16 | (SL_PRE_BF16 if pre_bf16 else 0)
+    o.x, o.ldx, o.w, o.bias = ctx.data_ptr(), ctx.stride(0), wpack.data_ptr(), bo.data_ptr()
+    o.C, o.ldc, o.out_scale, o.gate_scale = (x1.data_ptr() if save else 0), dm, 1.0, 1.0
+    o.drop_p, o.drop_site, o.drop_seed = drop_p, site_a, seed
+    o.residual, o.ldr, o.res_mod = residual.data_ptr(), residual.stride(0), res_mod
+    o.ln_gamma, o.ln_beta = gamma1.data_ptr(), beta1.data_ptr()
+    o.pre_ln_out, o.ln_mean, o.ln_rstd = (pre1.data_ptr() if save else 0), mean1.data_ptr(), rstd1.data_ptr()
+    f = FfnDesc()
+    f.M, f.d, f.p, f.flags, f.mode = M, dm, p, SL_X3_F16 | (SL_H_BF16 if hidden_bf16 else 0) | (SL_PRE_BF16 if pre_bf16 else 0), 0
+    f.x, f.ldx, f.w = (x1.data_ptr() if save else y.data_ptr()), dm, wpack.data_ptr() + 2 * (2 * dm * dm)      # (f.x is not read: the strip comes from the registers)
+    f.b1, f.b2 = b1.data_ptr(), b2.data_ptr()
+    if save:
+        f.h_out, f.ldh = hid.data_ptr(), p
+    f.drop_p, f.site_h, f.site_o, f.drop_seed = drop_p, site_h, site_o, seed
+    f.ln_gamma, f.ln_beta = gamma2.data_ptr(), beta2.data_ptr()
+    f.pre_ln_out = pre2.data_ptr() if save else 0
+    f.ln_mean, f.ln_rstd = mean2.data_ptr(), rstd2.data_ptr()
+    f.y, f.ldy = y.data_ptr(), dm
+    check(lib().hftt_attn_out_ffn_fwd(C.byref(o), C.byref(f), _stream(dev)), 'attn_out_ffn_fwd')
+    return (y, x1, pre1, mean1, rstd1, hid, pre2, mean2, rstd2) if save else y
+
+
 def ffn_bwd_dx(dy, wpack_bwd, p, hidden, gate_scale=1.0, residual=None, x3=False, grad_hi=False, dy_drop=None):
     """dh = (hidden > 0) * (dy @ fc_2.weight) * gate_scale;  dx = dh @ fc_1.weight (+ residual) -> (dx, dh); all bf16 (x3: all fp32).
     dy_drop = (p, site, seed) (x3): dy is the gradient of the block's OUTPUT dropout and is masked with that site while it is loaded."""

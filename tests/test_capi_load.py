@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(_capi.SIGNATURES.keys()), declared ^ set(_capi.SIGNATURES.keys())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hftt_abi_version() == _capi.ABI_VERSION == 7
+    assert lib.hftt_abi_version() == _capi.ABI_VERSION == 8
     assert lib.hftt_last_error() is not None
     # pure host helpers can be called without a GPU
     assert lib.hftt_gemm_tn_ws_bytes(1000, 256, 256) > 0

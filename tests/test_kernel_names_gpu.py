@@ -61,4 +61,5 @@ def test_inference_plan_kernel_names_are_the_traced_symbols(dev, tmp_path):
         assert not missing, (mode, missing)
         ffn = [e for e in plans['inference:%s' % mode] if '_mlp' in e[0]]
         assert len(ffn) == 9 and ffn[0][1][0] == 8 * 128 * 256          # three encoder launches at S_e, six at S_n
-    assert any(n.startswith('strip_mlp2_kernel<0, 16, false>') for n in traced) and any(n.startswith('x3_mlp_kernel<0, 16') for n in traced)
+    # (x3: fc_o + LayerNorm + FFN as one launch, the default since round 6 -- or the FFN block alone with HFTT_X3_FUSE_OFFN=0)
+    assert any(n.startswith('strip_mlp2_kernel<0, 16, false>') for n in traced) and any(n.startswith(('x3_oln_mlp_kernel<', 'x3_mlp_kernel<0, 16')) for n in traced)

@@ -377,7 +377,9 @@ def test_dropout_on_outputs_and_gradients_with_the_device_masks_exported_to_the_
             assert eng.strip_small and ws['strip'] and any('x3s_mlp_kernel<0' in k for k in fk) and any('x3s_mlp_kernel<1' in k for k in bk)
         else:
             assert eng.strip and ws['strip'] and not eng.strip_small
-            assert any(k.startswith('x3_mlp_kernel<0, 16') for k in fk) and any(k.startswith('x3_mlp_kernel<1, 16') for k in bk)
+            # (forward: the FFN block alone, or -- the default since round 6 -- fc_o + LayerNorm + FFN as one launch, hftt_attn_out_ffn_fwd)
+            assert any(k.startswith('x3_oln_mlp_kernel<' if eng.fuse_offn_opt == 'all' else 'x3_mlp_kernel<0, 16') for k in fk)
+            assert any(k.startswith('x3_mlp_kernel<1, 16') for k in bk)
             assert any(k.startswith('x3p_attn_fwd_kernel') for k in fk)
             if case == 'x3_256_long':       # the kernels of bench.py's step, dropout form 1 (one hash per key quad)
                 assert 'x3_attn_bwd_kernel<8, 64, true, 1>' in bk and 'x3p_attn_fwd_kernel<8, 8, false, 1>' in fk

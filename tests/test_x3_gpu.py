@@ -591,6 +591,37 @@ def test_small_strip_linear_layernorm(dev, elem):
 
 
 @pytest.mark.parametrize('hbf', [False, True])
+@pytest.mark.parametrize('M,res_mod', [(256, 0), (4096 + 96, 0), (33024, 0), (1056, 88)])
+def test_attention_output_and_ffn_as_one_launch_equal_the_two_launches_bit_for_bit(dev, M, res_mod, hbf):
+    """hftt_attn_out_ffn_fwd (ABI v8) == hftt_strip_linear (fc_o + dropout + residual + LayerNorm) followed by hftt_ffn_res_ln_fwd: every stored
+    tensor bit for bit, in the training form (everything a backward needs is written) and in the inference form (x1 is never written); the two
+    launches themselves are held against fp64 by test_strip_linear_layernorm and test_fused_ffn_forward_and_dx.  33,024 tokens = 258 blocks for
+    256 resident workgroups; res_mod: the broadcast residual of the decoder's layer zero."""
+    ops = _ops()
+    d, pf = 256, 512
+    g = torch.Generator().manual_seed(M + 7)
+    ctx = torch.randn(M, d, generator=g); Wo = torch.randn(d, d, generator=g) / 16.0; bo = torch.randn(d, generator=g) * 0.3
+    res = torch.randn(res_mod or M, d, generator=g)
+    W1 = torch.randn(pf, d, generator=g) / 16.0; W2 = torch.randn(d, pf, generator=g) / 22.0
+    b1 = torch.randn(pf, generator=g) * 0.3; b2 = torch.randn(d, generator=g) * 0.3
+    g1, be1, g2, be2 = (torch.randn(d, generator=g) for _ in range(4))
+    p, sa, sh, so, seed = 0.1, 20, 21, 22, 777
+    D = lambda t: t.to(dev)
+    x1, pre1, m1, r1 = ops.strip_linear(D(ctx), ops.x3_strip_pack(D(Wo), 2), d, D(bo), drop_p=p, drop_site=sa, drop_seed=seed, residual=D(res), res_mod=res_mod,
+                                        ln=(D(g1), D(be1)), x3=2, pre_bf16=hbf)
+    y, hid, pre2, m2, r2 = ops.ffn_res_ln_fwd(x1, ops.x3_ffn_pack(D(W1), D(W2)), pf, D(b1), D(b2), D(g2), D(be2), drop_p=p, site_h=sh, site_o=so, seed=seed, x3=True,
+                                              hidden_bf16=hbf, pre_bf16=hbf)
+    wp = ops.x3_attn_out_ffn_pack(D(Wo), D(W1), D(W2))
+    got = ops.attn_out_ffn_fwd(D(ctx), wp, D(bo), D(res), D(g1), D(be1), pf, D(b1), D(b2), D(g2), D(be2), drop_p=p, site_a=sa, site_h=sh, site_o=so, seed=seed,
+                               res_mod=res_mod, hidden_bf16=hbf, pre_bf16=hbf)
+    for name, a, b_ in zip(('y', 'x1', 'pre1', 'mean1', 'rstd1', 'hidden', 'pre2', 'mean2', 'rstd2'), got, (y, x1, pre1, m1, r1, hid, pre2, m2, r2)):
+        assert a.dtype == b_.dtype and torch.equal(a, b_), name
+    y_inf = ops.attn_out_ffn_fwd(D(ctx), wp, D(bo), D(res), D(g1), D(be1), pf, D(b1), D(b2), D(g2), D(be2), drop_p=p, site_a=sa, site_h=sh, site_o=so, seed=seed,
+                                 res_mod=res_mod, save=False)
+    assert torch.equal(y_inf, y)
+
+
+@pytest.mark.parametrize('hbf', [False, True])
 @pytest.mark.parametrize('M', [256, 4096 + 96, 90112])
 def test_small_fused_ffn_forward_and_dx(dev, M, hbf):
     ops = _ops()
