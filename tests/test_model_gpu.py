@@ -515,6 +515,41 @@ def test_strip_kernels_match_the_round1_kernels_with_dropout_on(dev, monkeypatch
         assert st['gcos'] > r1['gcos'] - (0.03 if drop == '0.0' else 0.06), (drop, st, r1)
 
 
+def test_one_launch_for_attention_output_and_ffn_changes_no_bit_of_a_step(dev, monkeypatch):
+    """HFTT_X3_FUSE_OFFN: 'all' (default) joins fc_o + LayerNorm and the FFN behind it into hftt_attn_out_ffn_fwd in both forward plans, 'inference' only
+    in the plan that saves nothing, '0' never.  The joined launch is bit-identical to the two (tests/test_x3_gpu.py), so the nine outputs, the loss
+    and EVERY gradient of a dropout-on training step, and the outputs of an eval forward, must be bit-identical across the three settings -- at the
+    paper's width and depth (three decoder layers: the cross-attention output projections with a broadcast residual in layer zero)."""
+    from hftt_hip.trainer import TrainStep
+    cfg = O.HfttConfig(n_frame=16, n_bin=32, n_note=8, **dict(_WIDE, enc_layer=2, dec_layer=3))
+    B = 2
+    x = (O.synth_spec(B, cfg, salt=41) * 0.5).to(dev)
+    ld = _to_dev(O.synth_labels(B, cfg, salt=42), dev)
+    res = {}
+    for mode in ('0', 'inference', 'all'):
+        monkeypatch.setenv('HFTT_X3_FUSE_OFFN', mode)
+        model = util.build_model(cfg, 9, dropout=0.1).to(dev)
+        model.hftt_precision = 'x3'
+        model.train()
+        ts = TrainStep(model, lr=1e-3)
+        loss = ts.forward_backward(x, *ld)
+        eng = ts.engine
+        n_tr = sum('x3_oln_mlp_kernel' in (m or {}).get('kernel', '') for _, _, _, m in eng._ws[B]['fwd'])
+        assert n_tr == (cfg.enc_layer + 2 * cfg.dec_layer if mode == 'all' else 0), (mode, n_tr)
+        tr = ([t.clone() for t in eng._ws[B]['outs']], loss[0].item(), eng.flat_grads.clone())
+        model.eval()
+        with torch.no_grad():
+            ev = [t.clone() for t in model(x)]
+        n_inf = sum('x3_oln_mlp_kernel' in (m or {}).get('kernel', '') for _, _, _, m in eng._ws[B]['fwd_inf'])
+        assert n_inf == (0 if mode == '0' else cfg.enc_layer + 2 * cfg.dec_layer), (mode, n_inf)
+        res[mode] = (tr, ev)
+    for mode in ('inference', 'all'):
+        (o0, l0, g0), e0 = res['0']
+        (o1, l1, g1), e1 = res[mode]
+        assert l0 == l1 and torch.equal(g0, g1) and all(torch.equal(a, b_) for a, b_ in zip(o0, o1)), mode
+        assert all(torch.equal(a, b_) for a, b_ in zip(e0, e1)), mode
+
+
 def test_backward_reports_gradient_buckets_when_final(dev):
     """HfttEngine.backward(on_ready=...) (the hook hftt_hip/ddp.py overlaps its all-reduce on): the three flat ranges tile
     the gradient buffer, and each range already holds its final value at the moment it is reported (stream-ordered
